@@ -1,0 +1,138 @@
+"""Synthetic nuScenes-shaped LiDAR scenes (SURVEY.md §8d "Synthetic scene").
+
+Reproduces the *output schema* of the reference loader
+(core/datasets/lc_semantic_nusc_tsd_full.py:415-433: ``voxel = round(xyz /
+0.05) - min``, de-duplicated keeping the first point, features
+``[x, y, z (m), intensity]`` un-normalised, label 0 = ignore) without the
+300 GB dataset.  numpy only; deterministic in ``seed``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ['synth_scene', 'synth_batch', 'CLASS_DISTRIBUTE', 'kmap_stats']
+
+# class frequencies in the spirit of lc_semantic_nusc_tsd_full.py:114-116
+# (17 classes, index 0 = ignore).
+CLASS_DISTRIBUTE = np.array(
+    [2.0, 0.2, 0.05, 0.6, 5.0, 0.2, 0.05, 0.3, 0.1, 1.0, 3.0, 35.0, 1.0, 8.0, 8.0, 20.0, 15.0],
+    dtype=np.float64)
+CLASS_DISTRIBUTE = CLASS_DISTRIBUTE / CLASS_DISTRIBUTE.sum()
+
+VOXEL_SIZE = 0.05
+
+
+def _lidar_sweep(rng: np.random.Generator, n_az: int, n_beams: int = 32):
+    """One LiDAR-like sweep: 32 elevation beams in [-30, +10] deg x n_az
+    azimuth steps; range = nearest of ground plane (z = -1.8 m), 64 radial wall
+    sectors and a few random boxes, out to 50 m; sigma = 2 cm range noise."""
+    elev = np.deg2rad(np.linspace(-30.0, 10.0, n_beams))
+    az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + rng.uniform(0, 2 * np.pi / n_az)
+    el, a = np.meshgrid(elev, az, indexing='ij')
+    dx, dy, dz = np.cos(el) * np.cos(a), np.cos(el) * np.sin(a), np.sin(el)
+    r = np.full(el.shape, 50.0)
+    down = dz < -1e-3
+    r_ground = np.where(down, -1.8 / np.where(down, dz, -1.0), np.inf)
+    r = np.minimum(r, r_ground)
+    # radial wall sectors (buildings): per azimuth sector a wall at a random distance
+    n_sec = 64
+    wall_r = rng.uniform(8.0, 45.0, n_sec)
+    wall_on = rng.uniform(size=n_sec) < 0.6
+    sec = ((a + np.pi) / (2 * np.pi) * n_sec).astype(np.int64) % n_sec
+    r_wall = np.where(wall_on[sec], wall_r[sec] / np.maximum(np.cos(el), 1e-3), np.inf)
+    wall_top = rng.uniform(2.0, 8.0, n_sec)
+    z_hit = r_wall * dz
+    r_wall = np.where(z_hit < wall_top[sec], r_wall, np.inf)
+    r = np.minimum(r, r_wall)
+    # a few boxes (vehicles): ray / axis-aligned box slab test
+    for _ in range(12):
+        c = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), -1.0])
+        half = np.array([rng.uniform(0.8, 2.5), rng.uniform(0.8, 2.5), 0.8])
+        lo, hi = c - half, c + half
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t1 = np.stack([lo[0] / dx, lo[1] / dy, lo[2] / dz])
+            t2 = np.stack([hi[0] / dx, hi[1] / dy, hi[2] / dz])
+        tmin = np.nanmax(np.minimum(t1, t2), axis=0)
+        tmax = np.nanmin(np.maximum(t1, t2), axis=0)
+        hit = (tmax >= tmin) & (tmin > 0.5)
+        r = np.where(hit, np.minimum(r, tmin), r)
+    valid = r < 49.9
+    r = r + rng.normal(0.0, 0.02, r.shape)
+    xyz = np.stack([r * dx, r * dy, r * dz], -1)[valid]
+    return xyz.astype(np.float32)
+
+
+def synth_scene(n_vox: int, seed: int = 1234, sweeps: int | None = None):
+    """Return a dict for one scene with exactly ``n_vox`` unique voxels:
+
+    ``coords`` int32 [n_vox,3] (voxel = round(xyz/0.05) - min), ``feats`` f32
+    [n_vox,4] = (x,y,z metres, intensity U[0,255)), ``labels`` int64 [n_vox]
+    (0 = ignore), ``keyframe`` bool [n_vox] (only sweep 0 is the key frame).
+
+    Azimuth density is the real sensor's (1085 steps x 32 beams = 34 720 rays
+    per sweep); larger scenes aggregate rigidly shifted sweeps (<= 0.5 m per
+    sweep) like the reference's multi-sweep loader
+    (lc_semantic_nusc_tsd_full.py:241-310).  ``sweeps=None`` adds sweeps until
+    ``n_vox`` unique voxels exist.
+    """
+    rng = np.random.default_rng(seed)
+    n_az = 1085
+    clouds = []
+    s = 0
+    while True:
+        p = _lidar_sweep(rng, n_az)
+        shift = np.array([0.37 * s, 0.11 * s, 0.0], dtype=np.float32)  # <= 0.5 m / sweep
+        clouds.append((p + shift, np.full(len(p), s == 0)))
+        s += 1
+        if sweeps is not None and s < sweeps:
+            continue
+        xyz = np.concatenate([c[0] for c in clouds])
+        kf = np.concatenate([c[1] for c in clouds])
+        vox = np.round(xyz / VOXEL_SIZE).astype(np.int32)
+        vox -= vox.min(0, keepdims=True)
+        # sparse_quantize semantics: keep the first point of every voxel
+        key64 = (vox[:, 0].astype(np.int64) << 40) | (vox[:, 1].astype(np.int64) << 20) | vox[:, 2].astype(np.int64)
+        _, first = np.unique(key64, return_index=True)
+        first.sort()
+        if len(first) >= n_vox:
+            break
+        if s > 64:
+            raise RuntimeError(f'synth_scene could not reach {n_vox} voxels')
+    sel = first[np.sort(rng.choice(len(first), n_vox, replace=False))]
+    xyz, vox, kf = xyz[sel], vox[sel], kf[sel]
+    vox = vox - vox.min(0, keepdims=True)
+    inten = rng.uniform(0, 255, (n_vox, 1)).astype(np.float32)
+    feats = np.concatenate([xyz, inten], 1).astype(np.float32)
+    labels = rng.choice(17, n_vox, p=CLASS_DISTRIBUTE).astype(np.int64)
+    return {'coords': np.ascontiguousarray(vox), 'feats': feats, 'labels': labels,
+            'keyframe': kf, 'sweeps': s}
+
+
+def synth_batch(n_vox: int, batch: int = 1, seed: int = 1234, sweeps: int | None = None):
+    """Collate ``batch`` scenes like sparse_collate (batch index LAST column)."""
+    cs, fs, ls, ks, num = [], [], [], [], []
+    for b in range(batch):
+        s = synth_scene(n_vox, seed + b, sweeps)
+        cs.append(np.concatenate([s['coords'], np.full((n_vox, 1), b, np.int32)], 1))
+        fs.append(s['feats'])
+        ls.append(s['labels'])
+        ks.append(s['keyframe'])
+        num.append(n_vox)
+    return {'coords': np.concatenate(cs), 'feats': np.concatenate(fs), 'labels': np.concatenate(ls),
+            'keyframe': np.concatenate(ks), 'num_vox': num}
+
+
+def kmap_stats(coords4: np.ndarray):
+    """N and pairs-per-voxel (k-bar) of the stride-1 k=3 map, via a set lookup
+    (independent of the oracle and the HIP path; used to report bytes)."""
+    c = coords4.astype(np.int64)
+    key = (c[:, 3] << 54) | ((c[:, 0] + 1) << 36) | ((c[:, 1] + 1) << 18) | (c[:, 2] + 1)
+    s = np.sort(key)
+    pairs = 0
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                q = key + (dx << 36) + (dy << 18) + dz
+                pos = np.minimum(np.searchsorted(s, q), len(s) - 1)
+                pairs += int((s[pos] == q).sum())
+    return len(c), pairs, pairs / max(len(c), 1)
