@@ -1,0 +1,126 @@
+/*
+ * u2mkd_hip.h -- C ABI of libu2mkd_hip.so, the MI355X (gfx950) native
+ * implementation of the U2MKD training hot path.
+ *
+ * Boundary rules
+ *   - plain C: device pointers + sizes + a HIP stream handle, no torch types;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function returns 0 on success, non-zero on error (message via
+ *     u2mkd_last_error()); nothing is allocated or synchronised inside, so
+ *     every call is hipGraph-capturable;
+ *   - outputs documented "pre-zeroed" must be zero-filled by the caller, the
+ *     convention of the reference's native layer (SURVEY.md section 8b:
+ *     "Python allocates outputs (zero-filled) and passes them in").
+ *
+ * Each entry cites the reference interface it replaces.  torchsparse v1.4.0
+ * (reference README.md:44-48) is the un-vendored native backend behind
+ * core/models/build_blocks.py:25-80 and core/models/utils.py:15-135; its
+ * pybind names are torchsparse.backend.<name>_cuda.  The sptr entries replace
+ * the extern "C" launchers declared in
+ * third_party/SparseTransformer/src/sptr/{precompute,attention,rpe}/..._kernel.h.
+ */
+#ifndef U2MKD_HIP_H
+#define U2MKD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *u2mkd_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------- */
+int u2mkd_version(void);
+const char *u2mkd_last_error(void);
+
+/* ---- coordinate hashing ------------------------------------------------
+ * replaces torchsparse.backend.hash_cuda / kernel_hash_cuda
+ * (F.sphash, called core/models/utils.py:19,43-49,86-92,133-134).
+ * FNV-1a-64 over the int32 words (x,y,z,b), folded to 60 bits.            */
+int u2mkd_hash(const int32_t *coords /*[n,4]*/, int64_t n, int64_t *out /*[n]*/, u2mkd_stream_t s);
+int u2mkd_kernel_hash(const int32_t *coords /*[n,4]*/, const int32_t *offsets /*[k,3]*/, int64_t n,
+                      int32_t k, int64_t *out /*[k,n]*/, u2mkd_stream_t s);
+
+/* ---- hash table --------------------------------------------------------
+ * replaces torchsparse.backend.hash_query_cuda (F.sphashquery,
+ * core/models/utils.py:21,50,93,135).  Open addressing, 64-bit keys;
+ * duplicates resolve to the smallest index (== dense_hash_map::insert).
+ * The table lives in caller memory of u2mkd_hash_table_bytes(n_refs) bytes. */
+size_t u2mkd_hash_table_bytes(int64_t n_refs);
+int u2mkd_hash_table_build(const int64_t *refs, int64_t n_refs, void *table, u2mkd_stream_t s);
+int u2mkd_hash_table_query(const void *table, int64_t n_refs, const int64_t *queries, int64_t n_q,
+                           int64_t *out /*[n_q] index or -1*/, u2mkd_stream_t s);
+
+/* ---- kernel map (rulebook) ---------------------------------------------
+ * replaces the kmap build of torchsparse F.conv3d (python: sphash(offsets) +
+ * sphashquery + nonzero).  The native form is the neighbour table
+ * nbr[k][j] = index of the input voxel at out_coords[j] + offsets[k], or -1.
+ * u2mkd_kmap_invert gives the table of the swapped roles (strided maps);
+ * u2mkd_kmap_sizes / u2mkd_kmap_compact produce torchsparse's
+ * (nbmaps [P,2] rows (in,out) grouped by k with ascending out, nbsizes [K]). */
+int u2mkd_kmap_build_table(const void *table, int64_t n_refs, const int32_t *out_coords /*[n_out,4]*/,
+                           int64_t n_out, const int32_t *offsets /*[k,3]*/, int32_t k,
+                           int32_t *nbr /*[k,n_out]*/, u2mkd_stream_t s);
+int u2mkd_kmap_invert(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int64_t n_in,
+                      int32_t *nbr_inv /*[k,n_in], pre-filled with -1*/, u2mkd_stream_t s);
+int u2mkd_kmap_sizes(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *nbsizes /*[k] pre-zeroed*/,
+                     int32_t *block_counts /*[k, ceil(n_out/1024)]*/, u2mkd_stream_t s);
+int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32_t *nbsizes /*[k]*/,
+                       int32_t *block_counts /*[k, ceil(n_out/1024)] from u2mkd_kmap_sizes (scanned in place)*/,
+                       int32_t *nbmaps /*[P,2]*/, u2mkd_stream_t s);
+/* downsample keys: pack floor(xyz / s) * s and b into an order-preserving
+ * int64 ((b,x,y,z) lexicographic, as torch.unique(dim=0) sorts) and back.
+ * replaces the arithmetic of F.spdownsample (Appendix A-4).                 */
+int u2mkd_downsample_keys(const int32_t *coords /*[n,4]*/, int64_t n, int32_t sx, int32_t sy, int32_t sz,
+                          int64_t *keys /*[n]*/, u2mkd_stream_t s);
+int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords /*[n,4]*/, u2mkd_stream_t s);
+
+/* ---- sparse convolution ------------------------------------------------
+ * replaces torchsparse.backend.convolution_forward_cuda /
+ * convolution_backward_cuda (ConvolutionFunction; every spnn.Conv3d of
+ * core/models/build_blocks.py:25-80).  Output-stationary: no atomics, every
+ * output row is written exactly once.
+ *   out[j] = sum_k in[nbr[k][j]] * B_k,  B_k = wt[kflip ? K-1-k : k] given
+ *   as [cout][cin] (reduction dim contiguous).
+ * forward:  wt = transpose of `kernel` (u2mkd_transpose_weights)
+ * dgrad:    wt = `kernel` itself with in := grad_out, nbr := table of the
+ *           swapped roles (kflip = 1 on the same table for submanifold maps). */
+int u2mkd_transpose_weights(const float *w /*[k,cin,cout]*/, int32_t k, int32_t cin, int32_t cout,
+                            float *wt /*[k,cout,cin]*/, u2mkd_stream_t s);
+int u2mkd_conv_forward(const float *in /*[n_in,cin]*/, int64_t n_in, int32_t cin, const float *wt /*[k,cout,cin]*/,
+                       int32_t cout, const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t kflip,
+                       float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* dW[k] = sum_j A_j^T B_j over rows with nbr[k][j] >= 0, where
+ *   a_gathered = 1: A_j = a[nbr[k][j]], B_j = b[j]       (normal conv)
+ *   a_gathered = 0: A_j = a[j],         B_j = b[nbr[k][j]] (transposed conv)
+ * a has ca channels (= cin of the layer), b has cb (= cout).  Deterministic
+ * (partial slabs in `workspace`, then an ordered reduction).                */
+size_t u2mkd_conv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k);
+int u2mkd_conv_wgrad(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *nbr /*[k,n_rows]*/,
+                     int64_t n_rows, int32_t k, int32_t a_gathered, int32_t centre_dense,
+                     void *workspace, size_t workspace_bytes, float *dw /*[k,ca,cb]*/, u2mkd_stream_t s);
+
+/* ---- point <-> voxel ---------------------------------------------------
+ * replace torchsparse.backend.count_cuda, voxelize_forward/backward_cuda,
+ * devoxelize_forward/backward_cuda (F.spcount / spvoxelize / spdevoxelize,
+ * core/models/utils.py:22-26,51,58,99,111) and F.calc_ti_weights (:94).    */
+int u2mkd_count(const int32_t *idx /*[n]*/, int64_t n, int32_t *counts /*[num] pre-zeroed*/, int64_t num,
+                u2mkd_stream_t s);
+int u2mkd_voxelize_forward(const float *feats /*[n,c]*/, const int32_t *idx /*[n]*/, const int32_t *counts /*[nv]*/,
+                           int64_t n, int64_t nv, int32_t c, float *out /*[nv,c] pre-zeroed*/, u2mkd_stream_t s);
+int u2mkd_voxelize_backward(const float *grad_out /*[nv,c]*/, const int32_t *idx, const int32_t *counts, int64_t n,
+                            int64_t nv, int32_t c, float *grad_feats /*[n,c]*/, u2mkd_stream_t s);
+int u2mkd_devoxelize_forward(const float *feats /*[nv,c]*/, const int32_t *idx /*[n,8]*/, const float *w /*[n,8]*/,
+                             int64_t n, int32_t c, float *out /*[n,c]*/, u2mkd_stream_t s);
+int u2mkd_devoxelize_backward(const float *grad_out /*[n,c]*/, const int32_t *idx /*[n,8]*/, const float *w /*[n,8]*/,
+                              int64_t n, int64_t nv, int32_t c, float *grad_feats /*[nv,c] pre-zeroed*/,
+                              u2mkd_stream_t s);
+int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
+                     float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U2MKD_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libu2mkd_hip.so (the C ABI declared in include/u2mkd_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this module
+raises.  Tensors cross the boundary as raw device pointers + sizes + the
+current HIP stream; torch only provides memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libu2mkd_hip.so')
+
+_i32, _i64, _sz, _f32, _p = C.c_int32, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/u2mkd_hip.h one to one
+SIGNATURES = {
+    'u2mkd_version': (C.c_int, []),
+    'u2mkd_last_error': (C.c_char_p, []),
+    'u2mkd_hash': (C.c_int, [_p, _i64, _p, _p]),
+    'u2mkd_kernel_hash': (C.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_hash_table_bytes': (_sz, [_i64]),
+    'u2mkd_hash_table_build': (C.c_int, [_p, _i64, _p, _p]),
+    'u2mkd_hash_table_query': (C.c_int, [_p, _i64, _p, _i64, _p, _p]),
+    'u2mkd_kmap_build_table': (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _p]),
+    'u2mkd_kmap_invert': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
+    'u2mkd_kmap_sizes': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    'u2mkd_kmap_compact': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    'u2mkd_downsample_keys': (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
+    'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_conv_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'u2mkd_conv_wgrad': (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p, _p]),
+    'u2mkd_count': (C.c_int, [_p, _i64, _p, _i64, _p]),
+    'u2mkd_voxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    'u2mkd_voxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    'u2mkd_devoxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_devoxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -m u2mkd_amd.build` '
+            '(u2mkd_amd has no CPU or PyTorch fallback path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; raise RuntimeError on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.u2mkd_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{name} failed (rc={rc}): {msg}')
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('u2mkd_amd operators run on the HIP device only (got a CPU tensor); '
+                               'there is no CPU fallback')

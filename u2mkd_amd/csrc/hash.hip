@@ -1,0 +1,289 @@
+// Coordinate hashing, device hash table, kernel-map (rulebook) construction.
+// Replaces torchsparse v1.4.0 hash_cuda / kernel_hash_cuda / hash_query_cuda
+// and the python kmap build of F.conv3d.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace u2mkd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ void hash_kernel(const int4 *__restrict__ coords, int64_t n, int64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int4 c = coords[i];
+        out[i] = fnv_hash4(c.x, c.y, c.z, c.w);
+    }
+}
+
+// grid.y = kernel offset (wave-uniform), threads over voxels: coalesced int4
+// reads, coalesced int64 writes into out[k][i].
+__global__ void kernel_hash_kernel(const int4 *__restrict__ coords, const int32_t *__restrict__ offsets,
+                                   int64_t n, int64_t *__restrict__ out) {
+    int k = blockIdx.y;
+    int ox = offsets[3 * k], oy = offsets[3 * k + 1], oz = offsets[3 * k + 2];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int4 c = coords[i];
+        out[(int64_t)k * n + i] = fnv_hash4(c.x + ox, c.y + oy, c.z + oz, c.w);
+    }
+}
+
+__global__ void table_insert_kernel(TableView t, const int64_t *__restrict__ refs, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t key = refs[i];
+    uint32_t slot = table_slot(t, key);
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.keys[slot]),
+                                            (unsigned long long)(-1LL), (unsigned long long)key);
+        if (prev == (unsigned long long)(-1LL) || prev == (unsigned long long)key) {
+            atomicMin(&t.vals[slot], (int)i);   // duplicates: smallest index wins
+            return;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+}
+
+__global__ void table_query_kernel(TableView t, const int64_t *__restrict__ q, int64_t n,
+                                   int64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)table_lookup(t, q[i]);
+}
+
+// Fused kernel_hash + query: nbr[k][j] = index of (out_coords[j] + offsets[k]) or -1.
+__global__ void kmap_table_kernel(TableView t, const int4 *__restrict__ out_coords,
+                                  const int32_t *__restrict__ offsets, int64_t n_out,
+                                  int32_t *__restrict__ nbr) {
+    int k = blockIdx.y;
+    int ox = offsets[3 * k], oy = offsets[3 * k + 1], oz = offsets[3 * k + 2];
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_out) {
+        int4 c = out_coords[j];
+        int64_t key = fnv_hash4(c.x + ox, c.y + oy, c.z + oz, c.w);
+        nbr[(int64_t)k * n_out + j] = table_lookup(t, key);
+    }
+}
+
+__global__ void kmap_invert_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int64_t n_in,
+                                   int32_t *__restrict__ inv) {
+    int k = blockIdx.y;
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_out) {
+        int i = nbr[(int64_t)k * n_out + j];
+        if (i >= 0 && i < n_in) inv[(int64_t)k * n_in + i] = (int)j;
+    }
+}
+
+// ---- rulebook compaction (torchsparse nbmaps order: by k, ascending out) ----
+// 1024 rows per block; wave ballots give the in-block rank of every valid pair.
+constexpr int kCompactBlock = 1024;
+
+__global__ void __launch_bounds__(kCompactBlock)
+kmap_sizes_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int32_t *__restrict__ nbsizes,
+                  int32_t *__restrict__ block_counts) {
+    __shared__ int wave_cnt[kCompactBlock / kWave];
+    int k = blockIdx.y;
+    int64_t j = (int64_t)blockIdx.x * kCompactBlock + threadIdx.x;
+    bool valid = (j < n_out) && nbr[(int64_t)k * n_out + j] >= 0;
+    unsigned long long m = __ballot(valid);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kCompactBlock / kWave; ++w) tot += wave_cnt[w];
+        block_counts[(int64_t)k * gridDim.x + blockIdx.x] = tot;
+        if (tot) atomicAdd(&nbsizes[k], tot);
+    }
+}
+
+// One block: exclusive scan of block_counts in (k, block) order, offset by the
+// prefix of nbsizes over k.  K * nblocks is small (27 * 300 for 300k voxels).
+__global__ void kmap_scan_kernel(const int32_t *__restrict__ nbsizes, int32_t *__restrict__ block_counts,
+                                 int k_total, int nblocks) {
+    __shared__ int kbase[256];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < k_total; ++k) { kbase[k] = acc; acc += nbsizes[k]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < k_total; k += blockDim.x) {
+        int acc = kbase[k];
+        int32_t *row = block_counts + (int64_t)k * nblocks;
+        for (int b = 0; b < nblocks; ++b) { int c = row[b]; row[b] = acc; acc += c; }
+    }
+}
+
+__global__ void __launch_bounds__(kCompactBlock)
+kmap_compact_kernel(const int32_t *__restrict__ nbr, int64_t n_out, const int32_t *__restrict__ block_base,
+                    int32_t *__restrict__ nbmaps) {
+    __shared__ int wave_cnt[kCompactBlock / kWave];
+    int k = blockIdx.y;
+    int64_t j = (int64_t)blockIdx.x * kCompactBlock + threadIdx.x;
+    int i = (j < n_out) ? nbr[(int64_t)k * n_out + j] : -1;
+    bool valid = i >= 0;
+    unsigned long long m = __ballot(valid);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (valid) {
+        int base = block_base[(int64_t)k * gridDim.x + blockIdx.x];
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+        int rank = __popcll(m & ((1ULL << lane) - 1ULL));
+        int64_t p = (int64_t)base + rank;
+        nbmaps[2 * p] = i;
+        nbmaps[2 * p + 1] = (int)j;
+    }
+}
+
+// ---- downsample keys: order-preserving (b,x,y,z) pack -----------------------
+// b: 10 bits, x/y/z: 18 bits each with bias 2^17 (|coord| < 131072).
+__global__ void downsample_keys_kernel(const int4 *__restrict__ coords, int64_t n, int sx, int sy, int sz,
+                                       int64_t *__restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    auto fl = [](int v, int s) { int q = v / s; if ((v % s != 0) && ((v < 0) != (s < 0))) --q; return q * s; };
+    int x = fl(c.x, sx), y = fl(c.y, sy), z = fl(c.z, sz);
+    const int64_t bias = 1 << 17;
+    keys[i] = ((int64_t)c.w << 54) | ((int64_t)(x + bias) << 36) | ((int64_t)(y + bias) << 18) | (int64_t)(z + bias);
+}
+
+__global__ void unpack_keys_kernel(const int64_t *__restrict__ keys, int64_t n, int4 *__restrict__ coords) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t key = keys[i];
+    const int64_t bias = 1 << 17, m18 = (1 << 18) - 1;
+    int4 c;
+    c.w = (int)(key >> 54);
+    c.x = (int)(((key >> 36) & m18) - bias);
+    c.y = (int)(((key >> 18) & m18) - bias);
+    c.z = (int)((key & m18) - bias);
+    coords[i] = c;
+}
+
+}  // namespace u2mkd
+
+using namespace u2mkd;
+
+extern "C" {
+
+int u2mkd_version(void) { return 100; }
+const char *u2mkd_last_error(void) { return g_err; }
+
+int u2mkd_hash(const int32_t *coords, int64_t n, int64_t *out, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(coords && out, "u2mkd_hash: null pointer");
+    hipLaunchKernelGGL(hash_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const int4 *>(coords), n, out);
+    return check_launch("u2mkd_hash");
+}
+
+int u2mkd_kernel_hash(const int32_t *coords, const int32_t *offsets, int64_t n, int32_t k, int64_t *out,
+                      u2mkd_stream_t s) {
+    if (n == 0 || k == 0) return 0;
+    U2_REQUIRE(coords && offsets && out, "u2mkd_kernel_hash: null pointer");
+    U2_REQUIRE(k <= 65535, "u2mkd_kernel_hash: k=%d too large", k);
+    hipLaunchKernelGGL(kernel_hash_kernel, dim3((unsigned)ceil_div(n, 256), k), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const int4 *>(coords), offsets, n, out);
+    return check_launch("u2mkd_kernel_hash");
+}
+
+size_t u2mkd_hash_table_bytes(int64_t n_refs) {
+    return (size_t)table_capacity(n_refs) * (sizeof(int64_t) + sizeof(int32_t));
+}
+
+int u2mkd_hash_table_build(const int64_t *refs, int64_t n_refs, void *table, u2mkd_stream_t s) {
+    U2_REQUIRE(table, "u2mkd_hash_table_build: null table");
+    U2_REQUIRE(n_refs < (1LL << 31) - 1, "u2mkd_hash_table_build: too many refs");
+    TableView t = make_table_view(table, n_refs);
+    int64_t cap = table_capacity(n_refs);
+    hipError_t e = hipMemsetAsync(t.keys, 0xFF, cap * sizeof(int64_t), as_stream(s));
+    if (e == hipSuccess) e = hipMemsetAsync(t.vals, 0x7F, cap * sizeof(int32_t), as_stream(s));
+    if (e != hipSuccess) { set_error("u2mkd_hash_table_build: memset: %s", hipGetErrorString(e)); return 1; }
+    if (n_refs == 0) return 0;
+    U2_REQUIRE(refs, "u2mkd_hash_table_build: null refs");
+    hipLaunchKernelGGL(table_insert_kernel, dim3((unsigned)ceil_div(n_refs, 256)), dim3(256), 0, as_stream(s), t,
+                       refs, n_refs);
+    return check_launch("u2mkd_hash_table_build");
+}
+
+int u2mkd_hash_table_query(const void *table, int64_t n_refs, const int64_t *queries, int64_t n_q, int64_t *out,
+                           u2mkd_stream_t s) {
+    if (n_q == 0) return 0;
+    U2_REQUIRE(table && queries && out, "u2mkd_hash_table_query: null pointer");
+    TableView t = make_table_view(const_cast<void *>(table), n_refs);
+    hipLaunchKernelGGL(table_query_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, as_stream(s), t,
+                       queries, n_q, out);
+    return check_launch("u2mkd_hash_table_query");
+}
+
+int u2mkd_kmap_build_table(const void *table, int64_t n_refs, const int32_t *out_coords, int64_t n_out,
+                           const int32_t *offsets, int32_t k, int32_t *nbr, u2mkd_stream_t s) {
+    if (n_out == 0 || k == 0) return 0;
+    U2_REQUIRE(table && out_coords && offsets && nbr, "u2mkd_kmap_build_table: null pointer");
+    U2_REQUIRE(k <= 65535, "u2mkd_kmap_build_table: k=%d too large", k);
+    TableView t = make_table_view(const_cast<void *>(table), n_refs);
+    hipLaunchKernelGGL(kmap_table_kernel, dim3((unsigned)ceil_div(n_out, 256), k), dim3(256), 0, as_stream(s), t,
+                       reinterpret_cast<const int4 *>(out_coords), offsets, n_out, nbr);
+    return check_launch("u2mkd_kmap_build_table");
+}
+
+int u2mkd_kmap_invert(const int32_t *nbr, int64_t n_out, int32_t k, int64_t n_in, int32_t *nbr_inv,
+                      u2mkd_stream_t s) {
+    if (n_out == 0 || k == 0) return 0;
+    U2_REQUIRE(nbr && nbr_inv, "u2mkd_kmap_invert: null pointer");
+    hipLaunchKernelGGL(kmap_invert_kernel, dim3((unsigned)ceil_div(n_out, 256), k), dim3(256), 0, as_stream(s), nbr,
+                       n_out, n_in, nbr_inv);
+    return check_launch("u2mkd_kmap_invert");
+}
+
+int u2mkd_kmap_sizes(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *nbsizes, int32_t *block_counts,
+                     u2mkd_stream_t s) {
+    if (n_out == 0 || k == 0) return 0;
+    U2_REQUIRE(nbr && nbsizes && block_counts, "u2mkd_kmap_sizes: null pointer");
+    hipLaunchKernelGGL(kmap_sizes_kernel, dim3((unsigned)ceil_div(n_out, kCompactBlock), k), dim3(kCompactBlock), 0,
+                       as_stream(s), nbr, n_out, nbsizes, block_counts);
+    return check_launch("u2mkd_kmap_sizes");
+}
+
+int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32_t *nbsizes, int32_t *block_counts,
+                       int32_t *nbmaps, u2mkd_stream_t s) {
+    if (n_out == 0 || k == 0) return 0;
+    U2_REQUIRE(nbr && nbsizes && block_counts && nbmaps, "u2mkd_kmap_compact: null pointer");
+    U2_REQUIRE(k <= 256, "u2mkd_kmap_compact: k=%d > 256", k);
+    int nblocks = (int)ceil_div(n_out, kCompactBlock);
+    hipLaunchKernelGGL(kmap_scan_kernel, dim3(1), dim3(64), 0, as_stream(s), nbsizes, block_counts, k, nblocks);
+    hipLaunchKernelGGL(kmap_compact_kernel, dim3(nblocks, k), dim3(kCompactBlock), 0, as_stream(s), nbr, n_out,
+                       block_counts, nbmaps);
+    return check_launch("u2mkd_kmap_compact");
+}
+
+int u2mkd_downsample_keys(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,
+                          u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(coords && keys, "u2mkd_downsample_keys: null pointer");
+    U2_REQUIRE(sx > 0 && sy > 0 && sz > 0, "u2mkd_downsample_keys: strides must be positive");
+    hipLaunchKernelGGL(downsample_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const int4 *>(coords), n, sx, sy, sz, keys);
+    return check_launch("u2mkd_downsample_keys");
+}
+
+int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(coords && keys, "u2mkd_unpack_keys: null pointer");
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), keys, n,
+                       reinterpret_cast<int4 *>(coords));
+    return check_launch("u2mkd_unpack_keys");
+}
+
+}  // extern "C"

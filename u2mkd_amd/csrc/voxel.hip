@@ -1,0 +1,250 @@
+// Point <-> voxel scatter/gather: count, voxelize (scatter-mean), devoxelize
+// (8-corner trilinear gather) and their backward passes, trilinear weights.
+// Replaces torchsparse v1.4.0 count_cuda / voxelize_*_cuda / devoxelize_*_cuda
+// and F.calc_ti_weights (call sites core/models/utils.py).
+//
+// HBM-bound row work: one thread moves 16 B (float4) of a row, so a row of C
+// floats is covered by C/4 adjacent lanes and every wave instruction touches
+// whole contiguous row segments.
+#include "common.h"
+
+namespace u2mkd {
+
+__global__ void count_kernel(const int32_t *__restrict__ idx, int64_t n, int32_t *__restrict__ counts,
+                             int64_t num) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int p = idx[i];
+        if (p >= 0 && p < num) atomicAdd(&counts[p], 1);
+    }
+}
+
+// out[idx[i]] += feats[i] / counts[idx[i]]  (float atomics, as the reference)
+template <int VEC>
+__global__ void voxelize_fwd_kernel(const float *__restrict__ feats, const int32_t *__restrict__ idx,
+                                    const int32_t *__restrict__ counts, int64_t n, int64_t nv, int c,
+                                    float *__restrict__ out) {
+    int cv = c / VEC;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / cv;
+    int j = (int)(t - i * cv) * VEC;
+    if (i >= n) return;
+    int p = idx[i];
+    if (p < 0 || p >= nv) return;
+    int cnt = counts[p];
+    if (cnt == 0) return;
+    float inv = (float)cnt;
+    const float *src = feats + i * c + j;
+    float *dst = out + (int64_t)p * c + j;
+    if (VEC == 4) {
+        float4 v = *reinterpret_cast<const float4 *>(src);
+        atomicAdd(dst + 0, v.x / inv);
+        atomicAdd(dst + 1, v.y / inv);
+        atomicAdd(dst + 2, v.z / inv);
+        atomicAdd(dst + 3, v.w / inv);
+    } else {
+        atomicAdd(dst, src[0] / inv);
+    }
+}
+
+template <int VEC>
+__global__ void voxelize_bwd_kernel(const float *__restrict__ gout, const int32_t *__restrict__ idx,
+                                    const int32_t *__restrict__ counts, int64_t n, int64_t nv, int c,
+                                    float *__restrict__ gin) {
+    int cv = c / VEC;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / cv;
+    int j = (int)(t - i * cv) * VEC;
+    if (i >= n) return;
+    int p = idx[i];
+    float *dst = gin + i * c + j;
+    bool ok = p >= 0 && p < nv;
+    int cnt = ok ? counts[p] : 0;
+    if (VEC == 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cnt > 0) {
+            float4 g = *reinterpret_cast<const float4 *>(gout + (int64_t)p * c + j);
+            float inv = (float)cnt;
+            v = make_float4(g.x / inv, g.y / inv, g.z / inv, g.w / inv);
+        }
+        *reinterpret_cast<float4 *>(dst) = v;
+    } else {
+        dst[0] = cnt > 0 ? gout[(int64_t)p * c + j] / (float)cnt : 0.f;
+    }
+}
+
+// out[i] = sum_k w[i,k] * feats[idx[i,k]]   (k ascending, idx < 0 skipped)
+template <int VEC>
+__global__ void devoxelize_fwd_kernel(const float *__restrict__ feats, const int32_t *__restrict__ idx,
+                                      const float *__restrict__ w, int64_t n, int c, float *__restrict__ out) {
+    int cv = c / VEC;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / cv;
+    int j = (int)(t - i * cv) * VEC;
+    if (i >= n) return;
+    const int32_t *ii = idx + i * 8;
+    const float *ww = w + i * 8;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int p = ii[k];
+        float wk = ww[k];
+        if (p >= 0) {
+            const float *src = feats + (int64_t)p * c + j;
+            if (VEC == 4) {
+                float4 f = *reinterpret_cast<const float4 *>(src);
+                acc[0] += wk * f.x; acc[1] += wk * f.y; acc[2] += wk * f.z; acc[3] += wk * f.w;
+            } else {
+                acc[0] += wk * src[0];
+            }
+        }
+    }
+    float *dst = out + i * c + j;
+    if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else dst[0] = acc[0];
+}
+
+// g_feats[idx[i,k]] += w[i,k] * g_out[i]   (float atomics, as the reference)
+template <int VEC>
+__global__ void devoxelize_bwd_kernel(const float *__restrict__ gout, const int32_t *__restrict__ idx,
+                                      const float *__restrict__ w, int64_t n, int64_t nv, int c,
+                                      float *__restrict__ gin) {
+    int cv = c / VEC;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / cv;
+    int j = (int)(t - i * cv) * VEC;
+    if (i >= n) return;
+    const int32_t *ii = idx + i * 8;
+    const float *ww = w + i * 8;
+    float g[VEC];
+    if (VEC == 4) {
+        float4 v = *reinterpret_cast<const float4 *>(gout + i * c + j);
+        g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+    } else {
+        g[0] = gout[i * c + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int p = ii[k];
+        float wk = ww[k];
+        if (p >= 0 && p < nv && wk != 0.f) {
+            float *dst = gin + (int64_t)p * c + j;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) atomicAdd(dst + v, wk * g[v]);
+        }
+    }
+}
+
+// F.calc_ti_weights fused with the [8,N] -> [N,8] transposes of
+// core/models/utils.py:94-95.  Same operation order as the reference:
+// products of differences, / scale^3, zero where idx == -1, / (sum + 1e-8).
+__global__ void ti_weights_kernel(const float4 *__restrict__ coords, const int64_t *__restrict__ idx_kn, int64_t n,
+                                  float scale, float *__restrict__ w_n8, int32_t *__restrict__ idx_n8) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = coords[i];
+    float xf, yf, zf;
+    if (scale != 1.f) {
+        xf = floorf(p.x / scale) * scale; yf = floorf(p.y / scale) * scale; zf = floorf(p.z / scale) * scale;
+    } else {
+        xf = floorf(p.x); yf = floorf(p.y); zf = floorf(p.z);
+    }
+    float xc = xf + scale, yc = yf + scale, zc = zf + scale;
+    float w[8];
+    w[0] = (xc - p.x) * (yc - p.y) * (zc - p.z);
+    w[1] = (xc - p.x) * (yc - p.y) * (p.z - zf);
+    w[2] = (xc - p.x) * (p.y - yf) * (zc - p.z);
+    w[3] = (xc - p.x) * (p.y - yf) * (p.z - zf);
+    w[4] = (p.x - xf) * (yc - p.y) * (zc - p.z);
+    w[5] = (p.x - xf) * (yc - p.y) * (p.z - zf);
+    w[6] = (p.x - xf) * (p.y - yf) * (zc - p.z);
+    w[7] = (p.x - xf) * (p.y - yf) * (p.z - zf);
+    float s3 = scale * scale * scale;
+    float sum = 0.f;
+    int id[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (scale != 1.f) w[k] = w[k] / s3;
+        id[k] = (int)idx_kn[(int64_t)k * n + i];
+        if (id[k] == -1) w[k] = 0.f;
+        sum += w[k];
+    }
+    sum += 1e-8f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        w_n8[i * 8 + k] = w[k] / sum;
+        idx_n8[i * 8 + k] = id[k];
+    }
+}
+
+}  // namespace u2mkd
+
+using namespace u2mkd;
+
+#define LAUNCH_ROWS(kernel, n, c, ...)                                                                  \
+    do {                                                                                                \
+        if ((c) % 4 == 0) {                                                                             \
+            int64_t total = (n) * ((c) / 4);                                                            \
+            hipLaunchKernelGGL(kernel<4>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), \
+                               __VA_ARGS__);                                                            \
+        } else {                                                                                        \
+            int64_t total = (n) * (int64_t)(c);                                                         \
+            hipLaunchKernelGGL(kernel<1>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), \
+                               __VA_ARGS__);                                                            \
+        }                                                                                               \
+    } while (0)
+
+extern "C" {
+
+int u2mkd_count(const int32_t *idx, int64_t n, int32_t *counts, int64_t num, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(idx && counts, "u2mkd_count: null pointer");
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), idx, n, counts,
+                       num);
+    return check_launch("u2mkd_count");
+}
+
+int u2mkd_voxelize_forward(const float *feats, const int32_t *idx, const int32_t *counts, int64_t n, int64_t nv,
+                           int32_t c, float *out, u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(feats && idx && counts && out, "u2mkd_voxelize_forward: null pointer");
+    LAUNCH_ROWS(voxelize_fwd_kernel, n, c, feats, idx, counts, n, nv, c, out);
+    return check_launch("u2mkd_voxelize_forward");
+}
+
+int u2mkd_voxelize_backward(const float *grad_out, const int32_t *idx, const int32_t *counts, int64_t n, int64_t nv,
+                            int32_t c, float *grad_feats, u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(grad_out && idx && counts && grad_feats, "u2mkd_voxelize_backward: null pointer");
+    LAUNCH_ROWS(voxelize_bwd_kernel, n, c, grad_out, idx, counts, n, nv, c, grad_feats);
+    return check_launch("u2mkd_voxelize_backward");
+}
+
+int u2mkd_devoxelize_forward(const float *feats, const int32_t *idx, const float *w, int64_t n, int32_t c, float *out,
+                             u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(feats && idx && w && out, "u2mkd_devoxelize_forward: null pointer");
+    LAUNCH_ROWS(devoxelize_fwd_kernel, n, c, feats, idx, w, n, c, out);
+    return check_launch("u2mkd_devoxelize_forward");
+}
+
+int u2mkd_devoxelize_backward(const float *grad_out, const int32_t *idx, const float *w, int64_t n, int64_t nv,
+                              int32_t c, float *grad_feats, u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(grad_out && idx && w && grad_feats, "u2mkd_devoxelize_backward: null pointer");
+    LAUNCH_ROWS(devoxelize_bwd_kernel, n, c, grad_out, idx, w, n, nv, c, grad_feats);
+    return check_launch("u2mkd_devoxelize_backward");
+}
+
+int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, float scale, float *w_n8,
+                     int32_t *idx_n8, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(coords && idx_kn && w_n8 && idx_n8, "u2mkd_ti_weights: null pointer");
+    hipLaunchKernelGGL(ti_weights_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8);
+    return check_launch("u2mkd_ti_weights");
+}
+
+}  // extern "C"

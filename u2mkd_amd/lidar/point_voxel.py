@@ -1,0 +1,126 @@
+"""Point <-> voxel transfers (rows a1-a3 of SURVEY.md §8a).
+
+Same results and the same caching keys as the reference's
+``core/models/utils.py`` (initial_voxelize :15-35, point_to_voxel :40-65,
+voxel_to_point :70-118, fetch_idx :121-135, SparseSyncBatchNorm :138-220), but
+each step is one HIP launch: the 8-corner hash + probe is fused with the
+trilinear weights and the [8,N]->[N,8] transposes, and index tensors are kept
+in the int32 form the kernels consume.
+"""
+import torch
+from torch import nn
+
+from .. import torchsparse
+from ..torchsparse import PointTensor, SparseTensor
+from ..torchsparse import nn as spnn
+from ..torchsparse.nn import functional as spf
+from ..torchsparse.nn.utils import fapply, get_kernel_offsets
+
+__all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'fetch_idx', 'SparseSyncBatchNorm']
+
+
+def _floor_coords(pc, stride):
+    """int32 (floor(xyz / s) * s, b) of float point coords [N,4]."""
+    xyz = torch.floor(pc[:, :3] / stride).int() * stride
+    return torch.cat([xyz, pc[:, -1].int().view(-1, 1)], 1)
+
+
+def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
+    """Points -> stride-1 voxels (mean of coords and feats per voxel); voxel
+    order = ascending FNV hash (torch.unique), as core/models/utils.py:15-35."""
+    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
+    floor_c = torch.floor(new_float_coord)
+    pc_hash = spf.sphash(floor_c.int())
+    sparse_hash = torch.unique(pc_hash)
+    idx_query = spf.sphashquery(pc_hash, sparse_hash)
+    counts = spf.spcount(idx_query.int(), len(sparse_hash))
+
+    inserted_coords = spf.spvoxelize(floor_c, idx_query, counts)
+    inserted_coords = torch.round(inserted_coords).int()
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+
+    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
+    z.additional_features['idx_query'][1] = idx_query
+    z.additional_features['counts'][1] = counts
+    z.C = new_float_coord
+    return new_tensor
+
+
+def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
+    """Scatter-mean point features into the voxels of ``x`` (utils.py:40-65)."""
+    cache = z.additional_features
+    if cache is None or cache.get('idx_query') is None or cache['idx_query'].get(x.s) is None:
+        pc_hash = spf.sphash(_floor_coords(z.C, x.s[0]))
+        idx_query = spf.HashTable(spf.sphash(x.C)).query(pc_hash)
+        counts = spf.spcount(idx_query.int(), x.C.shape[0])
+        z.additional_features['idx_query'][x.s] = idx_query
+        z.additional_features['counts'][x.s] = counts
+    else:
+        idx_query = cache['idx_query'][x.s]
+        counts = cache['counts'][x.s]
+
+    inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
+    new_tensor = SparseTensor(inserted_feat, x.C, x.s)
+    new_tensor.cmaps = x.cmaps
+    new_tensor.kmaps = x.kmaps
+    return new_tensor
+
+
+def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTensor:
+    """Trilinear devoxelisation of ``x`` at the points of ``z`` (utils.py:70-118)."""
+    if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None \
+            or z.weights.get(x.s) is None:
+        off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
+        old_hash = spf.sphash(_floor_coords(z.C, x.s[0]), off)          # [8, N]
+        idx_kn = spf.HashTable(spf.sphash(x.C.to(z.F.device))).query(old_hash)
+        weights, idx_query = spf.ti_weights_n8(z.C, idx_kn, scale=x.s[0])   # [N,8], [N,8]
+        if nearest:
+            weights[:, 1:] = 0.
+            idx_query[:, 1:] = -1
+        new_feat = spf.spdevoxelize(x.F, idx_query, weights)
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+        new_tensor.idx_query[x.s] = idx_query
+        new_tensor.weights[x.s] = weights
+        z.idx_query[x.s] = idx_query
+        z.weights[x.s] = weights
+    else:
+        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+    return new_tensor
+
+
+def fetch_idx(source_coords: torch.Tensor, target_coords: torch.Tensor) -> torch.Tensor:
+    """Index of every source coordinate in ``target_coords`` (utils.py:121-135)."""
+    assert isinstance(source_coords, torch.Tensor) and isinstance(target_coords, torch.Tensor)
+    return spf.sphashquery(spf.sphash(source_coords), spf.sphash(target_coords))
+
+
+class SparseSyncBatchNorm(nn.SyncBatchNorm):
+    """SyncBatchNorm over SparseTensor features (utils.py:138-220)."""
+
+    def forward(self, input: SparseTensor) -> SparseTensor:
+        return fapply(input, super().forward)
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        out = module
+        if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
+            klass = SparseSyncBatchNorm if isinstance(module, spnn.BatchNorm) else torch.nn.SyncBatchNorm
+            out = klass(module.num_features, module.eps, module.momentum, module.affine,
+                        module.track_running_stats, process_group)
+            if module.affine:
+                with torch.no_grad():
+                    out.weight = module.weight
+                    out.bias = module.bias
+            out.running_mean = module.running_mean
+            out.running_var = module.running_var
+            out.num_batches_tracked = module.num_batches_tracked
+            if hasattr(module, 'qconfig'):
+                out.qconfig = module.qconfig
+        for name, child in module.named_children():
+            out.add_module(name, cls.convert_sync_batchnorm(child, process_group))
+        del module
+        return out

@@ -1,0 +1,381 @@
+"""torchsparse.nn.functional on MI355X: every op is a HIP kernel behind the C ABI.
+
+Call sites in the reference: core/models/utils.py:15-135 (sphash, sphashquery,
+spcount, spvoxelize, spdevoxelize, calc_ti_weights) and every spnn.Conv3d of
+core/models/build_blocks.py:25-80 (conv3d).  Semantics follow torchsparse
+v1.4.0; the native data structure differs: a kernel map
+is a neighbour table ``nbr[k][j]`` (plus the swapped-role table for strided
+maps), consumed by an output-stationary MFMA kernel, instead of the
+(nbmaps, nbsizes) rulebook driving gather -> GEMM -> scatter.  The rulebook is
+still available lazily through the v1.4.0 ``kmap[0..2]`` interface.
+
+GPU only: CPU tensors raise (there is no fallback path).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from ... import _lib as L
+from ..tensor import SparseTensor
+from ..utils import make_ntuple
+from .utils import get_kernel_offsets
+
+__all__ = ['sphash', 'sphashquery', 'spcount', 'spvoxelize', 'spdevoxelize', 'calc_ti_weights',
+           'spdownsample', 'conv3d', 'KernelMap', 'HashTable', 'ti_weights_n8']
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.int()
+
+
+# --------------------------------------------------------------------------- hash
+def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
+    assert coords.dtype == torch.int, coords.dtype
+    assert coords.ndim == 2 and coords.shape[1] == 4, coords.shape
+    L.require_cuda(coords, offsets)
+    coords = coords.contiguous()
+    n = coords.shape[0]
+    if offsets is None:
+        out = torch.empty(n, dtype=torch.int64, device=coords.device)
+        L.call('u2mkd_hash', L.ptr(coords), n, L.ptr(out), L.stream())
+        return out
+    assert offsets.dtype == torch.int, offsets.dtype
+    assert offsets.ndim == 2 and offsets.shape[1] == 3, offsets.shape
+    offsets = offsets.contiguous()
+    k = offsets.shape[0]
+    out = torch.empty(k, n, dtype=torch.int64, device=coords.device)
+    L.call('u2mkd_kernel_hash', L.ptr(coords), L.ptr(offsets), n, k, L.ptr(out), L.stream())
+    return out
+
+
+class HashTable:
+    """Device hash table over int64 keys -> index (smallest index on duplicates)."""
+
+    def __init__(self, references: torch.Tensor):
+        L.require_cuda(references)
+        assert references.dtype == torch.int64
+        references = references.contiguous().view(-1)
+        self.n = references.shape[0]
+        nbytes = L.load().u2mkd_hash_table_bytes(self.n)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=references.device)
+        L.call('u2mkd_hash_table_build', L.ptr(references), self.n, L.ptr(self.buf), L.stream())
+
+    def query(self, queries: torch.Tensor) -> torch.Tensor:
+        L.require_cuda(queries)
+        assert queries.dtype == torch.int64
+        q = queries.contiguous()
+        out = torch.empty_like(q)
+        L.call('u2mkd_hash_table_query', L.ptr(self.buf), self.n, L.ptr(q), q.numel(), L.ptr(out), L.stream())
+        return out
+
+
+def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
+    """Index of every query hash in ``references`` (-1 on miss), query shape kept."""
+    return HashTable(references).query(queries)
+
+
+def spcount(coords: torch.Tensor, num: int) -> torch.Tensor:
+    L.require_cuda(coords)
+    idx = _i32(coords).contiguous()
+    out = torch.zeros(int(num), dtype=torch.int32, device=idx.device)
+    L.call('u2mkd_count', L.ptr(idx), idx.numel(), L.ptr(out), int(num), L.stream())
+    return out
+
+
+# ----------------------------------------------------------------- voxelize
+class VoxelizeFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, coords, counts):
+        L.require_cuda(feats, coords, counts)
+        feats = feats.contiguous().float()
+        coords = _i32(coords).contiguous()
+        counts = _i32(counts).contiguous()
+        n, c = feats.shape
+        nv = counts.shape[0]
+        out = torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
+        L.call('u2mkd_voxelize_forward', L.ptr(feats), L.ptr(coords), L.ptr(counts), n, nv, c, L.ptr(out), L.stream())
+        ctx.for_backwards = (coords, counts, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, counts, n = ctx.for_backwards
+        g = grad_output.contiguous().float()
+        nv, c = g.shape
+        gi = torch.empty(n, c, dtype=torch.float32, device=g.device)
+        L.call('u2mkd_voxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(counts), n, nv, c, L.ptr(gi), L.stream())
+        return gi, None, None
+
+
+def spvoxelize(feats, coords, counts):
+    return VoxelizeFunction.apply(feats, coords, counts)
+
+
+# --------------------------------------------------------------- devoxelize
+class DevoxelizeFunction(Function):
+    @staticmethod
+    def forward(ctx, feats, coords, weights):
+        L.require_cuda(feats, coords, weights)
+        feats = feats.contiguous().float()
+        coords = _i32(coords).contiguous()
+        weights = weights.contiguous().float()
+        nv, c = feats.shape
+        n = coords.shape[0]
+        assert coords.shape == (n, 8) and weights.shape == (n, 8), (coords.shape, weights.shape)
+        out = torch.empty(n, c, dtype=torch.float32, device=feats.device)
+        L.call('u2mkd_devoxelize_forward', L.ptr(feats), L.ptr(coords), L.ptr(weights), n, c, L.ptr(out), L.stream())
+        ctx.for_backwards = (coords, weights, nv)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        coords, weights, nv = ctx.for_backwards
+        g = grad_output.contiguous().float()
+        n, c = g.shape
+        gi = torch.zeros(nv, c, dtype=torch.float32, device=g.device)
+        L.call('u2mkd_devoxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(weights), n, nv, c, L.ptr(gi), L.stream())
+        return gi, None, None
+
+
+def spdevoxelize(feats, coords, weights):
+    return DevoxelizeFunction.apply(feats, coords, weights)
+
+
+def ti_weights_n8(coords: torch.Tensor, idx_query_kn: torch.Tensor, scale=1):
+    """Fused F.calc_ti_weights + the two [8,N]->[N,8] transposes of
+    core/models/utils.py:94-95.  Returns (weights f32 [N,8], idx int32 [N,8])."""
+    L.require_cuda(coords, idx_query_kn)
+    coords = coords.contiguous().float()
+    assert coords.ndim == 2 and coords.shape[1] == 4, coords.shape
+    idx = idx_query_kn.contiguous()
+    assert idx.dtype == torch.int64 and idx.shape == (8, coords.shape[0]), (idx.dtype, idx.shape)
+    n = coords.shape[0]
+    w = torch.empty(n, 8, dtype=torch.float32, device=coords.device)
+    i8 = torch.empty(n, 8, dtype=torch.int32, device=coords.device)
+    L.call('u2mkd_ti_weights', L.ptr(coords), L.ptr(idx), n, float(scale), L.ptr(w), L.ptr(i8), L.stream())
+    return w, i8
+
+
+def calc_ti_weights(coords, idx_query, scale=1):
+    """v1.4.0 signature: returns [8,N] (a transposed view of the fused [N,8]
+    result, so the caller's ``.transpose(0,1).contiguous()`` is free)."""
+    with torch.no_grad():
+        w, _ = ti_weights_n8(coords, idx_query, scale)
+        return w.t()
+
+
+# --------------------------------------------------------------- downsample
+def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
+    """Output coordinates of a strided conv, sorted by (b,x,y,z) (Appendix A-4).
+    Only the stride[k] in {1, kernel_size[k]} branch is on the U2MKD path."""
+    L.require_cuda(coords)
+    stride = make_ntuple(stride, ndim=3)
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    tensor_stride = make_ntuple(tensor_stride, ndim=3)
+    if not all(stride[k] in (1, kernel_size[k]) for k in range(3)):
+        raise NotImplementedError('spdownsample: only stride in {1, kernel_size} is supported '
+                                  '(the only form U2MKD uses: k=2, s=2)')
+    ss = [stride[k] * tensor_stride[k] for k in range(3)]
+    coords = _i32(coords).contiguous()
+    n = coords.shape[0]
+    keys = torch.empty(n, dtype=torch.int64, device=coords.device)
+    L.call('u2mkd_downsample_keys', L.ptr(coords), n, ss[0], ss[1], ss[2], L.ptr(keys), L.stream())
+    uniq = torch.unique(keys)  # sorted int64 == (b,x,y,z) lexicographic
+    out = torch.empty(uniq.shape[0], 4, dtype=torch.int32, device=coords.device)
+    L.call('u2mkd_unpack_keys', L.ptr(uniq), uniq.shape[0], L.ptr(out), L.stream())
+    return out
+
+
+# -------------------------------------------------------------- kernel maps
+class KernelMap:
+    """Kernel map of one (tensor_stride, kernel_size, stride, dilation) key.
+
+    ``nbr`` int32 [K, n_out]: input index feeding output row j through offset k
+    (-1 = none).  ``nbr_inv`` int32 [K, n_in]: output index fed by input row i
+    through offset k (strided maps; for submanifold maps it is ``nbr`` with the
+    offset order reversed and is not materialised).  Indexing ``kmap[0..2]``
+    gives torchsparse's (nbmaps [P,2] (in,out), nbsizes [K], (n_in, n_out)).
+    """
+
+    def __init__(self, nbr, nbr_inv, n_in, n_out, symmetric, out_coords):
+        self.nbr = nbr
+        self.nbr_inv = nbr_inv
+        self.n_in = int(n_in)
+        self.n_out = int(n_out)
+        self.k = int(nbr.shape[0])
+        self.symmetric = bool(symmetric)
+        self.out_coords = out_coords
+        self._rulebook = None
+
+    def rulebook(self):
+        if self._rulebook is None:
+            k, n_out = self.k, self.n_out
+            dev = self.nbr.device
+            nblocks = (n_out + 1023) // 1024
+            nbsizes = torch.zeros(k, dtype=torch.int32, device=dev)
+            block_counts = torch.empty(k, max(nblocks, 1), dtype=torch.int32, device=dev)
+            L.call('u2mkd_kmap_sizes', L.ptr(self.nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts), L.stream())
+            total = int(nbsizes.sum().item())
+            nbmaps = torch.empty(total, 2, dtype=torch.int32, device=dev)
+            if total:
+                L.call('u2mkd_kmap_compact', L.ptr(self.nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts),
+                       L.ptr(nbmaps), L.stream())
+            self._rulebook = (nbmaps, nbsizes)
+        return self._rulebook
+
+    def __len__(self):
+        return 3
+
+    def __getitem__(self, i):
+        if i == 0:
+            return self.rulebook()[0]
+        if i == 1:
+            return self.rulebook()[1]
+        if i == 2:
+            return (self.n_in, self.n_out)
+        raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self[0], self[1], self[2]))
+
+
+def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> KernelMap:
+    """Hash the input coordinates, probe every (output, offset) and fill the
+    neighbour table (v1.4.0 conv3d kmap build, fused)."""
+    coords = _i32(coords).contiguous()
+    L.require_cuda(coords)
+    dev = coords.device
+    n_in = coords.shape[0]
+    offsets = get_kernel_offsets(kernel_size, stride=tensor_stride, device=dev)
+    k = offsets.shape[0]
+    table = HashTable(sphash(coords))
+    strided = any(s > 1 for s in stride)
+    out_coords = spdownsample(coords, stride, kernel_size, tensor_stride) if strided else coords
+    n_out = out_coords.shape[0]
+    nbr = torch.empty(k, n_out, dtype=torch.int32, device=dev)
+    L.call('u2mkd_kmap_build_table', L.ptr(table.buf), n_in, L.ptr(out_coords), n_out, L.ptr(offsets), k,
+           L.ptr(nbr), L.stream())
+    symmetric = (not strided) and (k % 2 == 1)
+    nbr_inv = None
+    if not symmetric:
+        nbr_inv = torch.full((k, n_in), -1, dtype=torch.int32, device=dev)
+        L.call('u2mkd_kmap_invert', L.ptr(nbr), n_out, k, n_in, L.ptr(nbr_inv), L.stream())
+    return KernelMap(nbr, nbr_inv, n_in, n_out, symmetric, out_coords)
+
+
+# --------------------------------------------------------------------- conv
+def _conv_os(feats, wt, cout, nbr, n_rows, kflip):
+    """out[j] = sum_k feats[nbr[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin]."""
+    n_in, cin = feats.shape
+    k = nbr.shape[0]
+    out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
+    L.call('u2mkd_conv_forward', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(nbr), n_rows, k, int(kflip),
+           L.ptr(out), L.stream())
+    return out
+
+
+def _transpose_weights(weight):
+    k, cin, cout = weight.shape
+    wt = torch.empty(k, cout, cin, dtype=torch.float32, device=weight.device)
+    L.call('u2mkd_transpose_weights', L.ptr(weight), k, cin, cout, L.ptr(wt), L.stream())
+    return wt
+
+
+class ConvolutionFunction(Function):
+    """Sparse conv forward / backward on the neighbour tables of a KernelMap."""
+
+    @staticmethod
+    def forward(ctx, input, weight, kmap, transposed=False):
+        L.require_cuda(input, weight)
+        input = input.contiguous().float()
+        weight = weight.contiguous().float()
+        k, cin, cout = weight.shape
+        if input.shape[1] != cin:
+            raise RuntimeError(f'conv3d: input has {input.shape[1]} channels, kernel expects {cin}')
+        if cin % 4 != 0:
+            raise RuntimeError(f'conv3d: in_channels={cin} must be a multiple of 4 (16-byte row gathers)')
+        if not transposed:
+            tbl, n_rows = kmap.nbr, kmap.n_out
+            expect = kmap.n_in
+        else:
+            tbl, n_rows = kmap.nbr_inv, kmap.n_in
+            expect = kmap.n_out
+        if input.shape[0] != expect:
+            raise RuntimeError(f'conv3d: {input.shape[0]} input rows, kernel map expects {expect}')
+        wt = _transpose_weights(weight)
+        out = _conv_os(input, wt, cout, tbl, n_rows, 0)
+        ctx.save_for_backward(input, weight)
+        ctx.kmap = kmap
+        ctx.transposed = transposed
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        kmap, transposed = ctx.kmap, ctx.transposed
+        g = grad_output.contiguous().float()
+        k, cin, cout = weight.shape
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            # dX[i] = sum_k dY[out_k(i)] @ W[k]^T : same kernel on the swapped-role table,
+            # B_k = W[k] read as [cin][cout] (reduction over cout contiguous).
+            if not transposed:
+                if kmap.symmetric:
+                    tbl, kflip = kmap.nbr, 1
+                else:
+                    tbl, kflip = kmap.nbr_inv, 0
+            else:
+                tbl, kflip = kmap.nbr, 0
+            if cout % 4 != 0:
+                raise RuntimeError(f'conv3d backward: out_channels={cout} must be a multiple of 4')
+            grad_input = _conv_os(g, weight, cin, tbl, input.shape[0], kflip)
+        if ctx.needs_input_grad[1]:
+            # dW[k] = sum_pairs X[in]^T dY[out]; the table rows are the map's output side.
+            n_rows = kmap.n_out
+            a_gathered = 0 if transposed else 1
+            lib = L.load()
+            nbytes = lib.u2mkd_conv_wgrad_workspace_bytes(n_rows, cin, cout, k)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+            grad_weight = torch.empty_like(weight)
+            L.call('u2mkd_conv_wgrad', L.ptr(input), cin, L.ptr(g), cout, L.ptr(kmap.nbr), n_rows, k, a_gathered,
+                   1 if kmap.symmetric else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), L.stream())
+        return grad_input, grad_weight, None, None
+
+
+def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, stride=1, dilation=1,
+           transposed: bool = False) -> SparseTensor:
+    feats, coords = input.feats, input.coords
+    kernel_size = make_ntuple(kernel_size, ndim=3)
+    stride = make_ntuple(stride, ndim=3)
+    dilation = make_ntuple(dilation, ndim=3)
+
+    if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
+        feats = feats.matmul(weight)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(coords=coords, feats=feats, stride=input.stride)
+    elif not transposed:
+        key = (input.stride, kernel_size, stride, dilation)
+        kmap = input.kmaps.get(key)
+        if kmap is None:
+            # v1.4.0 builds the offsets from the tensor stride only (dilation is not applied)
+            kmap = build_kmap(coords, input.stride, kernel_size, stride)
+            input.kmaps[key] = kmap
+        feats = ConvolutionFunction.apply(feats, weight, kmap, transposed)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(coords=kmap.out_coords, feats=feats,
+                              stride=tuple(input.stride[k] * stride[k] for k in range(3)))
+    else:
+        tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
+        kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
+        feats = ConvolutionFunction.apply(feats, weight, kmap, transposed)
+        if bias is not None:
+            feats = feats + bias
+        output = SparseTensor(coords=input.cmaps[tensor_stride], feats=feats, stride=tensor_stride)
+
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(output.stride, output.coords)
+    output.kmaps = input.kmaps
+    return output
