@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""U2MKD hot-path benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one training step of the LiDAR hot path on one synthetic batch
+already resident in HBM: forward, Lovasz+CE loss, zero_grad, backward,
+SGD(nesterov) step, LR-scheduler step (the train branch of the reference's
+``_run_step``, core/spformer_trainer.py:58-94).  Workload at every N =
+BASELINE.json configs[1]: SPVCNN cr=1.0, LiDAR-only, one 80 000-voxel synthetic
+scene per GPU (weak scaling; scenes are independent, gradients are all-reduced
+by DDP over RCCL, BatchNorm statistics by SyncBatchNorm as the reference does).
+
+Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel group
+(SubMConv3d 64->64 k=3 at 80k voxels: forward + dgrad + wgrad), timed live with
+HIP events on the launch stream; ``cpu_baseline`` is the CPU oracle timed on
+the host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+N_VOX = 80000
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--voxels', type=int, default=N_VOX)
+    ap.add_argument('--cr', type=float, default=1.0)
+    ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-voxels', type=int, default=40000)
+    return ap.parse_args()
+
+
+def subm_algorithmic_bytes(n, p, cin, cout, k=27, s=4):
+    """bytes of SubMConv3d fwd + dgrad + wgrad, each gathered row
+    read once per pass, outputs written once, 8 B per (in,out) map entry."""
+    fwd = p * (cin * s + 8) + n * cout * s + k * cin * cout * s
+    dgrad = p * (cout * s + 8) + n * cin * s + k * cin * cout * s
+    wgrad = p * ((cin + cout) * s + 8) + k * cin * cout * s
+    return fwd, dgrad, wgrad
+
+
+def time_events(fn, iters, warmup=3):
+    """Average duration (ms) of fn() measured with HIP events on the current
+    stream -- the stream every u2mkd kernel is launched on."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def roofline_leg(coords_dev, iters=50):
+    """North-star micro-shape: Conv3d(64, 64, k=3, stride 1) on the scene's
+    stride-1 map; fwd, dgrad and wgrad each timed separately."""
+    from u2mkd_amd import _lib as L
+    from u2mkd_amd.torchsparse.nn import functional as F
+    cin = cout = 64
+    km = F.build_kmap(coords_dev, (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    n = km.n_out
+    p = int((km.nbr >= 0).sum().item())
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(n, cin, device='cuda', generator=g)
+    w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
+    gy = torch.randn(n, cout, device='cuda', generator=g)
+    wt = F._transpose_weights(w)
+    lib = L.load()
+    nbytes = lib.u2mkd_conv_wgrad_workspace_bytes(n, cin, cout, 27)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    dw = torch.empty_like(w)
+    out = torch.empty(n, cout, device='cuda')
+    dx = torch.empty(n, cin, device='cuda')
+    st = L.stream()
+
+    def fwd():
+        L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), n, 27, 0, L.ptr(out), st)
+
+    def dgrad():
+        L.call('u2mkd_conv_forward', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(km.nbr), n, 27, 1, L.ptr(dx), st)
+
+    def wgrad():
+        L.call('u2mkd_conv_wgrad', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(km.nbr), n, 27, 1, 1, L.ptr(ws), nbytes,
+               L.ptr(dw), st)
+
+    t_f, t_d, t_w = (time_events(f, iters) for f in (fwd, dgrad, wgrad))
+    b_f, b_d, b_w = subm_algorithmic_bytes(n, p, cin, cout)
+    total_b, total_t = b_f + b_d + b_w, t_f + t_d + t_w
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+    flops = 6.0 * p * cin * cout
+    return {
+        'bound': 'hbm', 'achieved': round(gbs(total_b, total_t), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(gbs(total_b, total_t) / HBM_PEAK_GBS, 4), 'traffic': None,
+        'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_os_kernel x2 + conv_wgrad_kernel), N=%d Cin=Cout=64 K=27' % n,
+        'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
+        'ms': {'fwd': round(t_f, 4), 'dgrad': round(t_d, 4), 'wgrad': round(t_w, 4), 'total': round(total_t, 4)},
+        'GBps': {'fwd': round(gbs(b_f, t_f), 1), 'dgrad': round(gbs(b_d, t_d), 1), 'wgrad': round(gbs(b_w, t_w), 1)},
+        'mfma_f32_tflops': round(flops / (total_t * 1e-3) / 1e12, 2), 'mfma_f32_peak_tflops': 157.3,
+    }
+
+
+def cpu_baseline_leg(n_vox, cr):
+    """The CPU oracle (a port of the torchsparse v1.4.0 CPU algorithm: per kernel
+    offset gather -> mm -> scatter-add) on the host cores: one fwd+bwd step of the
+    same network on a bounded sample scene."""
+    from oracle import spvcnn_ref as O
+    from oracle import torchsparse_cpu as ots
+    from u2mkd_amd.synth import synth_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = synth_batch(n_vox, 1, seed=1234)
+    model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
+    t0 = time.perf_counter()
+    out = model({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
+    loss = O.mix_lovasz_cross_entropy(out, labels)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {'value': round(n_vox / dt, 1), 'unit': 'points/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic '
+                      'scene, CPU oracle (torch CPU %d threads), %.1f s' % (cr, n_vox, cores, dt)}
+
+
+def cosine_warmup_lambda(num_epochs, batch_size, dataset_size, world):
+    """core/schedulers.py:10-35 (cosine_schedule_with_warmup)."""
+    def fn(k):
+        bs = batch_size * world
+        if world == 1:
+            warmup_iters = 0
+        else:
+            warmup_iters = 1000 // world
+        if k < warmup_iters:
+            return (k + 1) / warmup_iters
+        iter_per_epoch = (dataset_size + bs - 1) // bs
+        ratio = (k - warmup_iters) / (num_epochs * iter_per_epoch)
+        return 0.5 * (1 + np.cos(np.pi * ratio))
+    return fn
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    from u2mkd_amd.synth import synth_batch
+
+    b = synth_batch(args.voxels, 1, seed=1234 + rank)
+    feats = torch.from_numpy(b['feats']).cuda()
+    coords = torch.from_numpy(b['coords']).cuda()
+    labels = torch.from_numpy(b['labels']).cuda()
+
+    result = {}
+    if not args.kernel_only:
+        torch.manual_seed(0)
+        model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+        net = model
+        if world > 1:
+            model = lidar.SparseSyncBatchNorm.convert_sync_batchnorm(model)
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank],
+                                                            find_unused_parameters=False,
+                                                            gradient_as_bucket_view=True)
+        criterion = MixLovaszCrossEntropy(ignore_index=0)
+        opt = torch.optim.SGD(net.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, cosine_warmup_lambda(25, 1, 28130, world))
+
+        def step():
+            out = net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+            loss = criterion(out, labels)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            return loss
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        total_points = world * args.voxels * args.steps
+        result.update({
+            'metric': 'LiDAR points/sec/node fwd+bwd (teacher+student+KD), 1/2/4/8 MI355X',
+            'value': round(total_points / dt, 1), 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE '
+                                   '+ bwd + SGD), one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels),
+                       'voxels_per_gpu': args.voxels, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(float(loss), 5)},
+        })
+
+    if rank == 0:
+        result['roofline'] = roofline_leg(coords)
+        if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
+            result['cpu_baseline'] = cpu_baseline_leg(args.cpu_sample_voxels, args.cr)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
