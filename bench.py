@@ -161,6 +161,14 @@ def cosine_warmup_lambda(num_epochs, batch_size, dataset_size, world):
     return fn
 
 
+def log(msg):
+    sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -205,8 +213,10 @@ def main():
             sched.step()
             return loss
 
+        log('model built, scene resident; warm-up')
         for _ in range(args.warmup):
             step()
+        log('warm-up done')
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -217,6 +227,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        log('timed region done: %.3f s' % dt)
         if world > 1:
             t = torch.tensor([dt], device='cuda', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -235,6 +246,7 @@ def main():
 
     if rank == 0:
         result['roofline'] = roofline_leg(coords)
+        log('roofline leg done')
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             result['cpu_baseline'] = cpu_baseline_leg(args.cpu_sample_voxels, args.cr)
         print(json.dumps(result), flush=True)

@@ -15,21 +15,27 @@ __all__ = ['lovasz_softmax_flat', 'Lovasz_softmax', 'MixLovaszCrossEntropy']
 
 
 def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-    """probas [P, C] (rows of valid points only), labels [P]; classes='present'."""
+    """probas [P, C] (rows of valid points only), labels [P]; classes='present'.
+
+    Works on the [C, P] transpose so that the sort and the two cumulative sums
+    run along the contiguous dimension (a dim-0 cumsum of a [P, C] tensor is a
+    14 ms kernel at P = 80k on MI355X; the row-wise scan is ~20 us)."""
     if probas.numel() == 0:
         return probas.sum() * 0.
     P, C = probas.shape
-    fg = F.one_hot(labels, C).to(probas.dtype)                 # [P, C]
-    errors = (fg - probas).abs()
-    errors_sorted, perm = torch.sort(errors, 0, descending=True)
-    fg_sorted = torch.gather(fg, 0, perm)
-    gts = fg_sorted.sum(0, keepdim=True)                        # [1, C]
-    intersection = gts - fg_sorted.cumsum(0)
-    union = gts + (1. - fg_sorted).cumsum(0)
+    pt = probas.t().contiguous()                                 # [C, P]
+    fg = (labels.unsqueeze(0) == torch.arange(C, device=labels.device).unsqueeze(1)).to(probas.dtype)
+    errors = (fg - pt).abs()
+    errors_sorted, perm = torch.sort(errors, 1, descending=True)
+    fg_sorted = torch.gather(fg, 1, perm)
+    gts = fg_sorted.sum(1, keepdim=True)                         # [C, 1]
+    cs = fg_sorted.cumsum(1)
+    intersection = gts - cs
+    union = gts + (torch.arange(1, P + 1, device=probas.device, dtype=probas.dtype).unsqueeze(0) - cs)
     jaccard = 1. - intersection / union
-    jaccard = torch.cat([jaccard[:1], jaccard[1:] - jaccard[:-1]], 0)
-    per_class = (errors_sorted * jaccard).sum(0)                # [C]
-    present = (gts.squeeze(0) > 0).to(probas.dtype)
+    jaccard = torch.cat([jaccard[:, :1], jaccard[:, 1:] - jaccard[:, :-1]], 1)
+    per_class = (errors_sorted * jaccard).sum(1)                 # [C]
+    present = (gts.squeeze(1) > 0).to(probas.dtype)
     return (per_class * present).sum() / present.sum().clamp(min=1.)
 
 
