@@ -87,7 +87,9 @@ def roofline_leg(coords_dev, iters=50):
     gy = torch.randn(n, cout, device='cuda', generator=g)
     wt = F._transpose_weights(w)
     lib = L.load()
-    nbytes = lib.u2mkd_conv_wgrad_workspace_bytes(n, cin, cout, 27)
+    nbr_s, order = km.sorted_table(False)
+    pairs, _, plan = km.pairs_plan()
+    nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     dw = torch.empty_like(w)
     out = torch.empty(n, cout, device='cuda')
@@ -95,14 +97,16 @@ def roofline_leg(coords_dev, iters=50):
     st = L.stream()
 
     def fwd():
-        L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), n, 27, 0, L.ptr(out), st)
+        L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), n, 27, 0,
+               0, L.ptr(out), st)
 
     def dgrad():
-        L.call('u2mkd_conv_forward', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(km.nbr), n, 27, 1, L.ptr(dx), st)
+        L.call('u2mkd_conv_forward_sorted', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(nbr_s), L.ptr(order), n, 27, 1,
+               0, L.ptr(dx), st)
 
     def wgrad():
-        L.call('u2mkd_conv_wgrad', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(km.nbr), n, 27, 1, 1, L.ptr(ws), nbytes,
-               L.ptr(dw), st)
+        L.call('u2mkd_conv_wgrad_pairs', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(pairs), L.ptr(plan), n, 27, 0,
+               L.ptr(ws), nbytes, L.ptr(dw), st)
 
     t_f, t_d, t_w = (time_events(f, iters) for f in (fwd, dgrad, wgrad))
     b_f, b_d, b_w = subm_algorithmic_bytes(n, p, cin, cout)
@@ -112,7 +116,7 @@ def roofline_leg(coords_dev, iters=50):
     return {
         'bound': 'hbm', 'achieved': round(gbs(total_b, total_t), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(gbs(total_b, total_t) / HBM_PEAK_GBS, 4), 'traffic': None,
-        'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_os_kernel x2 + conv_wgrad_kernel), N=%d Cin=Cout=64 K=27' % n,
+        'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_os2_kernel x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
         'ms': {'fwd': round(t_f, 4), 'dgrad': round(t_d, 4), 'wgrad': round(t_w, 4), 'total': round(total_t, 4)},
         'GBps': {'fwd': round(gbs(b_f, t_f), 1), 'dgrad': round(gbs(b_d, t_d), 1), 'wgrad': round(gbs(b_w, t_w), 1)},

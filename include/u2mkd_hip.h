@@ -92,6 +92,18 @@ int u2mkd_transpose_weights(const float *w /*[k,cin,cout]*/, int32_t k, int32_t 
 int u2mkd_conv_forward(const float *in /*[n_in,cin]*/, int64_t n_in, int32_t cin, const float *wt /*[k,cout,cin]*/,
                        int32_t cout, const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t kflip,
                        float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* Same contraction on a MASK-SORTED table: row p of nbr_sorted / of the launch grid is
+ * original row order[p] (order == NULL: identity).  Sorting rows by their 27-bit
+ * neighbour mask makes 16-row MFMA blocks mask-homogeneous, so empty (block, offset)
+ * slots are skipped.  variant: 0 = built-in heuristic, else waves*100 + KC (tuning knob:
+ * waves in {4,8,16} = 64/128/256-row workgroup tiles, KC in {32,64} channels per stage).  */
+int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                              const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
+                              int64_t n_out, int32_t k, int32_t kflip, int32_t variant,
+                              float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* neighbour mask of every output row: bit k set iff nbr[k][j] >= 0 (k <= 32). */
+int u2mkd_kmap_rowmask(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t *mask /*[n_out]*/,
+                       u2mkd_stream_t s);
 /* dW[k] = sum_j A_j^T B_j over rows with nbr[k][j] >= 0, where
  *   a_gathered = 1: A_j = a[nbr[k][j]], B_j = b[j]       (normal conv)
  *   a_gathered = 0: A_j = a[j],         B_j = b[nbr[k][j]] (transposed conv)
@@ -101,6 +113,18 @@ size_t u2mkd_conv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, 
 int u2mkd_conv_wgrad(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *nbr /*[k,n_rows]*/,
                      int64_t n_rows, int32_t k, int32_t a_gathered, int32_t centre_dense,
                      void *workspace, size_t workspace_bytes, float *dw /*[k,ca,cb]*/, u2mkd_stream_t s);
+
+/* Weight gradient over the compacted pair list (the rulebook of u2mkd_kmap_compact; the
+ * buffer may be over-allocated, only plan[0] = P pairs are read).  u2mkd_wgrad_plan turns
+ * nbsizes into the device-side work split (no host sync); plan has u2mkd_wgrad_plan_ints(k)
+ * int32 entries.  swap = 0: A rows = pairs[:,0], B rows = pairs[:,1] (normal conv: A = the
+ * layer input, B = grad_output); swap = 1: the transposed conv.  Deterministic.           */
+int32_t u2mkd_wgrad_plan_ints(int32_t k);
+int u2mkd_wgrad_plan(const int32_t *nbsizes /*[k]*/, int32_t k, int64_t n_rows, int32_t *plan, u2mkd_stream_t s);
+size_t u2mkd_conv_wgrad_pairs_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k);
+int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs /*[>=P,2]*/,
+                           const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
+                           size_t workspace_bytes, float *dw /*[k,ca,cb]*/, u2mkd_stream_t s);
 
 /* ---- point <-> voxel ---------------------------------------------------
  * replace torchsparse.backend.count_cuda, voxelize_forward/backward_cuda,

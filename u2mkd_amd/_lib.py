@@ -33,8 +33,14 @@ SIGNATURES = {
     'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_kmap_rowmask': (C.c_int, [_p, _i64, _i32, _p, _p]),
     'u2mkd_conv_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'u2mkd_conv_wgrad': (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p, _p]),
+    'u2mkd_wgrad_plan_ints': (_i32, [_i32]),
+    'u2mkd_wgrad_plan': (C.c_int, [_p, _i32, _i64, _p, _p]),
+    'u2mkd_conv_wgrad_pairs_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'u2mkd_conv_wgrad_pairs': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     'u2mkd_count': (C.c_int, [_p, _i64, _p, _i64, _p]),
     'u2mkd_voxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_voxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),

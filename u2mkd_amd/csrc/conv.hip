@@ -33,82 +33,154 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
     wt[t] = w[(k * cin + ci) * cout + co];
 }
 
-template <int MR, int NB>
-__global__ void __launch_bounds__(256)
-conv_os_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
-               const int32_t *__restrict__ nbr, int64_t n_out, int K, int kflip, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+// ---- output-stationary kernel, LDS-staged weights -----------------------------------
+// Workgroup = WAVES waves = 16*WAVES output rows (mask-sorted order) x 16*NB output columns;
+// every wave owns one 16-row MFMA block and all NB column blocks.
+//   * the tile's neighbour indices (K x TM) and row ids are loaded once into LDS; the OR
+//     of the rows' neighbour masks gives the offsets this tile visits at all;
+//   * per (offset, KC-channel chunk) stage: the B tile wt[k][col0..][c..c+KC) is staged
+//     through LDS once for all waves ([col][ci] rows of KC+8 floats: a lane's
+//     ds_read_b128 of 4 consecutive ci is bank-conflict free), A rows are gathered
+//     straight into MFMA operand registers; the global loads of stage s+1 are issued
+//     before the MFMAs of stage s (register double buffering), one barrier per stage;
+//   * a wave whose 16 rows have no neighbour at the offset skips its MFMAs;
+//   * consecutive MFMAs go to different accumulators (16x16x4 f32 has a 40-cycle
+//     dependent latency against a 32-cycle issue interval).
+template <int WAVES, int NB, int KC>
+__global__ void __launch_bounds__(64 * WAVES)
+conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
+                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, int64_t n_out, int K, int kflip,
+                float *__restrict__ out) {
+    constexpr int NT = 64 * WAVES;
+    constexpr int TM = 16 * WAVES, TN = 16 * NB;
+    constexpr int BS = KC + 8;                          // LDS row stride (floats)
+    constexpr int F4ROW = KC / 4;                       // float4 per B row
+    constexpr int BPASS = (TN * F4ROW + NT - 1) / NT;   // float4 B loads per thread per stage
+    constexpr int NJ = KC / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Bs = reinterpret_cast<float *>(smem);                 // [2][TN][BS]
+    int *s_idx = reinterpret_cast<int *>(Bs + 2 * TN * BS);      // [K][TM]
+    int *s_rid = s_idx + K * TM;                                 // [TM]
+    unsigned *s_mask = reinterpret_cast<unsigned *>(s_rid + TM); // [1]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t row0 = tile * (16 * MR);
-    if (row0 >= n_out) return;  // wave-uniform
-    const int col0 = blockIdx.y * (16 * NB);
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int col0 = blockIdx.y * TN;
 
-    f32x4 acc[MR][NB];
+    if (tid == 0) *s_mask = 0u;
+    for (int e = tid; e < TM; e += NT) {
+        int64_t row = row0 + e;
+        s_rid[e] = row < n_out ? (order ? order[row] : (int)row) : -1;
+    }
+    __syncthreads();
+    unsigned mymask = 0u;
+    for (int e = tid; e < K * TM; e += NT) {
+        int k = e / TM, rr = e - k * TM;
+        int64_t row = row0 + rr;
+        int v = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+        s_idx[e] = v;
+        if (v >= 0) mymask |= 1u << k;
+    }
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int off = 32; off >= 1; off >>= 1) mymask |= __shfl_xor(mymask, off);
+    if (lane == 0 && mymask) atomicOr(s_mask, mymask);
+    __syncthreads();
+    unsigned km = *s_mask;
 
-    int64_t rows[MR];
+    f32x4 acc[NB];
 #pragma unroll
-    for (int m = 0; m < MR; ++m) rows[m] = row0 + 16 * m + r;
+    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int idx_next[MR];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) idx_next[m] = rows[m] < n_out ? nbr[rows[m]] : -1;
+    const int nchunk = (cin + KC - 1) / KC;
+    const int wrow = 16 * wave;   // first tile-local row of this wave
 
-    for (int k = 0; k < K; ++k) {
-        int idx[MR];
-        bool mine = false;
-#pragma unroll
-        for (int m = 0; m < MR; ++m) { idx[m] = idx_next[m]; mine |= idx[m] >= 0; }
-        if (k + 1 < K) {
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-                idx_next[m] = rows[m] < n_out ? nbr[(int64_t)(k + 1) * n_out + rows[m]] : -1;
-        }
-        if (__ballot(mine) == 0ULL) continue;  // no row of this tile has a neighbour at offset k
+    float4 a_cur[NJ], a_nxt[NJ], breg[BPASS];
+    bool act_cur = false, act_nxt = false;
+
+    auto load_stage = [&](int k, int c, float4 (&a)[NJ], bool &active) {
         const float *wk = wt + (size_t)(kflip ? K - 1 - k : k) * cout * cin;
-        for (int c0 = 0; c0 < cin; c0 += 16) {
-            const int ci = c0 + 4 * q;
-            const bool cok = ci < cin;
-            float4 a[MR], b[NB];
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                a[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx[m] >= 0 && cok) a[m] = *reinterpret_cast<const float4 *>(in + (size_t)idx[m] * cin + ci);
+        for (int p = 0; p < BPASS; ++p) {
+            int f = tid + NT * p;
+            int col = f / F4ROW, ci = c * KC + (f % F4ROW) * 4;
+            breg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < TN && col0 + col < cout && ci < cin)
+                breg[p] = *reinterpret_cast<const float4 *>(wk + (size_t)(col0 + col) * cin + ci);
+        }
+        int idx = s_idx[k * TM + wrow + r];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int ci = c * KC + 16 * j + 4 * q;
+            a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx >= 0 && ci < cin) a[j] = *reinterpret_cast<const float4 *>(in + (size_t)idx * cin + ci);
+        }
+        active = __ballot(idx >= 0) != 0ULL;
+    };
+    auto store_B = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int f = tid + NT * p;
+            int col = f / F4ROW;
+            if (col < TN)
+                *reinterpret_cast<float4 *>(Bs + ((size_t)buf * TN + col) * BS + (f % F4ROW) * 4) = breg[p];
+        }
+    };
+
+    if (km) {
+        int k = __builtin_ctz(km);
+        km &= km - 1;
+        int c = 0;
+        load_stage(k, 0, a_cur, act_cur);
+        store_B(0);
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            int kn = k, cn = c + 1;
+            bool have_next = true;
+            if (cn == nchunk) {
+                cn = 0;
+                if (km) { kn = __builtin_ctz(km); km &= km - 1; } else have_next = false;
             }
+            if (have_next) load_stage(kn, cn, a_nxt, act_nxt);
+            if (act_cur) {
+                const float *bb = Bs + (size_t)buf * TN * BS + r * BS + 4 * q;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                b[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok && col0 + 16 * n + r < cout)
-                    b[n] = *reinterpret_cast<const float4 *>(wk + (size_t)(col0 + 16 * n + r) * cin + ci);
-            }
+                for (int j = 0; j < NJ; ++j) {
+                    float4 b[NB];
 #pragma unroll
-            for (int m = 0; m < MR; ++m)
+                    for (int n = 0; n < NB; ++n) b[n] = *reinterpret_cast<const float4 *>(bb + 16 * n * BS + 16 * j);
 #pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, b[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, b[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, b[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, b[n].w, acc[n], 0, 0, 0);
                 }
+            }
+            if (!have_next) break;
+            store_B(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            k = kn;
+            c = cn;
+            act_cur = act_nxt;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) a_cur[j] = a_nxt[j];
         }
     }
-    // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    // epilogue: D row = 4q + reg, col = r; rows go to their original (unsorted) positions
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int reg = 0; reg < 4; ++reg) {
+        int rid = s_rid[wrow + 4 * q + reg];
+        if (rid >= 0) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            int64_t row = row0 + 16 * m + 4 * q + reg;
-            if (row < n_out) {
-#pragma unroll
-                for (int n = 0; n < NB; ++n)
-                    if (col0 + 16 * n + r < cout) out[row * cout + col0 + 16 * n + r] = acc[m][n][reg];
-            }
+            for (int n = 0; n < NB; ++n)
+                if (col0 + 16 * n + r < cout) out[(size_t)rid * cout + col0 + 16 * n + r] = acc[n][reg];
         }
+    }
 }
 
 // ---- weight gradient ---------------------------------------------------------
@@ -215,6 +287,170 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs0, int S0, co
     dw[(size_t)k * tile_elems + e] = acc;
 }
 
+// ---- weight gradient over the compacted pair list (rulebook) ----------------------------
+// dW[k] = sum over the pairs of offset k of A[pa]^T B[pb].  The pairs are the MFMA
+// reduction dimension: a workgroup stages CP pairs' rows (both operands gathered, full
+// 16-byte coalesced segments) into LDS as [pair][channel] images whose row stride is
+// == 16 (mod 32) floats, so the transposed operand reads (ds_read_b32, 16 channels x 4
+// pairs per wave instruction) are bank-conflict free.  Work split: every offset's pair
+// segment is cut into chunks of plan.ch pairs (computed on the device from the pair
+// count, so no host sync); workgroup w finds its (offset, chunk) in the 27-entry prefix.
+// Partial tiles go to slabs; wgrad_pairs_reduce_kernel sums them in a fixed order.
+//
+// plan layout (int32): [0] = P, [1] = CH, [2 .. 2+K] = pair offsets kofs[0..K],
+//                      [3+K .. 3+2K] = workgroup prefix wg[0..K].
+__global__ void wgrad_plan_kernel(const int32_t *__restrict__ nbsizes, int K, int g_target, int cp,
+                                  int32_t *__restrict__ plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int P = 0;
+    for (int k = 0; k < K; ++k) { plan[2 + k] = P; P += nbsizes[k]; }
+    plan[2 + K] = P;
+    int ch = (P + g_target - 1) / g_target;
+    if (ch < 256) ch = 256;
+    ch = (ch + cp - 1) / cp * cp;
+    plan[0] = P;
+    plan[1] = ch;
+    int w = 0;
+    for (int k = 0; k < K; ++k) { plan[3 + K + k] = w; w += (nbsizes[k] + ch - 1) / ch; }
+    plan[3 + 2 * K] = w;
+}
+
+template <int WM, int WN, int CP>
+__global__ void __launch_bounds__(256)
+conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
+                        const int32_t *__restrict__ pairs, const int32_t *__restrict__ plan, int K, int swap,
+                        int tiles_b, float *__restrict__ slabs) {
+    constexpr int TA = 32 * WM, TB = 32 * WN;
+    constexpr int SA = TA + 16 - (TA % 32 == 16 ? 16 : 0);   // row stride == 16 (mod 32)
+    constexpr int SB = TB + 16 - (TB % 32 == 16 ? 16 : 0);
+    constexpr int FA = TA / 4, FB = TB / 4;                  // float4 per staged row
+    constexpr int PA = (CP * FA + 255) / 256, PB = (CP * FB + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);             // [2][CP][SA]
+    float *Bs = As + 2 * CP * SA;                            // [2][CP][SB]
+
+    const int w = blockIdx.x;
+    const int *wg = plan + 3 + K;
+    if (w >= wg[K]) return;
+    int k = 0;
+    while (w >= wg[k + 1]) ++k;
+    const int ch = plan[1];
+    const int p_begin = plan[2 + k] + (w - wg[k]) * ch;
+    const int p_end = min(p_begin + ch, plan[2 + k + 1]);
+
+    const int ta = blockIdx.y / tiles_b, tb = blockIdx.y % tiles_b;
+    const int a0 = ta * TA, b0 = tb * TB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wy = wave >> 1, wx = wave & 1;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[PA], rb[PB];
+    auto load_chunk = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int f = tid + 256 * i;
+            int pr = f / FA, c = (f % FA) * 4;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < CP && p0 + pr < p_end && a0 + c < ca) {
+                int row = pairs[2 * (size_t)(p0 + pr) + (swap ? 1 : 0)];
+                ra[i] = *reinterpret_cast<const float4 *>(a + (size_t)row * ca + a0 + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int f = tid + 256 * i;
+            int pr = f / FB, c = (f % FB) * 4;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < CP && p0 + pr < p_end && b0 + c < cb) {
+                int row = pairs[2 * (size_t)(p0 + pr) + (swap ? 0 : 1)];
+                rb[i] = *reinterpret_cast<const float4 *>(b + (size_t)row * cb + b0 + c);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int f = tid + 256 * i;
+            int pr = f / FA, c = (f % FA) * 4;
+            if (pr < CP) *reinterpret_cast<float4 *>(As + ((size_t)buf * CP + pr) * SA + c) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int f = tid + 256 * i;
+            int pr = f / FB, c = (f % FB) * 4;
+            if (pr < CP) *reinterpret_cast<float4 *>(Bs + ((size_t)buf * CP + pr) * SB + c) = rb[i];
+        }
+    };
+
+    int buf = 0;
+    load_chunk(p_begin);
+    store_chunk(0);
+    __syncthreads();
+    for (int p0 = p_begin; p0 < p_end; p0 += CP) {
+        const bool have_next = p0 + CP < p_end;
+        if (have_next) load_chunk(p0 + CP);
+        const float *ap = As + (size_t)buf * CP * SA + q * SA + 16 * WM * wy + r;
+        const float *bp = Bs + (size_t)buf * CP * SB + q * SB + 16 * WN * wx + r;
+#pragma unroll 4
+        for (int s4 = 0; s4 < CP / 4; ++s4) {
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) av[m] = ap[s4 * 4 * SA + 16 * m];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv[n] = bp[s4 * 4 * SB + 16 * n];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+        if (have_next) {
+            store_chunk(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // D[i = a channel][j = b channel]: row = 4q + reg, col = r
+    float *slab = slabs + (size_t)w * ca * cb;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            int ach = a0 + 16 * (WM * wy + m) + 4 * q + reg;
+            if (ach < ca) {
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    int bch = b0 + 16 * (WN * wx + n) + r;
+                    if (bch < cb) slab[(size_t)ach * cb + bch] = acc[m][n][reg];
+                }
+            }
+        }
+}
+
+__global__ void wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ plan, int K,
+                                          int64_t tile_elems, float *__restrict__ dw) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (e >= tile_elems) return;
+    const int *wg = plan + 3 + K;
+    float acc = 0.f;
+    for (int w = wg[k]; w < wg[k + 1]; ++w) acc += slabs[(size_t)w * tile_elems + e];
+    dw[(size_t)k * tile_elems + e] = acc;
+}
+
+static int wgrad_g_target(int64_t n_rows, int k) {
+    int64_t g = (n_rows * (k < 8 ? k : 8) + 511) / 512;
+    if (g < 32) g = 32;
+    if (g > 768) g = 768;
+    return (int)g;
+}
+
 struct WgradPlan {
     int S0, S1, k_centre;
     size_t bytes;
@@ -244,13 +480,18 @@ static WgradPlan wgrad_plan(int64_t n_rows, int ca, int cb, int K, int centre_de
     return p;
 }
 
-template <int MR>
-static int launch_conv_os(int nb, dim3 grid, hipStream_t st, const float *in, int cin, const float *wt, int cout,
-                          const int32_t *nbr, int64_t n_out, int K, int kflip, float *out) {
-#define U2_CASE(N)                                                                                             \
-    case N:                                                                                                    \
-        hipLaunchKernelGGL((conv_os_kernel<MR, N>), grid, dim3(256), 0, st, in, cin, wt, cout, nbr, n_out, K, \
-                           kflip, out);                                                                        \
+template <int WAVES, int KC>
+static int launch_conv_os2(int nb, dim3 grid, int K, hipStream_t st, const float *in, int cin, const float *wt,
+                           int cout, const int32_t *nbr, const int32_t *order, int64_t n_out, int kflip, float *out) {
+    const int tm = 16 * WAVES, tn = 16 * nb;
+    size_t lds = (size_t)2 * tn * (KC + 8) * 4 + (size_t)K * tm * 4 + (size_t)tm * 4 + 16;
+#define U2_CASE(N)                                                                                                 \
+    case N:                                                                                                        \
+        if (lds > 65536)                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_os2_kernel<WAVES, N, KC>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((conv_os2_kernel<WAVES, N, KC>), grid, dim3(64 * WAVES), lds, st, in, cin, wt, cout,    \
+                           nbr, order, n_out, K, kflip, out);                                                      \
         break;
     switch (nb) {
         U2_CASE(1) U2_CASE(2) U2_CASE(3) U2_CASE(4) U2_CASE(5) U2_CASE(6) U2_CASE(7) U2_CASE(8)
@@ -260,7 +501,6 @@ static int launch_conv_os(int nb, dim3 grid, hipStream_t st, const float *in, in
     return 0;
 }
 
-// column blocks (of 16) per wave: all of them up to 8, else the largest divisor <= 8
 static int pick_nb(int cout16) {
     if (cout16 <= 8) return cout16;
     for (int nb = 8; nb >= 4; --nb)
@@ -283,21 +523,106 @@ int u2mkd_transpose_weights(const float *w, int32_t k, int32_t cin, int32_t cout
     return check_launch("u2mkd_transpose_weights");
 }
 
+int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
+                               int32_t variant, float *out, u2mkd_stream_t s);
+
 int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
                        int64_t n_out, int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
+    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, n_out, k, kflip, 0, out, s);
+}
+
+int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
+                               int32_t variant, float *out, u2mkd_stream_t s) {
     if (n_out == 0) return 0;
-    U2_REQUIRE(in && wt && nbr && out, "u2mkd_conv_forward: null pointer");
-    U2_REQUIRE(cin > 0 && cin % 4 == 0, "u2mkd_conv_forward: cin=%d must be a positive multiple of 4", cin);
-    U2_REQUIRE(cout > 0, "u2mkd_conv_forward: cout=%d must be positive", cout);
-    U2_REQUIRE(k > 0 && n_in >= 0, "u2mkd_conv_forward: bad sizes");
+    U2_REQUIRE(in && wt && nbr_sorted && out, "u2mkd_conv_forward_sorted: null pointer");
+    U2_REQUIRE(cin > 0 && cin % 4 == 0, "u2mkd_conv_forward_sorted: cin=%d must be a positive multiple of 4", cin);
+    U2_REQUIRE(cout > 0, "u2mkd_conv_forward_sorted: cout=%d must be positive", cout);
+    U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "u2mkd_conv_forward_sorted: kernel volume %d not in 1..32", k);
     const int c16 = (cout + 15) / 16;
     const int nb = pick_nb(c16);
-    constexpr int MR = 2;
-    int64_t tiles = ceil_div(n_out, 16 * MR);
-    dim3 grid((unsigned)ceil_div(tiles, 4), (unsigned)ceil_div(c16, nb));
-    int rc = launch_conv_os<MR>(nb, grid, as_stream(s), in, cin, wt, cout, nbr, n_out, k, kflip, out);
+    // variant: 0 = heuristic; otherwise waves * 100 + kc (e.g. 464 = 4 waves, KC 64)
+    int waves, kc;
+    if (variant == 0) {
+        kc = cin % 64 == 0 ? 64 : 32;   // measured: ab_conv.py (64/128/256/384 -> 64; 32/96 -> 32)
+        waves = 4;                      // larger tiles lose more to per-wave offset imbalance than they save on B
+    } else {
+        waves = variant / 100;
+        kc = variant % 100;
+    }
+    U2_REQUIRE((waves == 4 || waves == 8 || waves == 16) && (kc == 32 || kc == 64),
+               "u2mkd_conv_forward_sorted: bad variant %d", variant);
+    dim3 grid((unsigned)ceil_div(n_out, 16 * waves), (unsigned)ceil_div(c16, nb));
+    hipStream_t st = as_stream(s);
+    int rc;
+#define U2_V(W, KCV) rc = launch_conv_os2<W, KCV>(nb, grid, k, st, in, cin, wt, cout, nbr_sorted, order, n_out, kflip, out)
+    if (waves == 4 && kc == 32) U2_V(4, 32);
+    else if (waves == 4) U2_V(4, 64);
+    else if (waves == 8 && kc == 32) U2_V(8, 32);
+    else if (waves == 8) U2_V(8, 64);
+    else if (kc == 32) U2_V(16, 32);
+    else U2_V(16, 64);
+#undef U2_V
     if (rc) return rc;
-    return check_launch("u2mkd_conv_forward");
+    return check_launch("u2mkd_conv_forward_sorted");
+}
+
+int32_t u2mkd_wgrad_plan_ints(int32_t k) { return 4 + 2 * k; }
+
+int u2mkd_wgrad_plan(const int32_t *nbsizes, int32_t k, int64_t n_rows, int32_t *plan, u2mkd_stream_t s) {
+    U2_REQUIRE(nbsizes && plan, "u2mkd_wgrad_plan: null pointer");
+    U2_REQUIRE(k > 0 && k <= 64, "u2mkd_wgrad_plan: kernel volume %d not in 1..64", k);
+    hipLaunchKernelGGL(wgrad_plan_kernel, dim3(1), dim3(64), 0, as_stream(s), nbsizes, k, wgrad_g_target(n_rows, k), 64,
+                       plan);
+    return check_launch("u2mkd_wgrad_plan");
+}
+
+size_t u2mkd_conv_wgrad_pairs_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k) {
+    return ((size_t)wgrad_g_target(n_rows, k) + k) * (size_t)ca * cb * sizeof(float);
+}
+
+int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs,
+                           const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
+                           size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
+    U2_REQUIRE(a && b && pairs && plan && workspace && dw, "u2mkd_conv_wgrad_pairs: null pointer");
+    U2_REQUIRE(ca > 0 && cb > 0 && ca % 4 == 0 && cb % 4 == 0,
+               "u2mkd_conv_wgrad_pairs: ca=%d cb=%d must be positive multiples of 4", ca, cb);
+    U2_REQUIRE(k > 0 && k <= 64, "u2mkd_conv_wgrad_pairs: kernel volume %d not in 1..64", k);
+    const int g = wgrad_g_target(n_rows, k) + k;
+    U2_REQUIRE(workspace_bytes >= (size_t)g * ca * cb * sizeof(float), "u2mkd_conv_wgrad_pairs: workspace too small");
+    hipStream_t st = as_stream(s);
+    auto pick = [](int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); };
+    const int wm = pick(ca), wn = pick(cb);
+    const int tiles_a = (ca + 32 * wm - 1) / (32 * wm), tiles_b = (cb + 32 * wn - 1) / (32 * wn);
+    dim3 grid(g, tiles_a * tiles_b);
+    float *slabs = reinterpret_cast<float *>(workspace);
+#define U2_WP(WM_, WN_)                                                                                             \
+    do {                                                                                                            \
+        constexpr int CP_ = 64;                                                                                     \
+        constexpr int TA_ = 32 * WM_, TB_ = 32 * WN_;                                                               \
+        constexpr int SA_ = TA_ + 16 - (TA_ % 32 == 16 ? 16 : 0), SB_ = TB_ + 16 - (TB_ % 32 == 16 ? 16 : 0);       \
+        size_t lds = (size_t)2 * CP_ * (SA_ + SB_) * 4;                                                             \
+        if (lds > 65536)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_pairs_kernel<WM_, WN_, CP_>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        hipLaunchKernelGGL((conv_wgrad_pairs_kernel<WM_, WN_, CP_>), grid, dim3(256), lds, st, a, ca, b, cb, pairs, \
+                           plan, k, swap, tiles_b, slabs);                                                          \
+    } while (0)
+    if (wm == 1 && wn == 1) U2_WP(1, 1);
+    else if (wm == 1 && wn == 2) U2_WP(1, 2);
+    else if (wm == 1 && wn == 4) U2_WP(1, 4);
+    else if (wm == 2 && wn == 1) U2_WP(2, 1);
+    else if (wm == 2 && wn == 2) U2_WP(2, 2);
+    else if (wm == 2 && wn == 4) U2_WP(2, 4);
+    else if (wm == 4 && wn == 1) U2_WP(4, 1);
+    else if (wm == 4 && wn == 2) U2_WP(4, 2);
+    else U2_WP(4, 4);
+#undef U2_WP
+    int64_t tile_elems = (int64_t)ca * cb;
+    hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 256), k), dim3(256), 0, st,
+                       slabs, plan, k, tile_elems, dw);
+    return check_launch("u2mkd_conv_wgrad_pairs");
 }
 
 size_t u2mkd_conv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k) {

@@ -83,6 +83,16 @@ __global__ void kmap_invert_kernel(const int32_t *__restrict__ nbr, int64_t n_ou
     }
 }
 
+__global__ void kmap_rowmask_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int k_total,
+                                    int32_t *__restrict__ mask) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    unsigned m = 0u;
+    for (int k = 0; k < k_total; ++k)
+        if (nbr[(int64_t)k * n_out + j] >= 0) m |= 1u << k;
+    mask[j] = (int32_t)m;
+}
+
 // ---- rulebook compaction (torchsparse nbmaps order: by k, ascending out) ----
 // 1024 rows per block; wave ballots give the in-block rank of every valid pair.
 constexpr int kCompactBlock = 1024;
@@ -245,6 +255,15 @@ int u2mkd_kmap_invert(const int32_t *nbr, int64_t n_out, int32_t k, int64_t n_in
     hipLaunchKernelGGL(kmap_invert_kernel, dim3((unsigned)ceil_div(n_out, 256), k), dim3(256), 0, as_stream(s), nbr,
                        n_out, n_in, nbr_inv);
     return check_launch("u2mkd_kmap_invert");
+}
+
+int u2mkd_kmap_rowmask(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *mask, u2mkd_stream_t s) {
+    if (n_out == 0) return 0;
+    U2_REQUIRE(nbr && mask, "u2mkd_kmap_rowmask: null pointer");
+    U2_REQUIRE(k > 0 && k <= 31, "u2mkd_kmap_rowmask: kernel volume %d not in 1..31", k);
+    hipLaunchKernelGGL(kmap_rowmask_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, as_stream(s), nbr,
+                       n_out, k, mask);
+    return check_launch("u2mkd_kmap_rowmask");
 }
 
 int u2mkd_kmap_sizes(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *nbsizes, int32_t *block_counts,

@@ -207,21 +207,52 @@ class KernelMap:
         self.symmetric = bool(symmetric)
         self.out_coords = out_coords
         self._rulebook = None
+        self._pairs = None
+        self._sorted = {}
 
-    def rulebook(self):
-        if self._rulebook is None:
+    def sorted_table(self, inverse=False):
+        """(table with its rows permuted into neighbour-mask order, order int32 [rows]).
+        Mask-sorted rows make the kernel's 16-row MFMA blocks mask-homogeneous so
+        (block, offset) slots without any neighbour are skipped."""
+        hit = self._sorted.get(inverse)
+        if hit is None:
+            tbl = self.nbr_inv if inverse else self.nbr
+            k, n = tbl.shape
+            mask = torch.empty(n, dtype=torch.int32, device=tbl.device)
+            L.call('u2mkd_kmap_rowmask', L.ptr(tbl), n, k, L.ptr(mask), L.stream())
+            order = torch.argsort(mask, stable=True).int()
+            hit = (tbl.index_select(1, order.long()).contiguous(), order)
+            self._sorted[inverse] = hit
+        return hit
+
+    def pairs_plan(self):
+        """(pairs int32 [cap,2] rows (in,out) grouped by offset, nbsizes int32 [K], plan int32):
+        the compacted rulebook plus the device-side work split of the weight-gradient
+        kernel.  Built without any host synchronisation: the pair buffer is sized by
+        the upper bound K * n_out and only its first P rows are meaningful."""
+        if self._pairs is None:
             k, n_out = self.k, self.n_out
             dev = self.nbr.device
-            nblocks = (n_out + 1023) // 1024
+            nblocks = max((n_out + 1023) // 1024, 1)
             nbsizes = torch.zeros(k, dtype=torch.int32, device=dev)
-            block_counts = torch.empty(k, max(nblocks, 1), dtype=torch.int32, device=dev)
-            L.call('u2mkd_kmap_sizes', L.ptr(self.nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts), L.stream())
-            total = int(nbsizes.sum().item())
-            nbmaps = torch.empty(total, 2, dtype=torch.int32, device=dev)
-            if total:
+            block_counts = torch.empty(k, nblocks, dtype=torch.int32, device=dev)
+            cap = max(min(k * n_out, self.n_in * k), 1)
+            pairs = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+            plan = torch.empty(L.load().u2mkd_wgrad_plan_ints(k), dtype=torch.int32, device=dev)
+            if n_out:
+                L.call('u2mkd_kmap_sizes', L.ptr(self.nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts), L.stream())
                 L.call('u2mkd_kmap_compact', L.ptr(self.nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts),
-                       L.ptr(nbmaps), L.stream())
-            self._rulebook = (nbmaps, nbsizes)
+                       L.ptr(pairs), L.stream())
+            L.call('u2mkd_wgrad_plan', L.ptr(nbsizes), k, n_out, L.ptr(plan), L.stream())
+            self._pairs = (pairs, nbsizes, plan)
+        return self._pairs
+
+    def rulebook(self):
+        """torchsparse's (nbmaps [P,2], nbsizes [K]); trimming to P is the only host sync."""
+        if self._rulebook is None:
+            pairs, nbsizes, plan = self.pairs_plan()
+            total = int(plan[0].item())
+            self._rulebook = (pairs[:total], nbsizes)
         return self._rulebook
 
     def __len__(self):
@@ -265,13 +296,16 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> Kern
 
 
 # --------------------------------------------------------------------- conv
-def _conv_os(feats, wt, cout, nbr, n_rows, kflip):
-    """out[j] = sum_k feats[nbr[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin]."""
+def _conv_os(feats, wt, cout, kmap, inverse, n_rows, kflip):
+    """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin];
+    tbl = the kernel map's (inverse) neighbour table, walked in mask-sorted row order."""
     n_in, cin = feats.shape
-    k = nbr.shape[0]
+    nbr_s, order = kmap.sorted_table(inverse)
+    k = nbr_s.shape[0]
+    assert nbr_s.shape[1] == n_rows
     out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
-    L.call('u2mkd_conv_forward', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(nbr), n_rows, k, int(kflip),
-           L.ptr(out), L.stream())
+    L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order),
+           n_rows, k, int(kflip), 0, L.ptr(out), L.stream())
     return out
 
 
@@ -296,15 +330,15 @@ class ConvolutionFunction(Function):
         if cin % 4 != 0:
             raise RuntimeError(f'conv3d: in_channels={cin} must be a multiple of 4 (16-byte row gathers)')
         if not transposed:
-            tbl, n_rows = kmap.nbr, kmap.n_out
+            inverse, n_rows = False, kmap.n_out
             expect = kmap.n_in
         else:
-            tbl, n_rows = kmap.nbr_inv, kmap.n_in
+            inverse, n_rows = True, kmap.n_in
             expect = kmap.n_out
         if input.shape[0] != expect:
             raise RuntimeError(f'conv3d: {input.shape[0]} input rows, kernel map expects {expect}')
         wt = _transpose_weights(weight)
-        out = _conv_os(input, wt, cout, tbl, n_rows, 0)
+        out = _conv_os(input, wt, cout, kmap, inverse, n_rows, 0)
         ctx.save_for_backward(input, weight)
         ctx.kmap = kmap
         ctx.transposed = transposed
@@ -321,25 +355,21 @@ class ConvolutionFunction(Function):
             # dX[i] = sum_k dY[out_k(i)] @ W[k]^T : same kernel on the swapped-role table,
             # B_k = W[k] read as [cin][cout] (reduction over cout contiguous).
             if not transposed:
-                if kmap.symmetric:
-                    tbl, kflip = kmap.nbr, 1
-                else:
-                    tbl, kflip = kmap.nbr_inv, 0
+                inverse, kflip = (False, 1) if kmap.symmetric else (True, 0)
             else:
-                tbl, kflip = kmap.nbr, 0
+                inverse, kflip = False, 0
             if cout % 4 != 0:
                 raise RuntimeError(f'conv3d backward: out_channels={cout} must be a multiple of 4')
-            grad_input = _conv_os(g, weight, cin, tbl, input.shape[0], kflip)
+            grad_input = _conv_os(g, weight, cin, kmap, inverse, input.shape[0], kflip)
         if ctx.needs_input_grad[1]:
-            # dW[k] = sum_pairs X[in]^T dY[out]; the table rows are the map's output side.
-            n_rows = kmap.n_out
-            a_gathered = 0 if transposed else 1
+            # dW[k] = sum over the offset's pairs of X[in]^T dY[out] (transposed conv: roles swapped)
+            pairs, _, plan = kmap.pairs_plan()
             lib = L.load()
-            nbytes = lib.u2mkd_conv_wgrad_workspace_bytes(n_rows, cin, cout, k)
+            nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(kmap.n_out, cin, cout, k)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             grad_weight = torch.empty_like(weight)
-            L.call('u2mkd_conv_wgrad', L.ptr(input), cin, L.ptr(g), cout, L.ptr(kmap.nbr), n_rows, k, a_gathered,
-                   1 if kmap.symmetric else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), L.stream())
+            L.call('u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout, L.ptr(pairs), L.ptr(plan), kmap.n_out,
+                   k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), L.stream())
         return grad_input, grad_weight, None, None
 
 
