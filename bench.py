@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--cr', type=float, default=1.0)
     ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-voxels', type=int, default=40000)
+    ap.add_argument('--cpu-sample-voxels', type=int, default=20000)
     return ap.parse_args()
 
 
@@ -124,29 +124,48 @@ def roofline_leg(coords_dev, iters=50):
     }
 
 
-def cpu_baseline_leg(n_vox, cr):
+CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import torch
+from oracle import spvcnn_ref as O
+from oracle import torchsparse_cpu as ots
+from u2mkd_amd.synth import synth_batch
+n_vox, cr, threads = %(n_vox)d, %(cr)r, %(threads)d
+torch.set_num_threads(threads)
+b = synth_batch(n_vox, 1, seed=1234)
+model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
+opt = torch.optim.SGD(model.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
+t0 = time.perf_counter()
+out = model({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
+loss = O.mix_lovasz_cross_entropy(out, labels)
+opt.zero_grad(); loss.backward(); opt.step()
+print(json.dumps({'dt': time.perf_counter() - t0}))
+"""
+
+
+def cpu_baseline_leg(n_vox, cr, timeout_s=240):
     """The CPU oracle (a port of the torchsparse v1.4.0 CPU algorithm: per kernel
-    offset gather -> mm -> scatter-add) on the host cores: one fwd+bwd step of the
-    same network on a bounded sample scene."""
-    from oracle import spvcnn_ref as O
-    from oracle import torchsparse_cpu as ots
-    from u2mkd_amd.synth import synth_batch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    b = synth_batch(n_vox, 1, seed=1234)
-    model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
-    feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
-    t0 = time.perf_counter()
-    out = model({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
-    loss = O.mix_lovasz_cross_entropy(out, labels)
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {'value': round(n_vox / dt, 1), 'unit': 'points/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic '
-                      'scene, CPU oracle (torch CPU %d threads), %.1f s' % (cr, n_vox, cores, dt)}
+    offset gather -> mm -> scatter-add) on the host cores: one training step of the
+    same network on a bounded sample scene.  Runs in a child process (bounded by a
+    timeout) with a bounded thread count: the reference's CPU backend only threads
+    its GEMMs, and 256 OpenMP threads on tiny ops crawl."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 16)
+    code = CPU_CHILD % {'root': ROOT, 'n_vox': n_vox, 'cr': cr, 'threads': threads}
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+               OPENBLAS_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    sample = ('1 training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic scene, '
+              'CPU oracle, %d threads' % (cr, n_vox, threads))
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        dt = json.loads(r.stdout.strip().splitlines()[-1])['dt']
+    except Exception as e:  # timeout / crash: report it, never block the bench line
+        return {'value': None, 'unit': 'points/s', 'cores': threads, 'kind': 'port',
+                'sample': sample + ' -- FAILED: %s' % type(e).__name__}
+    return {'value': round(n_vox / dt, 1), 'unit': 'points/s', 'cores': threads, 'kind': 'port',
+            'sample': sample + ', %.1f s' % dt}
 
 
 def cosine_warmup_lambda(num_epochs, batch_size, dataset_size, world):
@@ -175,14 +194,10 @@ _T0 = time.perf_counter()
 
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    from u2mkd_amd import distributed as D
+    rank, world, local_rank = D.init_from_env('nccl')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from u2mkd_amd import lidar, torchsparse as ts
@@ -198,12 +213,7 @@ def main():
     if not args.kernel_only:
         torch.manual_seed(0)
         model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
-        net = model
-        if world > 1:
-            model = lidar.SparseSyncBatchNorm.convert_sync_batchnorm(model)
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank],
-                                                            find_unused_parameters=False,
-                                                            gradient_as_bucket_view=True)
+        net = D.wrap_model(model, sync_bn=True)
         criterion = MixLovaszCrossEntropy(ignore_index=0)
         opt = torch.optim.SGD(net.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, cosine_warmup_lambda(25, 1, 28130, world))
@@ -232,10 +242,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         log('timed region done: %.3f s' % dt)
-        if world > 1:
-            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = D.max_over_ranks(dt)
         total_points = world * args.voxels * args.steps
         result.update({
             'metric': 'LiDAR points/sec/node fwd+bwd (teacher+student+KD), 1/2/4/8 MI355X',
@@ -245,18 +252,17 @@ def main():
             'config': {'workload': 'BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE '
                                    '+ bwd + SGD), one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels),
                        'voxels_per_gpu': args.voxels, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
-                       'final_loss': round(float(loss), 5)},
+                       'final_loss': round(float(loss.detach()), 5)},
         })
 
     if rank == 0:
         result['roofline'] = roofline_leg(coords)
         log('roofline leg done')
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
+            log('cpu baseline (child process)')
             result['cpu_baseline'] = cpu_baseline_leg(args.cpu_sample_voxels, args.cr)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,66 @@
+"""N>1 path on CPU: 2 processes, gloo.  Each rank trains on ITS OWN scene
+(no data-path collective); DDP must leave every rank with the mean of the
+per-rank gradients.  The network is the CPU oracle SPVCNN (the HIP operators
+have no CPU path), wrapped by the product's u2mkd_amd.distributed helpers."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene_grads(seed, wrap):
+    from oracle import spvcnn_ref as O
+    from oracle import torchsparse_cpu as ots
+    from u2mkd_amd.synth import synth_batch
+    b = synth_batch(600, 1, seed=seed)
+    feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
+    m = O.fill_state_by_name(O.SPVCNN(cr=0.25, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
+    m.dropout.p = 0.0
+    net = wrap(m)
+    out = net({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
+    O.mix_lovasz_cross_entropy(out, labels).backward()
+    return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from u2mkd_amd import distributed as D
+    r, w, _ = D.init_from_env('gloo')
+    assert (r, w) == (rank, world) and D.world() == 2
+    seed = D.scene_seed(100)
+    assert seed == 100 + rank
+    grads = _scene_grads(seed, lambda m: D.wrap_model(m, sync_bn=False))
+    assert D.max_over_ranks(float(rank)) == 1.0
+    torch.save(grads, os.path.join(out_dir, f'g{rank}.pt'))
+    D.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradients_are_the_mean(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0 = torch.load(os.path.join(tmp_path, 'g0.pt'))
+    g1 = torch.load(os.path.join(tmp_path, 'g1.pt'))
+    torch.set_num_threads(2)
+    s0 = _scene_grads(100, lambda m: m)
+    s1 = _scene_grads(101, lambda m: m)
+    for name in g0:
+        assert torch.equal(g0[name], g1[name]), name          # all-reduced: identical on both ranks
+        want = (s0[name] + s1[name]) / 2
+        assert torch.allclose(g0[name], want, rtol=1e-4, atol=1e-6), name
