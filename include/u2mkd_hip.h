@@ -144,6 +144,26 @@ int u2mkd_devoxelize_backward(const float *grad_out /*[n,c]*/, const int32_t *id
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 
+/* ---- BatchNorm over feature rows (+ fused ReLU) ------------------------------
+ * replaces spnn.BatchNorm + spnn.ReLU (nn.BatchNorm1d / nn.ReLU over SparseTensor.feats,
+ * core/models/build_blocks.py:30-31,48-49,64-65,71,77).  Same statistics as
+ * nn.BatchNorm1d: biased variance for normalisation, unbiased for running_var,
+ * running = (1 - momentum) * running + momentum * batch.  Deterministic (slab partials in
+ * `partial`, [u2mkd_bn_num_slabs(n), 2, c] floats, merged in slab order).
+ * gamma / beta / running_* may be NULL.  relu != 0 fuses max(., 0) (backward re-derives the
+ * mask from x).                                                                          */
+int64_t u2mkd_bn_num_slabs(int64_t n);
+int u2mkd_bn_train_forward(const float *x /*[n,c]*/, int64_t n, int32_t c, const float *gamma, const float *beta,
+                           float eps, float momentum, float *running_mean, float *running_var, int32_t relu,
+                           float *partial, float *mean /*[c] out*/, float *invstd /*[c] out*/, float *y /*[n,c]*/,
+                           u2mkd_stream_t s);
+int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
+                          const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c] out*/,
+                          float *y, u2mkd_stream_t s);
+int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
+                      float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx /*[n,c]*/, u2mkd_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

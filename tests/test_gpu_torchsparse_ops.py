@@ -224,3 +224,36 @@ def test_empty_and_ragged(F):
     assert _rel(out, R.conv_forward(x, w, nbmaps, nbsizes, (3, 3))) < 1e-5
     with pytest.raises(RuntimeError):
         F.sphash(torch.zeros(3, 4, dtype=torch.int32))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('n,c', [(5000, 32), (80000, 96), (777, 256), (3000, 4), (1300, 48)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_batch_norm_matches_torch_cpu(F, n, c, relu):
+    """HIP BatchNorm(+ReLU) vs nn.BatchNorm1d (+ReLU) on the CPU in fp64: outputs, input and
+    affine gradients, running statistics; train and eval modes."""
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 2.5 + 3.0        # non-zero mean: exercises the centred variance
+    g = torch.randn(n, c)
+    ref = torch.nn.BatchNorm1d(c).double()
+    ref.weight.data.uniform_(0.5, 1.5)
+    ref.bias.data.normal_(0, 0.3)
+    ours = torch.nn.BatchNorm1d(c).cuda()
+    ours.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    for mode in ('train', 'eval'):
+        getattr(ref, mode)()
+        getattr(ours, mode)()
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        if relu:
+            yr = torch.relu(yr)
+        yr.backward(g.double())
+        xo = x.cuda().requires_grad_(True)
+        yo = F.batch_norm(xo, ours, relu)
+        yo.backward(g.cuda())
+        assert _rel(yo, yr) < 2e-6, mode
+        assert _rel(xo.grad, xr.grad) < 2e-5, mode
+        assert _rel(ours.weight.grad, ref.weight.grad) < 2e-5 and _rel(ours.bias.grad, ref.bias.grad) < 2e-5
+        assert _rel(ours.running_mean, ref.running_mean) < 1e-6 and _rel(ours.running_var, ref.running_var) < 1e-5
+        assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked)
+        ref.zero_grad()
+        ours.zero_grad()

@@ -41,6 +41,10 @@ SIGNATURES = {
     'u2mkd_wgrad_plan': (C.c_int, [_p, _i32, _i64, _p, _p]),
     'u2mkd_conv_wgrad_pairs_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'u2mkd_conv_wgrad_pairs': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
+    'u2mkd_bn_num_slabs': (_i64, [_i64]),
+    'u2mkd_bn_train_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_eval_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_count': (C.c_int, [_p, _i64, _p, _i64, _p]),
     'u2mkd_voxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_voxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),

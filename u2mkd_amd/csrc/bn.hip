@@ -1,0 +1,334 @@
+// BatchNorm over the rows of a [N, C] feature matrix, optionally fused with ReLU.
+// Replaces spnn.BatchNorm + spnn.ReLU (= nn.BatchNorm1d / nn.ReLU applied to
+// SparseTensor.feats through fapply; core/models/build_blocks.py:30-31,48-49,64-65,71,77;
+// 49 instances per SPVCNN).
+//
+// HBM-bound row work.  Statistics are deterministic and cancellation-safe:
+//   pass 1  each workgroup takes a slab of rows and computes, per channel, its local
+//           mean and the centred second moment M2 around that mean (the slab is re-read
+//           from L2), float4 columns x row lanes, LDS tree over the row lanes;
+//   pass 2  one thread per channel merges the slabs with Chan's parallel update in slab
+//           order (no atomics -> bitwise reproducible), writes mean / invstd and updates
+//           the running statistics (unbiased variance, momentum) like nn.BatchNorm1d;
+//   pass 3  y = (x - mean) * invstd * gamma + beta [, ReLU]  (float4 elementwise).
+// Backward mirrors it: slab partial sums of dy' and dy'*xhat (dy' = dy masked by the fused
+// ReLU, recomputed from x), ordered merge, then
+//   dx = gamma * invstd * (dy' - mean(dy') - xhat * mean(dy' * xhat)).
+#include "common.h"
+
+namespace u2mkd {
+
+constexpr int kBnThreads = 256;
+constexpr int kBnSlabRows = 512;   // rows per workgroup in the partial passes
+
+// thread layout for a [rows, C4 float4] slab: j = float4 column, ry = row lane
+struct BnLayout {
+    int c4, rl;
+};
+__device__ __forceinline__ BnLayout bn_layout(int c) {
+    BnLayout l;
+    l.c4 = c >> 2;
+    l.rl = kBnThreads / l.c4;
+    if (l.rl < 1) l.rl = 1;
+    return l;
+}
+
+// partial: [nslab][2][C] (mean_b, M2_b); rows of slab b = min(kBnSlabRows, n - b*kBnSlabRows)
+__global__ void __launch_bounds__(kBnThreads)
+bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];   // [rl][c4] (c4 <= 256)
+    const int c4 = c >> 2;
+    const int nloop = (c4 + kBnThreads - 1) / kBnThreads;           // > 1 only for C > 1024
+    const int64_t r0 = (int64_t)blockIdx.x * kBnSlabRows;
+    const int rows = (int)min((int64_t)kBnSlabRows, n - r0);
+    for (int it = 0; it < nloop; ++it) {
+        const int rl = c4 >= kBnThreads ? 1 : kBnThreads / c4;
+        const int j = c4 >= kBnThreads ? it * kBnThreads + threadIdx.x : threadIdx.x % c4;
+        const int ry = c4 >= kBnThreads ? 0 : threadIdx.x / c4;
+        const bool live = j < c4 && ry < rl;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+            for (int rr = ry; rr < rows; rr += rl) {
+                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        if (live) red[ry * c4 + (j % c4)] = s;
+        __syncthreads();
+        float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            for (int g = 0; g < rl; ++g) {
+                float4 v = red[g * c4 + (j % c4)];
+                mean.x += v.x; mean.y += v.y; mean.z += v.z; mean.w += v.w;
+            }
+            float inv = 1.f / (float)rows;
+            mean.x *= inv; mean.y *= inv; mean.z *= inv; mean.w *= inv;
+        }
+        __syncthreads();
+        float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+            for (int rr = ry; rr < rows; rr += rl) {
+                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
+                float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+                m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+            }
+        if (live) red[ry * c4 + (j % c4)] = m2;
+        __syncthreads();
+        if (live && ry == 0) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < rl; ++g) {
+                float4 v = red[g * c4 + (j % c4)];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *p = partial + (size_t)blockIdx.x * 2 * c;
+            *reinterpret_cast<float4 *>(p + 4 * j) = mean;
+            *reinterpret_cast<float4 *>(p + c + 4 * j) = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
+                                         float momentum, float *__restrict__ running_mean,
+                                         float *__restrict__ running_var, float *__restrict__ mean_out,
+                                         float *__restrict__ invstd_out) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = 0; b < nslab; ++b) {
+        float nb = (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows);
+        float mb = partial[(size_t)b * 2 * c + ch], m2b = partial[(size_t)b * 2 * c + c + ch];
+        float tot = na + nb;
+        float delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += m2b + delta * delta * (na * nb / tot);
+        na = tot;
+    }
+    float var = m2 / (float)n;
+    mean_out[ch] = mean;
+    invstd_out[ch] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+        float unbiased = n > 1 ? m2 / (float)(n - 1) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+}
+
+// y = (x - mean) * invstd * gamma + beta [, relu]; gamma / beta may be null (affine=False)
+__global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
+                                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, int relu, float *__restrict__ y) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    int j = (int)(t % c4) * 4;
+    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 m = *reinterpret_cast<const float4 *>(mean + j);
+    float4 is = *reinterpret_cast<const float4 *>(invstd + j);
+    float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = (v.x - m.x) * is.x * g.x + b.x;
+    o.y = (v.y - m.y) * is.y * g.y + b.y;
+    o.z = (v.z - m.z) * is.z * g.z + b.z;
+    o.w = (v.w - m.w) * is.w * g.w + b.w;
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4 *>(y)[t] = o;
+}
+
+// partial: [nslab][2][C] (sum dy', sum dy' * xhat)
+__global__ void __launch_bounds__(kBnThreads)
+bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t n, int c,
+                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                      const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                      float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];   // [2][rl][c4]
+    const int c4 = c >> 2;
+    const int nloop = (c4 + kBnThreads - 1) / kBnThreads;
+    const int64_t r0 = (int64_t)blockIdx.x * kBnSlabRows;
+    const int rows = (int)min((int64_t)kBnSlabRows, n - r0);
+    for (int it = 0; it < nloop; ++it) {
+        const int rl = c4 >= kBnThreads ? 1 : kBnThreads / c4;
+        const int j = c4 >= kBnThreads ? it * kBnThreads + threadIdx.x : threadIdx.x % c4;
+        const int ry = c4 >= kBnThreads ? 0 : threadIdx.x / c4;
+        const bool live = j < c4 && ry < rl;
+        const int cw = c4 >= kBnThreads ? kBnThreads : c4;
+        const int jl = c4 >= kBnThreads ? threadIdx.x : j;
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (live) {
+            float4 m = *reinterpret_cast<const float4 *>(mean + 4 * j);
+            float4 is = *reinterpret_cast<const float4 *>(invstd + 4 * j);
+            float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + 4 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 b = beta ? *reinterpret_cast<const float4 *>(beta + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rr = ry; rr < rows; rr += rl) {
+                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
+                float4 d = *reinterpret_cast<const float4 *>(dy + (r0 + rr) * c + 4 * j);
+                float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
+                if (relu) {
+                    if (hx * g.x + b.x <= 0.f) d.x = 0.f;
+                    if (hy * g.y + b.y <= 0.f) d.y = 0.f;
+                    if (hz * g.z + b.z <= 0.f) d.z = 0.f;
+                    if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+                }
+                s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                s2.x += d.x * hx; s2.y += d.y * hy; s2.z += d.z * hz; s2.w += d.w * hw;
+            }
+            red[ry * cw + jl] = s1;
+            red[(rl + ry) * cw + jl] = s2;
+        }
+        __syncthreads();
+        if (live && ry == 0) {
+            float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+            for (int gq = 0; gq < rl; ++gq) {
+                float4 a = red[gq * cw + jl], bq = red[(rl + gq) * cw + jl];
+                t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+                t2.x += bq.x; t2.y += bq.y; t2.z += bq.z; t2.w += bq.w;
+            }
+            float *p = partial + (size_t)blockIdx.x * 2 * c;
+            *reinterpret_cast<float4 *>(p + 4 * j) = t1;
+            *reinterpret_cast<float4 *>(p + c + 4 * j) = t2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c,
+                                       float *__restrict__ dbeta, float *__restrict__ dgamma) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nslab; ++b) {
+        s1 += partial[(size_t)b * 2 * c + ch];
+        s2 += partial[(size_t)b * 2 * c + c + ch];
+    }
+    dbeta[ch] = s1;
+    dgamma[ch] = s2;
+}
+
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
+                                    float inv_n, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                    const float *__restrict__ dbeta, const float *__restrict__ dgamma,
+                                    float *__restrict__ dx) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    int j = (int)(t % c4) * 4;
+    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 d = reinterpret_cast<const float4 *>(dy)[t];
+    float4 m = *reinterpret_cast<const float4 *>(mean + j);
+    float4 is = *reinterpret_cast<const float4 *>(invstd + j);
+    float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 db = *reinterpret_cast<const float4 *>(dbeta + j);
+    float4 dg = *reinterpret_cast<const float4 *>(dgamma + j);
+    float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
+    if (relu) {
+        if (hx * g.x + b.x <= 0.f) d.x = 0.f;
+        if (hy * g.y + b.y <= 0.f) d.y = 0.f;
+        if (hz * g.z + b.z <= 0.f) d.z = 0.f;
+        if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+    }
+    float4 o;
+    o.x = g.x * is.x * (d.x - db.x * inv_n - hx * dg.x * inv_n);
+    o.y = g.y * is.y * (d.y - db.y * inv_n - hy * dg.y * inv_n);
+    o.z = g.z * is.z * (d.z - db.z * inv_n - hz * dg.z * inv_n);
+    o.w = g.w * is.w * (d.w - db.w * inv_n - hw * dg.w * inv_n);
+    reinterpret_cast<float4 *>(dx)[t] = o;
+}
+
+// eval-mode backward / plain affine: dx = dy' * gamma * invstd
+__global__ void bn_bwd_eval_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
+                                   const float *__restrict__ mean, const float *__restrict__ invstd,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                   float *__restrict__ dx) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    int j = (int)(t % c4) * 4;
+    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 d = reinterpret_cast<const float4 *>(dy)[t];
+    float4 m = *reinterpret_cast<const float4 *>(mean + j);
+    float4 is = *reinterpret_cast<const float4 *>(invstd + j);
+    float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (relu) {
+        if ((v.x - m.x) * is.x * g.x + b.x <= 0.f) d.x = 0.f;
+        if ((v.y - m.y) * is.y * g.y + b.y <= 0.f) d.y = 0.f;
+        if ((v.z - m.z) * is.z * g.z + b.z <= 0.f) d.z = 0.f;
+        if ((v.w - m.w) * is.w * g.w + b.w <= 0.f) d.w = 0.f;
+    }
+    reinterpret_cast<float4 *>(dx)[t] = make_float4(d.x * g.x * is.x, d.y * g.y * is.y, d.z * g.z * is.z, d.w * g.w * is.w);
+}
+
+__global__ void bn_invstd_kernel(const float *__restrict__ var, int c, float eps, float *__restrict__ invstd) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < c) invstd[ch] = 1.f / sqrtf(var[ch] + eps);
+}
+
+static size_t bn_lds_bytes(int c, int arrays) {
+    int c4 = c / 4;
+    int rl = c4 >= kBnThreads ? 1 : kBnThreads / c4;
+    int cw = c4 >= kBnThreads ? kBnThreads : c4;
+    return (size_t)arrays * rl * cw * sizeof(float4);
+}
+
+}  // namespace u2mkd
+
+using namespace u2mkd;
+
+extern "C" {
+
+int64_t u2mkd_bn_num_slabs(int64_t n) { return n > 0 ? (n + kBnSlabRows - 1) / kBnSlabRows : 0; }
+
+int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
+                           float momentum, float *running_mean, float *running_var, int32_t relu,
+                           float *partial /*[slabs,2,c]*/, float *mean /*[c]*/, float *invstd /*[c]*/, float *y,
+                           u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(n > 0, "u2mkd_bn_train_forward: empty batch (n=%lld)", (long long)n);
+    U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
+    hipStream_t st = as_stream(s);
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, partial, nslab, n, c,
+                       eps, momentum, running_mean, running_var, mean, invstd);
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
+                       invstd, gamma, beta, relu, y);
+    return check_launch("u2mkd_bn_train_forward");
+}
+
+int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
+                          const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c]*/,
+                          float *y, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_eval_forward: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(x && running_mean && running_var && invstd && y, "u2mkd_bn_eval_forward: null pointer");
+    hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(bn_invstd_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, running_var, c, eps, invstd);
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
+                       running_mean, invstd, gamma, beta, relu, y);
+    return check_launch("u2mkd_bn_eval_forward");
+}
+
+int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
+                      float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward: c=%d must be a multiple of 4 in 4..1024", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(dy && x && mean && invstd && partial && dgamma && dbeta && dx, "u2mkd_bn_backward: null pointer");
+    hipStream_t st = as_stream(s);
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
+                       invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, partial, nslab, c,
+                       dbeta, dgamma);
+    int64_t total4 = n * (c / 4);
+    if (training)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
+                           c / 4, 1.f / (float)n, mean, invstd, gamma, beta, relu, dbeta, dgamma, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
+                           c / 4, mean, invstd, gamma, beta, relu, dx);
+    return check_launch("u2mkd_bn_backward");
+}
+
+}  // extern "C"

@@ -433,15 +433,36 @@ conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__rest
         }
 }
 
-__global__ void wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ plan, int K,
-                                          int64_t tile_elems, float *__restrict__ dw) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (e >= tile_elems) return;
+// dw[k][e] = sum of the offset's slabs, fixed order: 16 slab lanes x 16 float4 lanes per
+// block (64 elements); lane g sums slabs wg[k]+g, +16, ... and the 16 partials are added
+// in lane order through LDS (deterministic, ~P/CH/16 dependent loads per thread).
+__global__ void __launch_bounds__(256)
+wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ plan, int K,
+                          int64_t tile_elems, float *__restrict__ dw) {
+    __shared__ float4 part[16][16];
+    const int k = blockIdx.y;
+    const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t e = ((int64_t)blockIdx.x * 16 + lx) * 4;
     const int *wg = plan + 3 + K;
-    float acc = 0.f;
-    for (int w = wg[k]; w < wg[k + 1]; ++w) acc += slabs[(size_t)w * tile_elems + e];
-    dw[(size_t)k * tile_elems + e] = acc;
+    const int w0 = wg[k], w1 = wg[k + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < tile_elems) {
+        for (int w = w0 + g; w < w1; w += 16) {
+            float4 v = *reinterpret_cast<const float4 *>(slabs + (size_t)w * tile_elems + e);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    part[g][lx] = acc;
+    __syncthreads();
+    if (g == 0 && e < tile_elems) {
+        float4 t = part[0][lx];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+            float4 v = part[i][lx];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dw + (size_t)k * tile_elems + e) = t;
+    }
 }
 
 static int wgrad_g_target(int64_t n_rows, int k) {
@@ -620,7 +641,7 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     else U2_WP(4, 4);
 #undef U2_WP
     int64_t tile_elems = (int64_t)ca * cb;
-    hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 256), k), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 64), k), dim3(256), 0, st,
                        slabs, plan, k, tile_elems, dw);
     return check_launch("u2mkd_conv_wgrad_pairs");
 }

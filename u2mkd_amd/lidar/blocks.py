@@ -1,11 +1,48 @@
 """Sparse conv blocks with the reference's module layout
 (core/models/build_blocks.py:21-83) so state-dict keys match:
 ``net.0.kernel``, ``net.1.{weight,bias,running_*}``, ``downsample.0.kernel`` ..."""
+import torch
 from torch import nn
 
+from ..torchsparse import SparseTensor
 from ..torchsparse import nn as spnn
+from ..torchsparse.nn import functional as spf
+from ..torchsparse.nn.utils import fapply
 
-__all__ = ['BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock']
+__all__ = ['BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock', 'FusedSequential',
+           'PointBatchNorm1d']
+
+
+class PointBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d over point features [N, C] on the HIP BatchNorm kernels (the
+    reference's point_transforms use plain nn.BatchNorm1d, spvcnn.py:58-74; same keys)."""
+
+    def forward(self, input):
+        return spf.batch_norm(input, self)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the reference's layout (same state-dict keys) whose forward
+    runs every BatchNorm -> ReLU pair as ONE fused HIP pass (BN statistics, normalise,
+    affine and max(.,0) in a single read/write of the feature matrix)."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            fusable = (type(m) in (spnn.BatchNorm, PointBatchNorm1d) and type(nxt) in (spnn.ReLU, nn.ReLU))
+            if fusable:
+                if isinstance(x, SparseTensor):
+                    x = fapply(x, spf.batch_norm, m, True)
+                else:
+                    x = spf.batch_norm(x, m, True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 def _conv_bn(inc, outc, ks, stride=1, dilation=1, transposed=False, relu=True):
@@ -19,7 +56,7 @@ def _conv_bn(inc, outc, ks, stride=1, dilation=1, transposed=False, relu=True):
 class BasicConvolutionBlock(nn.Module):
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride, dilation))
+        self.net = FusedSequential(*_conv_bn(inc, outc, ks, stride, dilation))
 
     def forward(self, x):
         return self.net(x)
@@ -28,7 +65,7 @@ class BasicConvolutionBlock(nn.Module):
 class BasicDeconvolutionBlock(nn.Module):
     def __init__(self, inc, outc, ks=3, stride=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride, transposed=True))
+        self.net = FusedSequential(*_conv_bn(inc, outc, ks, stride, transposed=True))
 
     def forward(self, x):
         return self.net(x)
@@ -37,12 +74,12 @@ class BasicDeconvolutionBlock(nn.Module):
 class ResidualBlock(nn.Module):
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
-        self.net = nn.Sequential(*_conv_bn(inc, outc, ks, stride, dilation),
-                                 *_conv_bn(outc, outc, ks, 1, dilation, relu=False))
+        self.net = FusedSequential(*_conv_bn(inc, outc, ks, stride, dilation),
+                                   *_conv_bn(outc, outc, ks, 1, dilation, relu=False))
         if inc == outc and stride == 1:
             self.downsample = nn.Sequential()
         else:
-            self.downsample = nn.Sequential(*_conv_bn(inc, outc, 1, stride, 1, relu=False))
+            self.downsample = FusedSequential(*_conv_bn(inc, outc, 1, stride, 1, relu=False))
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):

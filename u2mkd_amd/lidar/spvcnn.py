@@ -8,7 +8,8 @@ from torch import nn
 from .. import torchsparse
 from ..torchsparse import PointTensor
 from ..torchsparse import nn as spnn
-from .blocks import BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock
+from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d,
+                     ResidualBlock)
 from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
 
 __all__ = ['SPVCNN']
@@ -29,7 +30,7 @@ class SPVCNN(nn.Module):
             self.pres = kwargs['pres']
             self.vres = kwargs['vres']
 
-        self.stem = nn.Sequential(
+        self.stem = FusedSequential(
             spnn.Conv3d(self.in_channel, cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True),
             spnn.Conv3d(cs[0], cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True))
 
@@ -50,7 +51,7 @@ class SPVCNN(nn.Module):
         self.classifier_vox = nn.Sequential(nn.Linear(cs[8], self.num_classes))
 
         self.point_transforms = nn.ModuleList([
-            nn.Sequential(nn.Linear(cs[a], cs[b]), nn.BatchNorm1d(cs[b]), nn.ReLU(True))
+            FusedSequential(nn.Linear(cs[a], cs[b]), PointBatchNorm1d(cs[b]), nn.ReLU(True))
             for a, b in ((0, 4), (4, 6), (6, 8))])
 
         self.weight_initialization()

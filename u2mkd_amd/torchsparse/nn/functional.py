@@ -22,7 +22,7 @@ from ..utils import make_ntuple
 from .utils import get_kernel_offsets
 
 __all__ = ['sphash', 'sphashquery', 'spcount', 'spvoxelize', 'spdevoxelize', 'calc_ti_weights',
-           'spdownsample', 'conv3d', 'KernelMap', 'HashTable', 'ti_weights_n8']
+           'spdownsample', 'conv3d', 'KernelMap', 'HashTable', 'ti_weights_n8', 'batch_norm']
 
 
 def _i32(t):
@@ -409,3 +409,66 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, st
     output.cmaps.setdefault(output.stride, output.coords)
     output.kmaps = input.kmaps
     return output
+
+
+# --------------------------------------------------------------- batch norm
+class BatchNormFunction(Function):
+    """BatchNorm over the rows of [N, C] (+ optional fused ReLU) on the HIP kernels of
+    csrc/bn.hip; statistics identical to nn.BatchNorm1d."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        L.require_cuda(x)
+        x = x.contiguous().float()
+        n, c = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        if training:
+            slabs = L.load().u2mkd_bn_num_slabs(n)
+            partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            L.call('u2mkd_bn_train_forward', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps), float(momentum),
+                   L.ptr(running_mean), L.ptr(running_var), int(relu), L.ptr(partial), L.ptr(mean), L.ptr(invstd),
+                   L.ptr(y), L.stream())
+        else:
+            mean = running_mean
+            L.call('u2mkd_bn_eval_forward', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+                   L.ptr(running_mean), L.ptr(running_var), int(relu), L.ptr(invstd), L.ptr(y), L.stream())
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu, ctx.training = bool(relu), bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        n, c = x.shape
+        dev = x.device
+        slabs = L.load().u2mkd_bn_num_slabs(n)
+        partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        L.call('u2mkd_bn_backward', L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
+               int(ctx.relu), int(ctx.training), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.stream())
+        return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None,
+                None, None, None, None, None, None)
+
+
+def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool = False) -> torch.Tensor:
+    """nn.BatchNorm1d semantics (training or eval, running statistics, momentum=None =
+    cumulative average) on a [N, C] tensor, optionally fused with ReLU."""
+    if x.dim() != 2:
+        raise RuntimeError(f'batch_norm expects [N, C] features, got {tuple(x.shape)}')
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    factor = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            factor = 1.0 / float(bn.num_batches_tracked)
+    if training and x.shape[0] < 2:
+        raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
+    rm = bn.running_mean if (not training or bn.track_running_stats) else None
+    rv = bn.running_var if (not training or bn.track_running_stats) else None
+    return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu)

@@ -65,8 +65,10 @@ class Conv3d(nn.Module):
 
 
 class BatchNorm(nn.BatchNorm1d):
+    """nn.BatchNorm1d over SparseTensor.feats on the HIP BatchNorm kernels."""
+
     def forward(self, input):
-        return fapply(input, super().forward)
+        return fapply(input, F.batch_norm, self)
 
 
 class ReLU(nn.ReLU):
