@@ -164,6 +164,41 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
                       const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
                       float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx /*[n,c]*/, u2mkd_stream_t s);
 
+/* ---- SphereFormer / sptr window attention ---------------------------------------
+ * replaces the extern "C" launchers of third_party/SparseTransformer/src/sptr:
+ *   precompute_all_cuda_launcher            (precompute/precompute_cuda_kernel.h)
+ *   dot_prod_with_idx_all_forward/_backward (rpe/relative_pos_encoding_cuda_kernel.h)
+ *   attention_step2_with_rel_pos_value_forward/_backward (same header)
+ *   attention_step1_backward_cuda_launcher  (attention/attention_cuda_kernel.h)
+ * plus torch_cluster grid_cluster, torch_scatter segment_csr softmax and the index glue of
+ * sptr/utils.py:49-95, sptr/modules.py:35-65.  No M-sized (pair) array exists: tokens are
+ * sorted by window key and each (token, head) walks its window.
+ *   keys     = grid_cluster key over (x,y,z,batch); lo4/hi4 = device min/max of (x,y,z,batch)
+ *   ranges   = per SORTED position: first position and length of its window
+ *   qc       = floor(((xyz - lo) % window) / quant) per sorted position (+ radial = xyz[:,2])
+ * q,k,v,out,dq,dk,dv: [n,h,16] in ORIGINAL token order (q pre-scaled); lse: [n,h] in sorted
+ * order; tables [L,3,h,16]; split_a > 0 selects the spherical branch (exponential radial
+ * split + clamp to [0, 2*qgl-1]).                                                         */
+int u2mkd_sptr_window_keys(const float *xyz /*[n,3]*/, const int32_t *batch /*[n]*/, int64_t n, const float *lo4,
+                           const float *hi4, float sx, float sy, float sz, int64_t *keys /*[n]*/, u2mkd_stream_t s);
+int u2mkd_sptr_window_ranges(const int64_t *sorted_keys, int64_t n, int32_t *wstart /*[n]*/, int32_t *wlen /*[n]*/,
+                             u2mkd_stream_t s);
+int u2mkd_sptr_quant_coords(const float *xyz /*[n,3]*/, const int32_t *sort_idx /*[n]*/, int64_t n, const float *lo,
+                            float wx, float wy, float wz, float qx, float qy, float qz, int32_t *qc /*[n,3]*/,
+                            float *radial /*[n] or NULL*/, u2mkd_stream_t s);
+int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v, const int32_t *sort_idx,
+                                 const int32_t *wstart, const int32_t *wlen, const int32_t *qc, const float *radial,
+                                 const float *tq, const float *tk, const float *tv, int32_t L, int32_t qgl,
+                                 float split_a, int64_t n, int32_t h, int32_t hdim, float *out, float *lse,
+                                 u2mkd_stream_t s);
+int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                  const float *lse, const int32_t *sort_idx, const int32_t *wstart,
+                                  const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
+                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n,
+                                  int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/, float *dq, float *dk,
+                                  float *dv, float *dtq /*pre-zeroed*/, float *dtk /*pre-zeroed*/,
+                                  float *dtv /*pre-zeroed*/, u2mkd_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,434 @@
+// SphereFormer / sptr variable-length window attention with contextual relative
+// position tables, fused.  Replaces, for the path the reference actually runs
+// (pe_type='contextual', rel_query=rel_key=rel_value=True):
+//   third_party/SparseTransformer/src/sptr/precompute/precompute_cuda_kernel.cu:4-35
+//   third_party/SparseTransformer/src/sptr/rpe/relative_pos_encoding_cuda_kernel.cu:42-149 (scores fwd/bwd)
+//   third_party/SparseTransformer/src/sptr/rpe/relative_pos_encoding_cuda_kernel.cu:151-274 (values fwd/bwd)
+//   third_party/SparseTransformer/src/sptr/attention/attention_cuda_kernel.cu:29-75   (q.k backward)
+//   sptr/utils.py:80-95 (CSR softmax) and the index glue of sptr/modules.py:35-65.
+//
+// The reference materialises M = sum_w L_w^2 pairs (index_0, index_1, rel_idx [M,3],
+// attn [M,h], softmax [M,h]) in HBM and walks them in five kernels.  Here nothing of
+// size M exists: tokens are sorted by window, every (token, head) thread walks the keys
+// of its window, derives the relative-position rows from per-token quantised
+// coordinates, keeps the three tables of its head in LDS and runs an online softmax;
+// backward recomputes the scores from the saved log-sum-exp.  Table gradients are
+// accumulated in LDS and flushed once per workgroup.
+#include "common.h"
+
+namespace u2mkd {
+
+constexpr int kHd = 16;        // head dim (asserted by the reference, sptr/functional.py:355)
+constexpr int kTabRow = 20;    // LDS floats per table row (16 + 4 pad against bank conflicts)
+constexpr int kSptrThreads = 128;
+
+// c10::div_floor_floating (torch.div(rounding_mode='floor') for floats)
+__device__ __forceinline__ float div_floor(float a, float b) {
+    if (b == 0.f) return a / b;
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if ((mod != 0.f) && ((b < 0.f) != (mod < 0.f))) div -= 1.f;
+    float fl;
+    if (div != 0.f) {
+        fl = floorf(div);
+        if (div - fl > 0.5f) fl += 1.f;
+    } else {
+        fl = copysignf(0.f, a / b);
+    }
+    return fl;
+}
+
+// torch_cluster grid_cluster over (x, y, z, batch): key = sum_d trunc((p_d - start_d)/size_d) * stride_d
+__global__ void window_keys_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ batch, int64_t n,
+                                   const float *__restrict__ lo, const float *__restrict__ hi,
+                                   const int32_t *__restrict__ bmax, float sx, float sy, float sz,
+                                   int64_t *__restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float size[3] = {sx, sy, sz};
+    int64_t c = 0, k = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        c += (int64_t)((xyz[i * 3 + d] - lo[d]) / size[d]) * k;
+        k *= (int64_t)((hi[d] - lo[d]) / size[d]) + 1;
+    }
+    // batch dimension: size 1, start = min(batch) (lo[3]) , end = max(batch)
+    float bl = lo[3];
+    c += (int64_t)(((float)batch[i] - bl) / 1.f) * k;
+    (void)bmax;
+    keys[i] = c;
+}
+
+// sorted keys -> (first sorted position, length) of the window of every sorted position
+__global__ void window_ranges_kernel(const int64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ wstart,
+                                     int32_t *__restrict__ wlen) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int64_t key = keys[p];
+    if (p > 0 && keys[p - 1] == key) return;       // not a window head
+    int64_t e = p + 1;
+    while (e < n && keys[e] == key) ++e;
+    for (int64_t t = p; t < e; ++t) {
+        wstart[t] = (int32_t)p;
+        wlen[t] = (int32_t)(e - p);
+    }
+}
+
+// floor(((xyz - min) % window) / quant) per sorted position (sptr/modules.py:40-43)
+__global__ void quant_coords_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ sort_idx, int64_t n,
+                                    const float *__restrict__ lo, float wx, float wy, float wz, float qx, float qy,
+                                    float qz, int32_t *__restrict__ qc, float *__restrict__ radial) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int64_t t = sort_idx[p];
+    const float w[3] = {wx, wy, wz}, qs[3] = {qx, qy, qz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float v = xyz[t * 3 + d] - lo[d] + 0.0f;
+        float m = fmodf(v, w[d]);
+        if ((m != 0.f) && ((w[d] < 0.f) != (m < 0.f))) m += w[d];
+        qc[p * 3 + d] = (int32_t)div_floor(m, qs[d]);
+    }
+    if (radial) radial[p] = xyz[t * 3 + 2];
+}
+
+// spherical_transformer.py:39-64 exponential_split on d = r_query - r_key
+__device__ __forceinline__ int exp_split(float d, float a) {
+    float da = fabsf(d);
+    float flag = d >= 0.f ? 1.f : 0.f;
+    float idx = 2.f * floorf(logf((da + 2.f * a) / a) / 0.6931471805599453f) - 2.f;
+    float half = floorf(idx / 2.f);
+    idx = idx + (((3.f * exp2f(half) - 2.f) * a <= da) ? 1.f : 0.f);
+    idx = idx * (2.f * flag - 1.f) + (flag - 1.f);
+    return (int)idx + 24;
+}
+
+struct RelCtx {
+    int qgl;        // quant_grid_length
+    float a;        // > 0: spherical branch (exponential radial split + clamp)
+};
+
+__device__ __forceinline__ void rel_rows(const RelCtx &c, const int qi[3], float ri, const int qj[3], float rj,
+                                         int r[3]) {
+    r[0] = qi[0] - qj[0] + c.qgl - 1;
+    r[1] = qi[1] - qj[1] + c.qgl - 1;
+    r[2] = qi[2] - qj[2] + c.qgl - 1;
+    if (c.a > 0.f) {
+        r[2] = exp_split(ri - rj, c.a);
+        const int hi = 2 * c.qgl - 1;
+        r[0] = min(max(r[0], 0), hi);
+        r[1] = min(max(r[1], 0), hi);
+        r[2] = min(max(r[2], 0), hi);
+    }
+}
+
+// s_tab: [3 tables][L][3][kTabRow]
+__device__ __forceinline__ void load_tables(float *s_tab, const float *tq, const float *tk, const float *tv, int L,
+                                            int h, int hh) {
+    const float *src[3] = {tq, tk, tv};
+    const int rows = L * 3;
+    for (int e = threadIdx.x; e < 3 * rows * kHd; e += blockDim.x) {
+        int t = e / (rows * kHd);
+        int rem = e - t * rows * kHd;
+        int row = rem / kHd, d = rem - row * kHd;
+        s_tab[(t * rows + row) * kTabRow + d] = src[t][((size_t)row * h + hh) * kHd + d];
+    }
+}
+
+__device__ __forceinline__ void tab_sum(const float *tab, const int r[3], float out[kHd]) {
+    const float4 *a = reinterpret_cast<const float4 *>(tab + (r[0] * 3 + 0) * kTabRow);
+    const float4 *b = reinterpret_cast<const float4 *>(tab + (r[1] * 3 + 1) * kTabRow);
+    const float4 *c = reinterpret_cast<const float4 *>(tab + (r[2] * 3 + 2) * kTabRow);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float4 x = a[v], y = b[v], z = c[v];
+        out[4 * v + 0] = x.x + y.x + z.x;
+        out[4 * v + 1] = x.y + y.y + z.y;
+        out[4 * v + 2] = x.z + y.z + z.z;
+        out[4 * v + 3] = x.w + y.w + z.w;
+    }
+}
+
+__device__ __forceinline__ void load16(const float *p, float out[kHd]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float4 x = reinterpret_cast<const float4 *>(p)[v];
+        out[4 * v] = x.x; out[4 * v + 1] = x.y; out[4 * v + 2] = x.z; out[4 * v + 3] = x.w;
+    }
+}
+
+// ---- forward: out[t,h,:] = softmax_j(s) . (v_j + Tv(rel)),  lse saved per (sorted pos, head)
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                     const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
+                     const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
+                     const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
+                     const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ out,
+                     float *__restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    const int hh = blockIdx.y;
+    load_tables(s_tab, tq, tk, tv, L, h, hh);
+    __syncthreads();
+    const float *Tq = s_tab, *Tk = s_tab + L * 3 * kTabRow, *Tv = s_tab + 2 * L * 3 * kTabRow;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t t = sort_idx[p];
+    const size_t hc = (size_t)h * kHd;
+    float qi[kHd];
+    load16(q + t * hc + hh * kHd, qi);
+    int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
+    float ri = radial ? radial[p] : 0.f;
+    const int ws = wstart[p], wl = wlen[p];
+    float m = -INFINITY, l = 0.f, acc[kHd];
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) acc[d] = 0.f;
+    for (int jj = 0; jj < wl; ++jj) {
+        const int pj = ws + jj;
+        const int64_t tj = sort_idx[pj];
+        int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
+        float rj = radial ? radial[pj] : 0.f;
+        int r[3];
+        rel_rows(rc, qci, ri, qcj, rj, r);
+        float kj[kHd], ts[kHd];
+        load16(k + tj * hc + hh * kHd, kj);
+        tab_sum(Tq, r, ts);
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) s += qi[d] * (kj[d] + ts[d]);
+        tab_sum(Tk, r, ts);
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) s += kj[d] * ts[d];
+        float mn = fmaxf(m, s);
+        float corr = __expf(m - mn), pe = __expf(s - mn);
+        l = l * corr + pe;
+        float vj[kHd];
+        load16(v + tj * hc + hh * kHd, vj);
+        tab_sum(Tv, r, ts);
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) acc[d] = acc[d] * corr + pe * (vj[d] + ts[d]);
+        m = mn;
+    }
+    float inv = 1.f / l;
+    float *o = out + t * hc + hh * kHd;
+#pragma unroll
+    for (int v4 = 0; v4 < 4; ++v4)
+        reinterpret_cast<float4 *>(o)[v4] =
+            make_float4(acc[4 * v4] * inv, acc[4 * v4 + 1] * inv, acc[4 * v4 + 2] * inv, acc[4 * v4 + 3] * inv);
+    lse[p * h + hh] = m + __logf(l);
+}
+
+// delta[p,h] = sum_d dout[t,h,d] * out[t,h,d]
+__global__ void sptr_delta_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                  const int32_t *__restrict__ sort_idx, int64_t n, int h, float *__restrict__ delta) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * h) return;
+    int64_t p = e / h;
+    int hh = (int)(e - p * h);
+    int64_t t = sort_idx[p];
+    const float *a = dout + (t * h + hh) * kHd, *b = out + (t * h + hh) * kHd;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) s += a[d] * b[d];
+    delta[e] = s;
+}
+
+__device__ __forceinline__ void lds_add_rows(float *tab, const int r[3], float scale, const float vec[kHd]) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        float *row = tab + (r[ax] * 3 + ax) * kTabRow;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) atomicAdd(row + d, scale * vec[d]);
+    }
+}
+
+// ---- backward: every (sorted position, head) thread acts as query (dq, table grads) and as key (dk, dv)
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                     const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
+                     const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
+                     const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
+                     const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
+                     const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
+                     float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ dtq, float *__restrict__ dtk,
+                     float *__restrict__ dtv) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    const int hh = blockIdx.y;
+    const int tabf = L * 3 * kTabRow;
+    float *g_tab = s_tab + 3 * tabf;                 // gradient accumulators, same layout
+    load_tables(s_tab, tq, tk, tv, L, h, hh);
+    for (int e = threadIdx.x; e < 3 * tabf; e += blockDim.x) g_tab[e] = 0.f;
+    __syncthreads();
+    const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
+    float *Gq = g_tab, *Gk = g_tab + tabf, *Gv = g_tab + 2 * tabf;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hc = (size_t)h * kHd;
+    if (p < n) {
+        const int64_t t = sort_idx[p];
+        int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
+        float ri = radial ? radial[p] : 0.f;
+        const int ws = wstart[p], wl = wlen[p];
+        float qi[kHd], ki[kHd], vi[kHd], doi[kHd];
+        load16(q + t * hc + hh * kHd, qi);
+        load16(k + t * hc + hh * kHd, ki);
+        load16(v + t * hc + hh * kHd, vi);
+        load16(dout + t * hc + hh * kHd, doi);
+        const float lse_i = lse[p * h + hh], del_i = delta[p * h + hh];
+        float dqi[kHd], dki[kHd], dvi[kHd];
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) { dqi[d] = 0.f; dki[d] = 0.f; dvi[d] = 0.f; }
+        for (int jj = 0; jj < wl; ++jj) {
+            const int pj = ws + jj;
+            const int64_t tj = sort_idx[pj];
+            int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
+            float rj = radial ? radial[pj] : 0.f;
+            float xj[kHd], ts[kHd], tks[kHd];
+            int r[3];
+            // ---- this thread as QUERY i = p against key j = pj
+            rel_rows(rc, qci, ri, qcj, rj, r);
+            load16(k + tj * hc + hh * kHd, xj);                  // k_j
+            tab_sum(Tq, r, ts);
+            tab_sum(Tk, r, tks);
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) s += qi[d] * (xj[d] + ts[d]) + xj[d] * tks[d];
+            float pr = __expf(s - lse_i);
+            float vj[kHd], tvs[kHd];
+            load16(v + tj * hc + hh * kHd, vj);
+            tab_sum(Tv, r, tvs);
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dp += doi[d] * (vj[d] + tvs[d]);
+            float ds = pr * (dp - del_i);
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dqi[d] += ds * (xj[d] + ts[d]);
+            lds_add_rows(Gq, r, ds, qi);
+            lds_add_rows(Gk, r, ds, xj);
+            lds_add_rows(Gv, r, pr, doi);
+            // ---- this thread as KEY j = p against query i = pj
+            rel_rows(rc, qcj, rj, qci, ri, r);
+            float qj[kHd], doj[kHd];
+            load16(q + tj * hc + hh * kHd, qj);
+            load16(dout + tj * hc + hh * kHd, doj);
+            tab_sum(Tq, r, ts);
+            tab_sum(Tk, r, tks);
+            float s2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) s2 += qj[d] * (ki[d] + ts[d]) + ki[d] * tks[d];
+            float pr2 = __expf(s2 - lse[pj * h + hh]);
+            tab_sum(Tv, r, tvs);
+            float dp2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dp2 += doj[d] * (vi[d] + tvs[d]);
+            float ds2 = pr2 * (dp2 - delta[pj * h + hh]);
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) {
+                dki[d] += ds2 * (qj[d] + tks[d]);
+                dvi[d] += pr2 * doj[d];
+            }
+        }
+        float *o1 = dq + t * hc + hh * kHd, *o2 = dk + t * hc + hh * kHd, *o3 = dv + t * hc + hh * kHd;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) { o1[d] = dqi[d]; o2[d] = dki[d]; o3[d] = dvi[d]; }
+    }
+    __syncthreads();
+    // flush table gradients: [L,3,h,16] global layout
+    float *dst[3] = {dtq, dtk, dtv};
+    const int rows = L * 3;
+    for (int e = threadIdx.x; e < 3 * rows * kHd; e += blockDim.x) {
+        int tb = e / (rows * kHd);
+        int rem = e - tb * rows * kHd;
+        int row = rem / kHd, d = rem - row * kHd;
+        float g = g_tab[(tb * rows + row) * kTabRow + d];
+        if (g != 0.f) atomicAdd(dst[tb] + ((size_t)row * h + hh) * kHd + d, g);
+    }
+}
+
+}  // namespace u2mkd
+
+using namespace u2mkd;
+
+extern "C" {
+
+int u2mkd_sptr_window_keys(const float *xyz, const int32_t *batch, int64_t n, const float *lo4, const float *hi4,
+                           float sx, float sy, float sz, int64_t *keys, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(xyz && batch && lo4 && hi4 && keys, "u2mkd_sptr_window_keys: null pointer");
+    U2_REQUIRE(sx > 0 && sy > 0 && sz > 0, "u2mkd_sptr_window_keys: window sizes must be positive");
+    hipLaunchKernelGGL(window_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), xyz, batch, n,
+                       lo4, hi4, (const int32_t *)nullptr, sx, sy, sz, keys);
+    return check_launch("u2mkd_sptr_window_keys");
+}
+
+int u2mkd_sptr_window_ranges(const int64_t *sorted_keys, int64_t n, int32_t *wstart, int32_t *wlen,
+                             u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(sorted_keys && wstart && wlen, "u2mkd_sptr_window_ranges: null pointer");
+    hipLaunchKernelGGL(window_ranges_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), sorted_keys,
+                       n, wstart, wlen);
+    return check_launch("u2mkd_sptr_window_ranges");
+}
+
+int u2mkd_sptr_quant_coords(const float *xyz, const int32_t *sort_idx, int64_t n, const float *lo, float wx, float wy,
+                            float wz, float qx, float qy, float qz, int32_t *qc, float *radial, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(xyz && sort_idx && lo && qc, "u2mkd_sptr_quant_coords: null pointer");
+    hipLaunchKernelGGL(quant_coords_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), xyz,
+                       sort_idx, n, lo, wx, wy, wz, qx, qy, qz, qc, radial);
+    return check_launch("u2mkd_sptr_quant_coords");
+}
+
+static int sptr_check(const char *who, int64_t n, int h, int hdim, int L, int qgl, float a) {
+    U2_REQUIRE(hdim == kHd, "%s: head dim %d != 16 (the reference asserts hdim == 16)", who, hdim);
+    U2_REQUIRE(h > 0 && h <= 65535, "%s: bad head count %d", who, h);
+    U2_REQUIRE(L > 0 && L <= 50, "%s: table length %d not in 1..50 (the reference asserts L <= 50)", who, L);
+    U2_REQUIRE(a > 0.f ? L >= 2 * qgl : L >= 2 * qgl - 1, "%s: table length %d too short for grid length %d", who, L,
+               qgl);
+    (void)n;
+    return 0;
+}
+
+int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v, const int32_t *sort_idx,
+                                 const int32_t *wstart, const int32_t *wlen, const int32_t *qc, const float *radial,
+                                 const float *tq, const float *tk, const float *tv, int32_t L, int32_t qgl,
+                                 float split_a, int64_t n, int32_t h, int32_t hdim, float *out, float *lse,
+                                 u2mkd_stream_t s) {
+    if (n == 0 || h == 0) return 0;
+    U2_REQUIRE(q && k && v && sort_idx && wstart && wlen && qc && tq && tk && tv && out && lse,
+               "u2mkd_sptr_attention_forward: null pointer");
+    if (int rc = sptr_check("u2mkd_sptr_attention_forward", n, h, hdim, L, qgl, split_a)) return rc;
+    U2_REQUIRE(split_a <= 0.f || radial, "u2mkd_sptr_attention_forward: spherical branch needs the radial coordinate");
+    RelCtx rc{qgl, split_a};
+    size_t lds = (size_t)3 * L * 3 * kTabRow * sizeof(float);
+    hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
+                       as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk, tv,
+                       L, rc, n, h, out, lse);
+    return check_launch("u2mkd_sptr_attention_forward");
+}
+
+int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                  const float *lse, const int32_t *sort_idx, const int32_t *wstart,
+                                  const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
+                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n,
+                                  int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/, float *dq, float *dk,
+                                  float *dv, float *dtq /*pre-zeroed*/, float *dtk /*pre-zeroed*/,
+                                  float *dtv /*pre-zeroed*/, u2mkd_stream_t s) {
+    if (n == 0 || h == 0) return 0;
+    U2_REQUIRE(q && k && v && out && dout && lse && sort_idx && wstart && wlen && qc && tq && tk && tv && delta && dq &&
+                   dk && dv && dtq && dtk && dtv,
+               "u2mkd_sptr_attention_backward: null pointer");
+    if (int rc = sptr_check("u2mkd_sptr_attention_backward", n, h, hdim, L, qgl, split_a)) return rc;
+    RelCtx rc{qgl, split_a};
+    hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(sptr_delta_kernel, dim3((unsigned)ceil_div(n * h, 256)), dim3(256), 0, st, dout, out, sort_idx,
+                       n, h, delta);
+    size_t lds = (size_t)6 * L * 3 * kTabRow * sizeof(float);
+    if (lds > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_attn_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sptr_attn_bwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds, st,
+                       q, k, v, dout, lse, delta, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk,
+                       tv, L, rc, n, h, dq, dk, dv, dtq, dtk, dtv);
+    return check_launch("u2mkd_sptr_attention_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""Window attention with contextual relative position tables on the HIP kernels of
+csrc/sptr.hip (rows a10-a11 of SURVEY.md §8a)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import _lib as L
+
+__all__ = ['WindowPlan', 'get_indices_params', 'sparse_self_attention', 'window_attention']
+
+
+class _Inert:
+    """Placeholder for an M-sized index tensor of the reference API; only ever passed back."""
+
+    def int(self):
+        return self
+
+    def long(self):
+        return self
+
+
+class WindowPlan:
+    """Tokens sorted by window: ``sort_idx`` (token id at sorted position), and per sorted
+    position the first position / length of its window.  Built with no host sync."""
+
+    def __init__(self, xyz: torch.Tensor, batch: torch.Tensor, window_size):
+        L.require_cuda(xyz, batch)
+        xyz = xyz.contiguous().float()
+        n = xyz.shape[0]
+        dev = xyz.device
+        w = [float(v) for v in np.asarray(window_size, dtype=np.float64).reshape(-1)]
+        b32 = batch.int().contiguous()
+        p4 = torch.cat([xyz, b32.view(-1, 1).float()], 1)
+        lo4 = p4.amin(0).contiguous()
+        hi4 = p4.amax(0).contiguous()
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        L.call('u2mkd_sptr_window_keys', L.ptr(xyz), L.ptr(b32), n, L.ptr(lo4), L.ptr(hi4), w[0], w[1], w[2],
+               L.ptr(keys), L.stream())
+        skeys, sort_idx = torch.sort(keys, stable=True)
+        self.sort_idx = sort_idx.int().contiguous()
+        self.wstart = torch.empty(n, dtype=torch.int32, device=dev)
+        self.wlen = torch.empty(n, dtype=torch.int32, device=dev)
+        L.call('u2mkd_sptr_window_ranges', L.ptr(skeys), n, L.ptr(self.wstart), L.ptr(self.wlen), L.stream())
+        self.n = n
+        self.window_size = w
+        self.lo = lo4
+        self._qc = {}
+
+    def int(self):
+        return self
+
+    def long(self):
+        return self
+
+    def quant_coords(self, xyz: torch.Tensor, quant_size, want_radial: bool):
+        """(int32 [n,3] quantised in-window coordinates, radial f32 [n] or None), sorted order."""
+        q = tuple(float(v) for v in np.asarray(quant_size, dtype=np.float64).reshape(-1))
+        key = (q, want_radial)
+        hit = self._qc.get(key)
+        if hit is None:
+            xyz = xyz.contiguous().float()
+            qc = torch.empty(self.n, 3, dtype=torch.int32, device=xyz.device)
+            radial = torch.empty(self.n, dtype=torch.float32, device=xyz.device) if want_radial else None
+            w = self.window_size
+            L.call('u2mkd_sptr_quant_coords', L.ptr(xyz), L.ptr(self.sort_idx), self.n, L.ptr(self.lo), w[0], w[1],
+                   w[2], q[0], q[1], q[2], L.ptr(qc), L.ptr(radial), L.stream())
+            hit = (qc, radial)
+            self._qc[key] = hit
+        return hit
+
+    @property
+    def n_max(self) -> int:      # only for API compatibility (host sync); the kernels do not need it
+        return int(self.wlen.max().item()) if self.n else 0
+
+
+class WindowAttentionFunction(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, tq, tk, tv, plan, qc, radial, qgl, split_a):
+        L.require_cuda(q, k, v, tq, tk, tv)
+        q, k, v = (t.contiguous().float() for t in (q, k, v))
+        tq, tk, tv = (t.contiguous().float() for t in (tq, tk, tv))
+        n, h, d = q.shape
+        tl = tq.shape[0]
+        if h == 0 or n == 0:
+            ctx.empty = True
+            ctx.shapes = (q.shape, tq.shape)
+            return torch.zeros_like(q)
+        ctx.empty = False
+        if tq.shape != (tl, 3, h, d) or tk.shape != tq.shape or tv.shape != tq.shape:
+            raise RuntimeError(f'relative position tables must be [L,3,{h},{d}], got {tuple(tq.shape)}')
+        out = torch.empty_like(q)
+        lse = torch.empty(n, h, dtype=torch.float32, device=q.device)
+        L.call('u2mkd_sptr_attention_forward', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(plan.sort_idx), L.ptr(plan.wstart),
+               L.ptr(plan.wlen), L.ptr(qc), L.ptr(radial), L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, int(qgl),
+               float(split_a), n, h, d, L.ptr(out), L.ptr(lse), L.stream())
+        ctx.save_for_backward(q, k, v, out, lse, tq, tk, tv, qc, radial if radial is not None else q.new_empty(0))
+        ctx.plan, ctx.qgl, ctx.split_a, ctx.has_radial = plan, int(qgl), float(split_a), radial is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.empty:
+            qs, ts = ctx.shapes
+            z = dout.new_zeros(qs)
+            t = dout.new_zeros(ts)
+            return z, z, z, t, t, t, None, None, None, None, None
+        q, k, v, out, lse, tq, tk, tv, qc, radial = ctx.saved_tensors
+        plan = ctx.plan
+        dout = dout.contiguous().float()
+        n, h, d = q.shape
+        tl = tq.shape[0]
+        delta = torch.empty(n, h, dtype=torch.float32, device=q.device)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dtq, dtk, dtv = torch.zeros_like(tq), torch.zeros_like(tk), torch.zeros_like(tv)
+        L.call('u2mkd_sptr_attention_backward', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse),
+               L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(qc),
+               L.ptr(radial) if ctx.has_radial else None, L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, ctx.qgl, ctx.split_a,
+               n, h, d, L.ptr(delta), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dtq), L.ptr(dtk), L.ptr(dtv), L.stream())
+        return dq, dk, dv, dtq, dtk, dtv, None, None, None, None, None
+
+
+def window_attention(q, k, v, xyz, plan: WindowPlan, quant_size, quant_grid_length, table_q, table_k, table_v,
+                     split_a=None):
+    """softmax over each token's window of (q.k + q.Tq(rel) + k.Tk(rel)) applied to (v + Tv(rel));
+    q,k,v [N,h,16] (q pre-scaled), tables [L,3,h,16]; ``split_a`` selects the spherical branch."""
+    sphere = split_a is not None
+    qc, radial = plan.quant_coords(xyz, quant_size, sphere)
+    return WindowAttentionFunction.apply(q, k, v, table_q, table_k, table_v, plan, qc, radial,
+                                         int(quant_grid_length), float(split_a) if sphere else 0.0)
+
+
+def get_indices_params(xyz, batch, window_size, shift_win: bool):
+    """sptr/utils.py:49-78 signature.  Returns (plan, inert, n_max, inert, inert, sort_idx)."""
+    if shift_win:
+        raise NotImplementedError('shift_win=True is never used by U2MKD (spherical_transformer.py:79)')
+    plan = WindowPlan(xyz, batch, window_size)
+    return plan, _Inert(), None, _Inert(), _Inert(), plan.sort_idx
+
+
+def sparse_self_attention(query, key, value, xyz, index_0, index_0_offsets, n_max, index_1, index_1_offsets, sort_idx,
+                          window_size, shift_win, pe_type='none', rel_query=False, rel_key=False, rel_value=False,
+                          quant_size=None, quant_grid_length=None, relative_pos_query_table=None,
+                          relative_pos_key_table=None, relative_pos_value_table=None, split_func=None):
+    """sptr/modules.py:11-66 signature; ``index_0`` must be the WindowPlan of get_indices_params."""
+    if not (pe_type == 'contextual' and rel_query and rel_key and rel_value):
+        raise NotImplementedError('only pe_type="contextual" with rel_query=rel_key=rel_value=True is on the '
+                                  'U2MKD path (core/models/nuscenes/spvcnn_spformer.py:70-72)')
+    if not isinstance(index_0, WindowPlan):
+        raise TypeError('index_0 must come from u2mkd_amd.sptr.get_indices_params')
+    split_a = None
+    if split_func is not None:
+        split_a = getattr(split_func, 'keywords', {}).get('a', 0.05 * 0.25)
+    return window_attention(query, key, value, xyz, index_0, quant_size, quant_grid_length, relative_pos_query_table,
+                            relative_pos_key_table, relative_pos_value_table, split_a)
