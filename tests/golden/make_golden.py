@@ -46,6 +46,33 @@ def import_reference():
     return SPVCNN, MixLovaszCrossEntropy
 
 
+def import_reference_spformer(cr):
+    """The reference's SphereFormer / SPVCNN_SPFORMER modules with their un-installable imports
+    stubbed: timm (DropPath, trunc_normal_), torch_scatter, torchpack configs, and
+    third_party.SparseTransformer.sptr -> oracle.sptr_cpu (CPU restatement of the CUDA ops)."""
+    from oracle import sptr_cpu
+    from oracle.spformer_ref import DropPath
+    timm = types.ModuleType('timm')
+    timm_models = types.ModuleType('timm.models')
+    timm_layers = types.ModuleType('timm.models.layers')
+    timm_layers.DropPath = DropPath
+    timm_layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules.update({'timm': timm, 'timm.models': timm_models, 'timm.models.layers': timm_layers})
+    tscatter = types.ModuleType('torch_scatter')
+    tscatter.scatter_mean = None
+    sys.modules['torch_scatter'] = tscatter
+    for name in ('third_party', 'third_party.SparseTransformer'):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['third_party.SparseTransformer.sptr'] = sptr_cpu
+    tp = types.ModuleType('torchpack')
+    tpu = types.ModuleType('torchpack.utils')
+    tpc = types.ModuleType('torchpack.utils.config')
+    tpc.configs = {'model': {'cr': cr, 'in_channel': 4}, 'data': {'num_classes': 17}}
+    sys.modules.update({'torchpack': tp, 'torchpack.utils': tpu, 'torchpack.utils.config': tpc})
+    from core.models.nuscenes.spvcnn_spformer import SPVCNN_SPFORMER
+    return SPVCNN_SPFORMER
+
+
 def main():
     SPVCNN, MixLovaszCrossEntropy = import_reference()
     torch.manual_seed(0)
@@ -76,7 +103,31 @@ def main():
     l2.backward()
     np.savez_compressed(os.path.join(HERE, 'lovasz_ce.npz'), x=x.detach().numpy(), y=y.numpy(),
                         loss=np.float32(l2.item()), grad=x.grad.numpy())
-    print('golden written:', float(loss), float(l2))
+    # ---- SPVCNN_SPFORMER (teacher), the reference class with the builder's arguments
+    from oracle.spformer_ref import default_spformer_kwargs
+    cr = 1.0
+    SPF = import_reference_spformer(cr)
+    kw = default_spformer_kwargs(cr=cr, drop_path_rate=0.0)
+    for k in ('cr', 'in_channel', 'num_classes'):
+        kw.pop(k)
+    b = synth_batch(2000, 2, seed=33)
+    feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
+    ref = O.fill_state_by_name(SPF(**kw)).train()
+    ref.dropout.p = 0.0
+    out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
+    loss3 = crit(out, labels)
+    loss3.backward()
+    grads = {n: p.grad for n, p in ref.named_parameters()}
+    blk = 'transformer_blocks.1.attn.'
+    np.savez_compressed(
+        os.path.join(HERE, 'spformer_cr10_4000.npz'),
+        logits=out.detach().numpy().astype(np.float32), loss=np.float32(loss3.item()),
+        grad_tq=grads[blk + 'relative_pos_query_table'].numpy(),
+        grad_tv_sphere=grads[blk + 'relative_pos_value_table_sphere'].numpy(),
+        grad_qkv=grads[blk + 'qkv.weight'].numpy())
+    with open(os.path.join(HERE, 'spformer_cr10_keys.json'), 'w') as f:
+        json.dump({k: list(v.shape) for k, v in ref.state_dict().items()}, f, indent=0)
+    print('golden written:', float(loss), float(l2), float(loss3))
 
 
 if __name__ == '__main__':

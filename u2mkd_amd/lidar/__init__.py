@@ -7,6 +7,9 @@ its checkpoints load unchanged.
 from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point, fetch_idx, SparseSyncBatchNorm
 from .blocks import BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock
 from .spvcnn import SPVCNN
+from .sphereformer import SphereFormer
+from .spvcnn_spformer import SPVCNN_SPFORMER, spformer_kwargs
 
 __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'fetch_idx', 'SparseSyncBatchNorm',
-           'BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock', 'SPVCNN']
+           'BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock', 'SPVCNN', 'SphereFormer',
+           'SPVCNN_SPFORMER', 'spformer_kwargs']

@@ -1,0 +1,130 @@
+"""SphereFormer block (row a10; core/models/sphereformer/spherical_transformer.py:12-348)
+on the fused HIP window attention of ``u2mkd_amd.sptr``.
+
+Half of the heads attend inside cubic xyz windows, the other half inside spherical
+(theta, beta, r) windows with an exponentially split radial index; both use contextual
+relative-position tables for query, key and value.  Parameter names match the reference
+(``norm1``, ``attn.qkv``, ``attn.relative_pos_*_table[_sphere]``, ``attn.proj``, ``norm2``,
+``mlp.fc1/fc2``) so its checkpoints load unchanged.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import sptr
+
+__all__ = ['SphereFormer', 'SparseMultiheadSASphereConcat', 'DropPath', 'cart2sphere']
+
+
+def cart2sphere(xyz):
+    """(theta [0,360) deg, beta [0,180] deg, r) -- spherical_transformer.py:31-36."""
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    theta = (torch.atan2(y, x) + np.pi) * 180 / np.pi
+    beta = torch.atan2(torch.sqrt(x ** 2 + y ** 2), z) * 180 / np.pi
+    r = torch.sqrt(x ** 2 + y ** 2 + z ** 2)
+    return torch.stack([theta, beta, r], -1)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth over dim 0 (timm.models.layers.DropPath, as the reference uses it)."""
+
+    def __init__(self, drop_prob=0.):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class SparseMultiheadSASphereConcat(nn.Module):
+    def __init__(self, embed_dim, num_heads, window_size, window_size_sphere, quant_size, quant_size_sphere, a):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        head_dim = embed_dim // num_heads
+        assert head_dim == 16, 'the sptr kernels are built for head_dim 16 (sptr/functional.py:355)'
+        self.scale = head_dim ** -0.5
+        # to_3d_numpy keeps ndarray identity: quant_size_sphere is shared (and later mutated) by the
+        # caller exactly as in the reference
+        self.window_size = sptr.to_3d_numpy(window_size)
+        self.window_size_sphere = sptr.to_3d_numpy(window_size_sphere)
+        self.quant_size = sptr.to_3d_numpy(quant_size)
+        self.quant_size_sphere = sptr.to_3d_numpy(quant_size_sphere)
+        self.a = a
+        qgl = int((window_size[0] + 1e-4) / quant_size[0])
+        assert qgl == int((window_size[1] + 1e-4) / quant_size[1])
+        h1 = num_heads // 2
+        h2 = num_heads - h1
+        self.num_heads_brc1 = h1
+        self.quant_grid_length = qgl
+
+        def table(rows, heads):
+            return nn.Parameter(nn.init.trunc_normal_(torch.zeros(rows, 3, heads, head_dim), std=.02))
+
+        self.relative_pos_query_table = table(2 * qgl - 1, h1)
+        self.relative_pos_key_table = table(2 * qgl - 1, h1)
+        self.relative_pos_value_table = table(2 * qgl - 1, h1)
+        qgs = int((window_size_sphere[0] + 1e-4) / quant_size_sphere[0])
+        assert qgs == int((window_size_sphere[1] + 1e-4) / quant_size_sphere[1])
+        self.quant_grid_length_sphere = qgs
+        self.relative_pos_query_table_sphere = table(2 * qgs, h2)
+        self.relative_pos_key_table_sphere = table(2 * qgs, h2)
+        self.relative_pos_value_table_sphere = table(2 * qgs, h2)
+        self.qkv = nn.Linear(embed_dim, embed_dim * 3, bias=True)
+        self.proj = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, feats, xyz, batch):
+        N, C = feats.shape
+        qkv = self.qkv(feats).reshape(N, 3, self.num_heads, C // self.num_heads)
+        query = qkv[:, 0] * self.scale
+        key, value = qkv[:, 1], qkv[:, 2]
+        h1 = self.num_heads_brc1
+        xyz = xyz.float()
+        xyz_sphere = cart2sphere(xyz)
+        plan = sptr.WindowPlan(xyz, batch, self.window_size)
+        plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
+        out1 = sptr.window_attention(query[:, :h1], key[:, :h1], value[:, :h1], xyz, plan, self.quant_size,
+                                     self.quant_grid_length, self.relative_pos_query_table,
+                                     self.relative_pos_key_table, self.relative_pos_value_table, None)
+        out2 = sptr.window_attention(query[:, h1:], key[:, h1:], value[:, h1:], xyz_sphere, plan_s,
+                                     self.quant_size_sphere, self.quant_grid_length_sphere,
+                                     self.relative_pos_query_table_sphere, self.relative_pos_key_table_sphere,
+                                     self.relative_pos_value_table_sphere, self.a)
+        x = torch.cat([out1, out2], 1).view(N, C)
+        return self.proj(x)
+
+
+class SphereFormer(nn.Module):
+    def __init__(self, dim, num_heads, window_size, window_size_sphere, quant_size, quant_size_sphere,
+                 indice_key=None, pe_type='contextual', rel_query=True, rel_key=True, rel_value=True, drop_path=0.0,
+                 mlp_ratio=4.0, a=0.05 * 0.25):
+        super().__init__()
+        assert pe_type == 'contextual' and rel_query and rel_key and rel_value
+        self.window_size = window_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = SparseMultiheadSASphereConcat(dim, num_heads, window_size, window_size_sphere, quant_size,
+                                                  quant_size_sphere, a)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, feats, xyz, batch):
+        short_cut = feats
+        feats = self.attn(self.norm1(feats), xyz, batch)
+        feats = short_cut + self.drop_path(feats)
+        return feats + self.drop_path(self.mlp(self.norm2(feats)))
