@@ -57,7 +57,6 @@ def test_two_rank_gradients_are_the_mean(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     g0 = torch.load(os.path.join(tmp_path, 'g0.pt'))
     g1 = torch.load(os.path.join(tmp_path, 'g1.pt'))
-    torch.set_num_threads(2)
     s0 = _scene_grads(100, lambda m: m)
     s1 = _scene_grads(101, lambda m: m)
     for name in g0:

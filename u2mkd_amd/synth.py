@@ -29,6 +29,10 @@ def _lidar_sweep(rng: np.random.Generator, n_az: int, n_beams: int = 32):
     elev = np.deg2rad(np.linspace(-30.0, 10.0, n_beams))
     az = np.linspace(-np.pi, np.pi, n_az, endpoint=False) + rng.uniform(0, 2 * np.pi / n_az)
     el, a = np.meshgrid(elev, az, indexing='ij')
+    # per-ray angular jitter (beam divergence / encoder noise, ~0.03 deg): without it whole beams sit at
+    # exactly representable angles, i.e. exactly ON SphereFormer's 2-degree window boundaries
+    el = el + rng.normal(0.0, 5e-4, el.shape)
+    a = a + rng.normal(0.0, 5e-4, a.shape)
     dx, dy, dz = np.cos(el) * np.cos(a), np.cos(el) * np.sin(a), np.sin(el)
     r = np.full(el.shape, 50.0)
     down = dz < -1e-3
