@@ -63,6 +63,9 @@ def import_reference_spformer(cr):
     sys.modules['torch_scatter'] = tscatter
     for name in ('third_party', 'third_party.SparseTransformer'):
         sys.modules[name] = types.ModuleType(name)
+    # a package path lets fusion_blocks import the reference's pure-python third_party.csrc wrapper
+    # (dead CamLiFlow code with torch fallbacks); the sptr entry below still wins over the real one
+    sys.modules['third_party'].__path__ = [os.path.join(REF, 'third_party')]
     sys.modules['third_party.SparseTransformer.sptr'] = sptr_cpu
     tp = types.ModuleType('torchpack')
     tpu = types.ModuleType('torchpack.utils')
@@ -127,7 +130,79 @@ def main():
         grad_qkv=grads[blk + 'qkv.weight'].numpy())
     with open(os.path.join(HERE, 'spformer_cr10_keys.json'), 'w') as f:
         json.dump({k: list(v.shape) for k, v in ref.state_dict().items()}, f, indent=0)
+    make_kd_golden(crit)
     print('golden written:', float(loss), float(l2), float(loss3))
+
+
+def kd_inputs(b):
+    """numpy KD batch -> (student in_mod, teacher in_mod, extras) as torch CPU tensors, with the
+    reference's layouts (images already permuted to [B, ncam, 3, H, W] like _prepare_input does)."""
+    s, t = b['student'], b['teacher']
+    stu = {'lidar': ots.SparseTensor(torch.from_numpy(s['feats']), torch.from_numpy(s['coords'])),
+           'images': torch.from_numpy(s['images']).permute(0, 1, 4, 2, 3).contiguous(),
+           'pixel_coordinates': [torch.from_numpy(c) for c in s['pixel_coordinates']],
+           'masks': [torch.from_numpy(m) for m in s['masks']], 'fov_mask': torch.from_numpy(s['fov_mask'])}
+    tea = {'lidar': ots.SparseTensor(torch.from_numpy(t['feats']), torch.from_numpy(t['coords']))}
+    return stu, tea
+
+
+def make_kd_golden(crit):
+    """The reference's own SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL (student + teacher) and the KD loss
+    arithmetic of NuScenesLCTSDFullTrainer._run_step, on CPU over the oracle operators."""
+    import torch.nn.functional as F
+    from u2mkd_amd.synth import synth_kd_batch
+    from oracle.spformer_ref import default_spformer_kwargs
+    cfg = sys.modules['torchpack.utils.config'].configs
+    cfg['model'].update({'cr': 1.0, 'cr_t': 1.0, 'in_channel': 4, 'in_channel_t': 4, 'imagenet_pretrain': None})
+    cfg['eval'] = {'run_pix_decoder': True, 'run_align_loss': True}
+    cfg['debug'] = {'debug_val': False}
+    torch.Tensor.cuda = lambda self, *a, **k: self          # Feature_Fetch hard-codes .cuda() (fusion_blocks.py:271-273)
+    from core.models.nuscenes.spvcnn_swiftnet18_spformer_tsd_full import SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL
+    kw = default_spformer_kwargs(drop_path_rate=0.0)
+    for k in ('cr', 'in_channel', 'num_classes'):
+        kw.pop(k)
+    model = O.fill_state_by_name(SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL(**kw)).train()
+    model.model_t.eval()
+    model.model_s.dropout.p = 0.0
+    b = synth_kd_batch(1500, 2, seed=77, image_hw=(64, 112))
+    stu, tea = kd_inputs(b)
+    out = model({'student': stu, 'teacher': tea})
+    s, t = b['student'], b['teacher']
+    targets = torch.from_numpy(s['targets'])
+    fov = torch.from_numpy(s['fov_mask'])
+    inv_map = torch.from_numpy(t['inverse_map'])
+    # core/nusc_trainers.py:288-345, verbatim arithmetic
+    x_vox_t2s, feat_t2s = [], []
+    cur_v = cur_p = 0
+    for n_p, n_v, inds in zip(t['num_pts'], t['num_vox'], s['inds']):
+        inv = inv_map[cur_p:cur_p + n_p]
+        x_vox_t2s.append(out['t']['x_vox'][cur_v:cur_v + n_v][inv, :][torch.from_numpy(inds[0]), :])
+        feat_t2s.append(out['t']['pts_feats'][0][cur_v:cur_v + n_v][inv, :][torch.from_numpy(inds[0]), :])
+        cur_v += n_v
+        cur_p += n_p
+    x_vox_t2s, feat_t2s = torch.cat(x_vox_t2s), torch.cat(feat_t2s)
+    x_vox, x_pix = out['stu']['x_vox'], out['stu']['x_pix']
+    ce_vox = crit(x_vox, targets)
+    ce_pix = crit(x_pix[fov], targets[fov])
+    kl = torch.nn.KLDivLoss(reduction='batchmean')(F.log_softmax(x_vox, dim=1), F.softmax(x_vox_t2s.detach(), dim=1))
+    feat = torch.nn.MSELoss()(out['stu']['pts_feats'][0], feat_t2s.detach())
+    total = ce_vox + ce_pix + 1.0 * kl + sum(out['stu']['mse_loss']) + 1.0 * feat
+    total.backward()
+    g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    np.savez_compressed(
+        os.path.join(HERE, 'kd_cr10_3000.npz'),
+        x_vox=x_vox.detach().numpy(), x_pix=x_pix.detach().numpy(), x_vox_t=out['t']['x_vox'].numpy(),
+        mse=np.array([float(m) for m in out['stu']['mse_loss']], dtype=np.float32),
+        pts_feats_s=out['stu']['pts_feats'][0].detach().numpy()[::16],
+        feat_t2s=feat_t2s.numpy()[::16],
+        losses=np.array([float(ce_vox), float(ce_pix), float(kl), float(feat), float(total)], dtype=np.float32),
+        grad_l2c=g['model_s.l2c_fusion_blocks.1.conv1.weight'].numpy(),
+        grad_c2l=g['model_s.c2l_fusion_blocks.2.conv1.weight'].numpy(),
+        grad_layer2=g['model_s.pix_branch.layer2.0.conv1.weight'].numpy()[:8],
+        grad_stem=g['model_s.stem.3.kernel'].numpy())
+    with open(os.path.join(HERE, 'kd_cr10_keys.json'), 'w') as f:
+        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0)
+    print('kd golden losses', [float(x) for x in (ce_vox, ce_pix, kl, feat, total)])
 
 
 if __name__ == '__main__':

@@ -1,0 +1,126 @@
+"""KD path (rows a13-a18).  CPU: the batched point<->pixel transfers and the one-gather
+teacher->student re-index equal the reference's loops (oracle.fusion_ref); SwiftNet / fusion /
+student state-dict keys equal the reference's.  GPU: the whole student + teacher + KD losses on
+the HIP operators vs golden vectors made by the reference's own model class."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fusion_ref as FR
+from u2mkd_amd import fusion as PF
+from u2mkd_amd.synth import synth_kd_batch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _kd_tensors(b, dev='cpu'):
+    s = b['student']
+    pc = [torch.from_numpy(c).to(dev) for c in s['pixel_coordinates']]
+    ms = [torch.from_numpy(m).to(dev) for m in s['masks']]
+    return pc, ms
+
+
+@pytest.mark.parametrize('idx', [0, 2, 3])
+def test_l2c_scatter_equals_reference_loop(idx):
+    b = synth_kd_batch(700, 2, seed=3, image_hw=(64, 112))
+    pc, ms = _kd_tensors(b)
+    ms[1][2] = False                       # a camera that sees nothing -> zero map
+    torch.manual_seed(idx)
+    feats = torch.randn(sum(m.shape[1] for m in ms), 24, dtype=torch.float64)
+    ifh, ifw = (32, 56) if idx == 0 else (8, 14)
+    want = FR.l2c_loop(feats, [c.double() for c in pc], ms, ifh, ifw, 4, idx)
+    got = PF.l2c_scatter(feats, [c.double() for c in pc], ms, ifh, ifw, 4 - idx)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 1e-12
+
+
+def test_c2l_gather_equals_reference_loop():
+    b = synth_kd_batch(700, 2, seed=4, image_hw=(64, 112))
+    pc, ms = _kd_tensors(b)
+    fmaps = torch.randn(2, 6, 10, 16, 28, dtype=torch.float64)
+    want = FR.c2l_loop(fmaps, [c.double() for c in pc], ms)
+    got = PF.c2l_gather(fmaps, [c.double() for c in pc], ms)
+    assert float((got - want).abs().max()) < 1e-12
+    fov = torch.from_numpy(b['student']['fov_mask'])
+    assert float(got[~fov].abs().max()) == 0.0
+
+
+def test_teacher_to_student_equals_reference_loop():
+    from u2mkd_amd.kd import teacher_to_student
+    b = synth_kd_batch(900, 3, seed=5, image_hw=(32, 56))
+    s, t = b['student'], b['teacher']
+    x_t = torch.randn(sum(t['num_vox']), 7)
+    inv = torch.from_numpy(t['inverse_map'])
+    inds = [[torch.from_numpy(i[0])] for i in s['inds']]
+    want = FR.t2s_loop(x_t, inv, inds, t['num_pts'], t['num_vox'])
+    got = teacher_to_student(x_t, inv, inds, t['num_pts'], t['num_vox'])
+    assert torch.equal(got, want)
+    kfm = torch.rand(len(inv)) < 0.9
+    # with a key-frame mask the student indices address the masked points
+    inds2 = []
+    cur = 0
+    for n_p in t['num_pts']:
+        k = int(kfm[cur:cur + n_p].sum())
+        inds2.append([torch.randint(0, k, (50,))])
+        cur += n_p
+    assert torch.equal(teacher_to_student(x_t, inv, inds2, t['num_pts'], t['num_vox'], kfm),
+                       FR.t2s_loop(x_t, inv, inds2, t['num_pts'], t['num_vox'], kfm))
+
+
+def _build(dev):
+    from u2mkd_amd import kd, lidar
+    sp = {k: v for k, v in lidar.spformer_kwargs(drop_path_rate=0.0).items() if k not in ('cr', 'in_channel', 'num_classes')}
+    return kd.TSDFull(cr=1.0, cr_t=1.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp)
+
+
+def test_kd_state_dict_keys_match_reference():
+    with open(os.path.join(G, 'kd_cr10_keys.json')) as f:
+        keys = json.load(f)
+    sd = _build('cpu').state_dict()
+    assert list(sd.keys()) == list(keys.keys())
+    assert {k: list(v.shape) for k, v in sd.items()} == keys
+
+
+@pytest.mark.gpu
+def test_hip_kd_step_matches_reference_golden(hip):
+    from oracle.spvcnn_ref import fill_state_by_name
+    from u2mkd_amd import kd, torchsparse as ts
+    gold = np.load(os.path.join(G, 'kd_cr10_3000.npz'))
+    model = fill_state_by_name(_build('cuda')).cuda().train()
+    model.model_t.eval()
+    model.model_s.dropout.p = 0.0
+    b = synth_kd_batch(1500, 2, seed=77, image_hw=(64, 112))
+    s, t = b['student'], b['teacher']
+    pc, ms = _kd_tensors(b, 'cuda')
+    stu = {'lidar': ts.SparseTensor(torch.from_numpy(s['feats']).cuda(), torch.from_numpy(s['coords']).cuda()),
+           'images': torch.from_numpy(s['images']).permute(0, 1, 4, 2, 3).contiguous().cuda(),
+           'pixel_coordinates': pc, 'masks': ms, 'fov_mask': torch.from_numpy(s['fov_mask']).cuda()}
+    tea = {'lidar': ts.SparseTensor(torch.from_numpy(t['feats']).cuda(), torch.from_numpy(t['coords']).cuda())}
+    out = model({'student': stu, 'teacher': tea})
+    crit = kd.KDCriterion(ignore_index=0, w_kl=1.0, w_feat=1.0)
+    inds = [[torch.from_numpy(i[0]).cuda()] for i in s['inds']]
+    ld = kd.kd_losses(out, torch.from_numpy(s['targets']).cuda(), stu['fov_mask'],
+                      torch.from_numpy(t['inverse_map']).cuda(), inds, t['num_pts'], t['num_vox'], crit)
+    ld['total'].backward()
+
+    def err(a, key):
+        return float((a.detach().cpu() - torch.from_numpy(gold[key])).abs().max())
+    assert err(out['t']['x_vox'], 'x_vox_t') < 1e-3
+    assert err(out['stu']['x_vox'], 'x_vox') < 1e-3
+    assert err(out['stu']['x_pix'], 'x_pix') < 1e-3
+    assert err(out['stu']['pts_feats'][0][::16], 'pts_feats_s') < 1e-3
+    mse = torch.stack([m.detach() for m in out['stu']['mse_loss']]).cpu().numpy()
+    assert np.abs(mse - gold['mse']).max() < 1e-3
+    got = np.array([float(ld[k].detach()) for k in ('ce_vox', 'ce_pix', 'kl', 'feat', 'total')])
+    assert np.abs(got - gold['losses']).max() < 2e-3, (got, gold['losses'])
+    g = dict(model.named_parameters())
+    for name, key, sl in (('model_s.l2c_fusion_blocks.1.conv1.weight', 'grad_l2c', slice(None)),
+                          ('model_s.c2l_fusion_blocks.2.conv1.weight', 'grad_c2l', slice(None)),
+                          ('model_s.pix_branch.layer2.0.conv1.weight', 'grad_layer2', slice(0, 8)),
+                          ('model_s.stem.3.kernel', 'grad_stem', slice(None))):
+        a, bb = g[name].grad.cpu().double()[sl], torch.from_numpy(gold[key]).double()
+        assert float((a - bb).norm() / bb.norm()) < 3e-2, name
+    assert all(p.grad is None for p in model.model_t.parameters())

@@ -1,0 +1,249 @@
+"""Uni-to-multi-modal knowledge distillation: the multi-modal student, the teacher/student
+wrapper and the KD training losses (rows a12-a18 of SURVEY.md §8a).
+
+Reference: core/models/nuscenes/spvcnn_swiftnet18_spformer_tsd_full.py:197-596 (student
+``SPVCNN_SWIFTNET18_SPFORMER_MSP2IFM``, wrapper ``..._TSD_FULL``) and the train branch of
+``NuScenesLCTSDFullTrainer._run_step`` (core/nusc_trainers.py:255-366).  Hyper-parameters that
+the reference reads from the global torchpack ``configs`` are explicit arguments here.
+Module / parameter names equal the reference's (checkpoint compatible)."""
+from copy import deepcopy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import torchsparse
+from .camera import BNReluConv, SwiftNetRes18
+from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c_scatter
+from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d,
+                           ResidualBlock)
+from .lidar.point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .lidar.sphereformer import SphereFormer
+from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
+from .losses import MixLovaszCrossEntropy
+from .torchsparse import PointTensor
+from .torchsparse import nn as spnn
+
+__all__ = ['StudentMSP2IFM', 'TSDFull', 'teacher_to_student', 'kd_losses', 'KDCriterion']
+
+_BASE_CHANNELS = (32, 32, 64, 128, 256, 256, 128, 96, 96)
+
+
+class StudentMSP2IFM(nn.Module):
+    """SPVCNN + SphereFormer LiDAR branch fused at four scales with a SwiftNet-18 camera branch
+    (``SPVCNN_SWIFTNET18_SPFORMER_MSP2IFM``, tsd_full.py:197-559)."""
+
+    def __init__(self, cr, in_channel, num_classes, window_size, window_size_sphere, quant_size, quant_size_sphere,
+                 window_size_scale, drop_path_rate, a, pres, vres, imagenet_pretrain=None, run_pix_decoder=True):
+        super().__init__()
+        cs = [int(cr * c) for c in _BASE_CHANNELS]
+        self.cs = cs
+        self.pix_branch = SwiftNetRes18(num_feature=(128, 128, 128), pretrained_path=imagenet_pretrain)
+        img_cs = self.pix_branch.img_cs
+        self.in_channel, self.num_classes, self.out_channel = in_channel, num_classes, cs[-1]
+        self.pres, self.vres = pres, vres
+
+        self.stem = FusedSequential(
+            spnn.Conv3d(in_channel, cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True),
+            spnn.Conv3d(cs[0], cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True))
+        self.vox_downs = nn.ModuleList([
+            nn.Sequential(BasicConvolutionBlock(cs[i], cs[i], ks=2, stride=2, dilation=1),
+                          ResidualBlock(cs[i], cs[i + 1], ks=3, stride=1, dilation=1),
+                          ResidualBlock(cs[i + 1], cs[i + 1], ks=3, stride=1, dilation=1))
+            for i in range(4)])
+
+        self.window_size, self.window_size_sphere = window_size, window_size_sphere
+        self.quant_size, self.quant_size_sphere = quant_size, quant_size_sphere
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, 7)]
+        self.transformer_blocks = nn.ModuleList()
+        for idx in range(1, 5):
+            self.transformer_blocks.append(SphereFormer(
+                cs[idx], cs[idx] // 16, self.window_size, self.window_size_sphere, self.quant_size,
+                self.quant_size_sphere, indice_key='sphereformer{}'.format(idx + 1), drop_path=dpr[idx], a=a))
+            sc, ss = window_size_scale
+            self.window_size = self.window_size * sc
+            self.quant_size = self.quant_size * sc
+            self.window_size_sphere[0] = self.window_size_sphere[0] * ss
+            self.window_size_sphere[1] = self.window_size_sphere[1] * ss
+            self.quant_size_sphere[0] = self.quant_size_sphere[0] * ss      # in place
+            self.quant_size_sphere[1] = self.quant_size_sphere[1] * ss
+
+        self.c2l_fusion_blocks = nn.ModuleList(
+            [Atten_Fusion_Conv(inplanes_I=img_cs[i], inplanes_P=cs[i], outplanes=cs[i]) for i in range(1, 5)])
+        self.l2c_fusion_blocks = nn.ModuleList(
+            [L2CFusion(inplanes_I=img_cs[i], inplanes_P=cs[i], outplanes=img_cs[i]) for i in range(1, 5)])
+        self.learner = nn.ModuleList([
+            nn.Sequential(nn.Linear(cs[i], img_cs[i]), nn.BatchNorm1d(img_cs[i]), nn.ReLU(True),
+                          nn.Linear(img_cs[i], img_cs[i]), nn.BatchNorm1d(img_cs[i]))
+            for i in range(1, 5)])
+        self.mse = nn.MSELoss()
+
+        self.vox_ups = nn.ModuleList([
+            nn.ModuleList([
+                BasicDeconvolutionBlock(cs[i], cs[i + 1], ks=2, stride=2),
+                nn.Sequential(
+                    ResidualBlock(cs[i + 1] + cs[len(cs) - 2 - i], cs[i + 1], ks=3, stride=1, dilation=1),
+                    ResidualBlock(cs[i + 1], cs[i + 1], ks=3, stride=1, dilation=1))])
+            for i in range(4, len(cs) - 1)])
+        self.classifier_vox = nn.Sequential(nn.Linear(cs[8], num_classes))
+        self.classifier_pix = BNReluConv(self.pix_branch.num_features, num_classes, k=1)
+        self.point_transforms = nn.ModuleList([
+            FusedSequential(nn.Linear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
+            for a_, b_ in ((0, 4), (4, 6), (6, 8))])
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self.dropout = nn.Dropout(0.3, True)
+        self.run_pix_decoder = run_pix_decoder
+        self.adapt_layer = None          # attached by TSDFull (tsd_full.py:576-580)
+
+    def forward(self, in_mod):
+        x = in_mod['lidar']
+        im = in_mod['images']                                   # [B, ncam, 3, H, W]
+        ib, ncam, ic, ih, iw = im.shape
+        im = im.reshape(-1, ic, ih, iw)
+        pixel_coordinates, masks, fov_mask = in_mod['pixel_coordinates'], in_mod['masks'], in_mod['fov_mask']
+        z = PointTensor(x.F, x.C.float())
+        x0 = initial_voxelize(z, self.pres, self.vres)
+        zz = PointTensor(x0.F, x0.C.float())
+        x0 = self.stem(x0)
+        z0 = voxel_to_point(x0, z, nearest=False)
+
+        x_im = self.pix_branch.forward_stem(im)
+        vox_feats = [point_to_voxel(x0, z0)]
+        img_feats, mse_loss, pts_feats = [], [], []
+        n_stage = len(self.vox_downs)
+        for idx in range(n_stage):
+            vox_out = self.vox_downs[idx](vox_feats[idx])
+            tmp_p = point_to_voxel(vox_out, zz)
+            coord_xyz, batch = tmp_p.F[:, :3], tmp_p.C[:, 3]
+            vox_out.F = self.transformer_blocks[idx](vox_out.F, coord_xyz, batch)
+            pts_feat = voxel_to_point(vox_out, z0)
+            if idx == n_stage - 1:
+                pts_feats.append(self.adapt_layer(pts_feat.F))
+
+            x_im, skip = self.pix_branch.forward_resblock(x_im, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
+            if idx == n_stage - 1:
+                skip = self.pix_branch.spp(skip)
+            _, ifc, ifh, ifw = skip.shape
+
+            # LiDAR -> camera: multi-scale scatter-mean of the point features into every camera's map
+            l2c_feat_map = l2c_scatter(pts_feat.F, pixel_coordinates, masks, ifh, ifw, n_stage - idx)
+            x_im, skip = self.l2c_fusion_blocks[idx](l2c_feat_map, skip)
+            img_feats.append(skip)
+
+            # camera -> LiDAR: bilinear gather, later cameras overwrite; points no camera sees take the
+            # learner's pseudo image feature (not detached), the MSE target is detached (Appendix C-5)
+            img_feat_tensor = c2l_gather(skip.view(ib, ncam, ifc, ifh, ifw), pixel_coordinates, masks)
+            pseudo = self.learner[idx](pts_feat.F)
+            img_feat_tensor = torch.where(fov_mask.unsqueeze(1), img_feat_tensor, pseudo)
+            mse_loss.append(self.mse(pseudo[fov_mask], img_feat_tensor[fov_mask].detach()))
+            pts_feat.F = self.c2l_fusion_blocks[idx](pts_feat.F, img_feat_tensor)
+            vox_feats.append(point_to_voxel(vox_out, pts_feat))
+
+        _, x1, x2, x3, x4 = vox_feats
+        z1 = pts_feat
+        z1.F = z1.F + self.point_transforms[0](z0.F)
+        y1 = point_to_voxel(x4, z1)
+        y1.F = self.dropout(y1.F)
+        y1 = self.vox_ups[0][0](y1)
+        y1 = self.vox_ups[0][1](torchsparse.cat([y1, x3]))
+        y2 = self.vox_ups[1][0](y1)
+        y2 = self.vox_ups[1][1](torchsparse.cat([y2, x2]))
+        z2 = voxel_to_point(y2, z1)
+        z2.F = z2.F + self.point_transforms[1](z1.F)
+        y3 = point_to_voxel(y2, z2)
+        y3.F = self.dropout(y3.F)
+        y3 = self.vox_ups[2][0](y3)
+        y3 = self.vox_ups[2][1](torchsparse.cat([y3, x1]))
+        y4 = self.vox_ups[3][0](y3)
+        y4 = self.vox_ups[3][1](torchsparse.cat([y4, x0]))
+        z3 = voxel_to_point(y4, z2)
+        z3.F = z3.F + self.point_transforms[2](z2.F)
+
+        ret = {'x_vox': self.classifier_vox(z3.F), 'num_pts': [c.shape[1] for c in pixel_coordinates],
+               'mse_loss': mse_loss, 'pts_feats': pts_feats}
+        if self.run_pix_decoder:
+            up = self.pix_branch.forward_up(img_feats, im_size=(ih, iw))
+            fmap = self.classifier_pix(up)
+            fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
+            ret['x_pix'] = feature_fetch(masks, pixel_coordinates, fmap)
+        return ret
+
+
+class TSDFull(nn.Module):
+    """Student + frozen teacher (``SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL``, tsd_full.py:562-596).
+    ``spformer`` holds the shared SphereFormer hyper-parameters (see lidar.spformer_kwargs); like
+    the reference the teacher receives a deep copy (separate aliasing of quant_size_sphere)."""
+
+    def __init__(self, cr, cr_t, in_channel, in_channel_t, num_classes, spformer: dict, imagenet_pretrain=None,
+                 run_pix_decoder=True, debug_val=False):
+        super().__init__()
+        param_s, param_t = dict(spformer), deepcopy(spformer)
+        self.model_s = StudentMSP2IFM(cr=cr, in_channel=in_channel, num_classes=num_classes,
+                                      imagenet_pretrain=imagenet_pretrain, run_pix_decoder=run_pix_decoder, **param_s)
+        self.model_t = SPVCNN_SPFORMER(cr=cr_t, in_channel=in_channel_t, num_classes=num_classes,
+                                       return_pts_feats=True, **param_t)
+        self.model_t.requires_grad_(False)
+        self.num_classes = num_classes
+        self.debug_val = debug_val
+        self.model_s.adapt_layer = nn.Sequential(
+            nn.Linear(self.model_s.cs[4], self.model_t.cs[4]), nn.BatchNorm1d(self.model_t.cs[4]), nn.ReLU(True))
+
+    def forward(self, in_mod: dict):
+        ret = {'stu': self.model_s(in_mod['student'])}
+        if self.training or self.debug_val:
+            with torch.no_grad():
+                ret['t'] = self.model_t(in_mod['teacher'])
+        return ret
+
+
+def teacher_to_student(x_t, inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full=None):
+    """Re-index a per-teacher-voxel tensor to the student's voxels:
+    ``x_t[inv][keyframe][inds]`` per sample (core/nusc_trainers.py:288-324), as ONE gather:
+    the composed index is built from the per-sample offsets, no Python-side tensor slicing."""
+    idx = []
+    cur_v = cur_p = 0
+    for n_p, n_v, inds in zip(num_pts, num_vox_t, inds_s):
+        inv = inverse_map[cur_p:cur_p + n_p]
+        if keyframe_mask_full is not None:
+            inv = inv[keyframe_mask_full[cur_p:cur_p + n_p]]
+        idx.append(inv[inds[0]] + cur_v)
+        cur_v += n_v
+        cur_p += n_p
+    return x_t.index_select(0, torch.cat(idx))
+
+
+class KDCriterion(nn.Module):
+    """The three criteria of configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:1-9."""
+
+    def __init__(self, ignore_index=0, w_kl=1.0, w_feat=1.0, mse_norm_feat=False):
+        super().__init__()
+        self.lovasz = MixLovaszCrossEntropy(ignore_index=ignore_index)
+        self.kl = nn.KLDivLoss(reduction='batchmean')
+        self.mse = nn.MSELoss()
+        self.w_kl, self.w_feat, self.mse_norm_feat = w_kl, w_feat, mse_norm_feat
+
+
+def kd_losses(outputs, targets, fov_mask, inverse_map, inds_s, num_pts, num_vox_t, crit: KDCriterion,
+              keyframe_mask_full=None):
+    """Loss terms and total of the KD step (core/nusc_trainers.py:288-358)."""
+    x_vox_t2s = teacher_to_student(outputs['t']['x_vox'], inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full)
+    feat_t2s = teacher_to_student(outputs['t']['pts_feats'][0], inverse_map, inds_s, num_pts, num_vox_t,
+                                  keyframe_mask_full)
+    x_vox, x_pix = outputs['stu']['x_vox'], outputs['stu']['x_pix']
+    ld = {'ce_vox': crit.lovasz(x_vox, targets),
+          'ce_pix': crit.lovasz(x_pix[fov_mask], targets[fov_mask]),
+          'kl': crit.kl(F.log_softmax(x_vox, dim=1), F.softmax(x_vox_t2s.detach(), dim=1)),
+          'mse': outputs['stu']['mse_loss']}
+    pts_feat_s = outputs['stu']['pts_feats'][0]
+    if crit.mse_norm_feat:
+        def norm(f):
+            f_max, f_min = f.max(-1, keepdim=True).values, f.min(-1, keepdim=True).values
+            return (f - f_min) / (f_max - f_min)
+        pts_feat_s, feat_t2s = norm(pts_feat_s), norm(feat_t2s)
+    ld['feat'] = crit.mse(pts_feat_s, feat_t2s.detach())
+    total = ld['ce_vox'] + ld['ce_pix'] + crit.w_kl * ld['kl'] + sum(ld['mse']) + crit.w_feat * ld['feat']
+    ld['total'] = total
+    return ld

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ['synth_scene', 'synth_batch', 'CLASS_DISTRIBUTE', 'kmap_stats']
+__all__ = ['synth_scene', 'synth_batch', 'synth_kd_batch', 'project_to_cameras', 'CLASS_DISTRIBUTE', 'kmap_stats']
 
 # class frequencies in the spirit of lc_semantic_nusc_tsd_full.py:114-116
 # (17 classes, index 0 = ignore).
@@ -140,3 +140,102 @@ def kmap_stats(coords4: np.ndarray):
                 pos = np.minimum(np.searchsorted(s, q), len(s) - 1)
                 pairs += int((s[pos] == q).sum())
     return len(c), pairs, pairs / max(len(c), 1)
+
+
+# --------------------------------------------------------------------------- KD batch
+_CAM_YAW_DEG = (55.0, 0.0, -55.0, 110.0, 180.0, -110.0)
+
+
+def project_to_cameras(xyz: np.ndarray, image_hw=(900, 1600)):
+    """6 pinhole cameras (yaw +55, 0, -55, +110, 180, -110 deg; fx = fy = 1266, cx = 816,
+    cy = 491 on a 1600x900 sensor, mounted 1.5 m above the LiDAR origin).  Returns
+    ``pixel_coordinates`` f32 [6,N,2] normalised to [-1,1] by (W-1, H-1) and ``masks`` bool
+    [6,N] = depth > 1 m and strictly inside (-1,1)^2 -- the schema of
+    core/datasets/lc_semantic_nusc_tsd_full.py:344-387."""
+    H, W = 900, 1600
+    fx = fy = 1266.0
+    cx, cy = 816.0, 491.0
+    n = xyz.shape[0]
+    pix = np.zeros((6, n, 2), dtype=np.float32)
+    masks = np.zeros((6, n), dtype=bool)
+    for c, yaw in enumerate(_CAM_YAW_DEG):
+        a = np.deg2rad(yaw)
+        fwd = np.array([np.cos(a), np.sin(a), 0.0])
+        left = np.array([-np.sin(a), np.cos(a), 0.0])
+        up = np.array([0.0, 0.0, 1.0])
+        p = xyz[:, :3].astype(np.float64) - np.array([0.0, 0.0, 1.5])
+        depth = p @ fwd
+        xr = -(p @ left)
+        yd = -(p @ up)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            u = fx * xr / depth + cx
+            v = fy * yd / depth + cy
+        un = u / (W - 1) * 2 - 1
+        vn = v / (H - 1) * 2 - 1
+        ok = (depth > 1.0) & (un > -1) & (un < 1) & (vn > -1) & (vn < 1)
+        pix[c, :, 0] = np.where(ok, un, 0.0)
+        pix[c, :, 1] = np.where(ok, vn, 0.0)
+        masks[c] = ok
+    return pix, masks
+
+
+def _yaw(xyz, deg):
+    a = np.deg2rad(deg)
+    r = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+    return xyz @ r.T
+
+
+def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 640), ncam: int = 6):
+    """Student + teacher feed dicts with the collate schema of
+    core/datasets/lc_semantic_nusc_tsd_full.py:436-486, numpy payloads.
+
+    One LiDAR scene per sample.  The student sees it under one random yaw and its voxels in a
+    shuffled order; the teacher sees the same key-frame points under another yaw, re-voxelised
+    (so points may merge: ``inverse_map`` point -> teacher voxel).  ``inds`` maps every student
+    voxel to its key-frame point, as core/nusc_trainers.py:295-324 consumes it."""
+    rng = np.random.default_rng(seed + 7919)
+    H, W = image_hw
+    S = {'coords': [], 'feats': [], 'targets': [], 'pixel_coordinates': [], 'masks': [], 'fov_mask': [], 'inds': [],
+         'num_vox': []}
+    T = {'coords': [], 'feats': [], 'targets': [], 'inverse_map': [], 'num_pts': [], 'num_vox': []}
+    for b in range(batch):
+        sc = synth_scene(n_vox, seed + b)
+        xyz, inten, labels = sc['feats'][:, :3], sc['feats'][:, 3:], sc['labels']
+        npts = xyz.shape[0]
+        # ---- student: yaw, voxelise (unique by construction up to rounding), shuffled voxel order
+        xs = _yaw(xyz, rng.uniform(-180, 180))
+        vs = np.round(xs / VOXEL_SIZE).astype(np.int32)
+        vs -= vs.min(0, keepdims=True)
+        key = (vs[:, 0].astype(np.int64) << 40) | (vs[:, 1].astype(np.int64) << 20) | vs[:, 2].astype(np.int64)
+        _, first = np.unique(key, return_index=True)
+        inds = rng.permutation(first)                      # student voxel -> key-frame point
+        pix, masks = project_to_cameras(xs[inds])
+        S['coords'].append(np.concatenate([vs[inds], np.full((len(inds), 1), b, np.int32)], 1))
+        S['feats'].append(np.concatenate([xs[inds], inten[inds]], 1).astype(np.float32))
+        S['targets'].append(labels[inds])
+        S['pixel_coordinates'].append(pix[:ncam])
+        S['masks'].append(masks[:ncam])
+        S['fov_mask'].append(masks[:ncam].any(0))
+        S['inds'].append([inds.astype(np.int64)])
+        S['num_vox'].append(len(inds))
+        # ---- teacher: another yaw, re-voxelised; inverse_map over ALL key-frame points
+        xt = _yaw(xyz, rng.uniform(-180, 180))
+        vt = np.round(xt / VOXEL_SIZE).astype(np.int32)
+        vt -= vt.min(0, keepdims=True)
+        keyt = (vt[:, 0].astype(np.int64) << 40) | (vt[:, 1].astype(np.int64) << 20) | vt[:, 2].astype(np.int64)
+        _, firstt, inv = np.unique(keyt, return_index=True, return_inverse=True)
+        T['coords'].append(np.concatenate([vt[firstt], np.full((len(firstt), 1), b, np.int32)], 1))
+        T['feats'].append(np.concatenate([xt[firstt], inten[firstt]], 1).astype(np.float32))
+        T['targets'].append(labels[firstt])
+        T['inverse_map'].append(inv.astype(np.int64))
+        T['num_pts'].append(npts)
+        T['num_vox'].append(len(firstt))
+    images = rng.uniform(0, 255, (batch, ncam, H, W, 3)).astype(np.float32)
+    student = {'coords': np.concatenate(S['coords']), 'feats': np.concatenate(S['feats']),
+               'targets': np.concatenate(S['targets']), 'images': images,
+               'pixel_coordinates': S['pixel_coordinates'], 'masks': S['masks'],
+               'fov_mask': np.concatenate(S['fov_mask']), 'inds': S['inds'], 'num_vox': S['num_vox']}
+    teacher = {'coords': np.concatenate(T['coords']), 'feats': np.concatenate(T['feats']),
+               'targets': np.concatenate(T['targets']), 'inverse_map': np.concatenate(T['inverse_map']),
+               'num_pts': T['num_pts'], 'num_vox': T['num_vox']}
+    return {'student': student, 'teacher': teacher}
