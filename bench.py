@@ -41,6 +41,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--voxels', type=int, default=N_VOX)
     ap.add_argument('--cr', type=float, default=1.0)
+    ap.add_argument('--workload', choices=['spvcnn', 'kd'], default='spvcnn',
+                    help="spvcnn = BASELINE.json configs[1] (default, the judged line); kd = configs[2]: SPVCNN+SphereFormer "
+                         "teacher (cr_t 2.0) + SwiftNet18 student (cr 1.0) + KD losses, 6 cameras")
+    ap.add_argument('--image-hw', type=int, nargs=2, default=[360, 640])
     ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-voxels', type=int, default=20000)
@@ -211,21 +215,31 @@ def main():
 
     result = {}
     if not args.kernel_only:
+        from u2mkd_amd import train as T
         torch.manual_seed(0)
-        model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
-        net = D.wrap_model(model, sync_bn=True)
-        criterion = MixLovaszCrossEntropy(ignore_index=0)
-        opt = torch.optim.SGD(net.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
-        sched = torch.optim.lr_scheduler.LambdaLR(opt, cosine_warmup_lambda(25, 1, 28130, world))
+        if args.workload == 'spvcnn':
+            model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+            runner = T.LidarStep(model, num_epochs=25, batch_size=1)
 
-        def step():
-            out = net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
-            loss = criterion(out, labels)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            sched.step()
-            return loss
+            def step():
+                return runner(feats, coords, labels)
+            workload = ('BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE + bwd + SGD), '
+                        'one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels))
+        else:
+            from u2mkd_amd import kd as KD
+            from u2mkd_amd.synth import synth_kd_batch
+            sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+            model = KD.TSDFull(cr=args.cr, cr_t=2.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+            runner = T.KDStep(model, num_epochs=50, batch_size=1)
+            runner.train_mode()
+            dbatch = T.kd_batch_to_device(synth_kd_batch(args.voxels, 1, seed=1234 + rank,
+                                                         image_hw=tuple(args.image_hw)))
+
+            def step():
+                return runner(dbatch)
+            workload = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t 2.0, frozen) + SwiftNet18/SPVCNN '
+                        'student (cr %g) + KD losses train step, %d voxels + 6 cameras %dx%d per GPU'
+                        % (args.cr, args.voxels, args.image_hw[0], args.image_hw[1]))
 
         log('model built, scene resident; warm-up')
         for _ in range(args.warmup):
@@ -249,8 +263,7 @@ def main():
             'value': round(total_points / dt, 1), 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE '
-                                   '+ bwd + SGD), one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels),
+            'config': {'workload': workload,
                        'voxels_per_gpu': args.voxels, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
                        'final_loss': round(float(loss.detach()), 5)},
         })

@@ -1,0 +1,106 @@
+"""Training-step drivers of the hot path (row a19 + the train branches of the reference's
+trainers): LiDAR-only (core/spformer_trainer.py:58-94) and KD
+(core/nusc_trainers.py:255-366).  One call = forward, losses, zero_grad, backward (DDP
+all-reduce overlapped), SGD-nesterov step, LR-scheduler step; no ``.item()`` host syncs."""
+import numpy as np
+import torch
+
+from . import distributed as D
+from . import kd as KD
+from . import torchsparse as ts
+from .losses import MixLovaszCrossEntropy
+
+__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device']
+
+
+def cosine_schedule_with_warmup(k, num_epochs, batch_size, dataset_size, world):
+    """core/schedulers.py:10-35: the batch is scaled by the world size, warm-up lasts
+    1000 // world iterations and only exists for world > 1."""
+    batch_size *= world
+    warmup_iters = 0 if world == 1 else 1000 // world
+    if k < warmup_iters:
+        return (k + 1) / warmup_iters
+    iter_per_epoch = (dataset_size + batch_size - 1) // batch_size
+    return 0.5 * (1 + np.cos(np.pi * (k - warmup_iters) / (num_epochs * iter_per_epoch)))
+
+
+def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4):
+    """core/builder.py:663-669 (SGD, nesterov)."""
+    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
+
+
+def _scheduler(opt, num_epochs, batch_size, dataset_size=28130):
+    w = D.world()
+    return torch.optim.lr_scheduler.LambdaLR(
+        opt, lambda k: cosine_schedule_with_warmup(k, num_epochs, batch_size, dataset_size, w))
+
+
+class LidarStep:
+    """Teacher / LiDAR-only training step."""
+
+    def __init__(self, model, num_epochs=25, batch_size=1, ignore_index=0):
+        self.model = model
+        self.net = D.wrap_model(model, sync_bn=True)
+        self.criterion = MixLovaszCrossEntropy(ignore_index=ignore_index)
+        self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
+        self.sched = _scheduler(self.opt, num_epochs, batch_size)
+
+    def __call__(self, feats, coords, targets, keyframe_mask=None):
+        out = self.net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+        if keyframe_mask is not None:
+            out, targets = out[keyframe_mask], targets[keyframe_mask]
+        loss = self.criterion(out, targets)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        self.sched.step()
+        return loss.detach()
+
+
+def kd_batch_to_device(b, device='cuda'):
+    """numpy KD batch (synth.synth_kd_batch / the reference's collate schema) -> device tensors
+    laid out as NuScenesLCTSDFullTrainer._prepare_input does (images -> [B, ncam, 3, H, W])."""
+    s, t = b['student'], b['teacher']
+    dev = torch.device(device)
+    f = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+    return {
+        's_feats': f(s['feats']), 's_coords': f(s['coords']), 'targets': f(s['targets']),
+        'images': f(s['images']).permute(0, 1, 4, 2, 3).contiguous(),
+        'pixel_coordinates': [f(c) for c in s['pixel_coordinates']], 'masks': [f(m) for m in s['masks']],
+        'fov_mask': f(s['fov_mask']), 'inds': [[f(i[0])] for i in s['inds']],
+        't_feats': f(t['feats']), 't_coords': f(t['coords']), 'inverse_map': f(t['inverse_map']),
+        'num_pts': list(t['num_pts']), 'num_vox_t': list(t['num_vox']),
+        'keyframe_mask_full': f(t['keyframe_mask_full']) if 'keyframe_mask_full' in t else None,
+    }
+
+
+class KDStep:
+    """Uni-to-multi-modal KD training step: frozen teacher forward (no grad, eval-mode BN),
+    student forward/backward, the five loss terms."""
+
+    def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0):
+        self.model = model
+        if D.world() > 1:
+            from .lidar.point_voxel import SparseSyncBatchNorm
+            model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
+        self.net = D.wrap_model(model, sync_bn=False)
+        self.crit = KD.KDCriterion(ignore_index=0, w_kl=w_kl, w_feat=w_feat)
+        self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
+        self.sched = _scheduler(self.opt, num_epochs, batch_size)
+
+    def train_mode(self):
+        self.model.train()
+        self.model.model_t.eval()          # core/nusc_trainers.py:203-208
+
+    def __call__(self, d):
+        stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
+               'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
+        tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
+        out = self.net({'student': stu, 'teacher': tea})
+        ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
+                          self.crit, d['keyframe_mask_full'])
+        self.opt.zero_grad()
+        ld['total'].backward()
+        self.opt.step()
+        self.sched.step()
+        return ld['total'].detach()
