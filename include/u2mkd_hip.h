@@ -141,6 +141,12 @@ int u2mkd_devoxelize_forward(const float *feats /*[nv,c]*/, const int32_t *idx /
 int u2mkd_devoxelize_backward(const float *grad_out /*[n,c]*/, const int32_t *idx /*[n,8]*/, const float *w /*[n,8]*/,
                               int64_t n, int64_t nv, int32_t c, float *grad_feats /*[nv,c] pre-zeroed*/,
                               u2mkd_stream_t s);
+/* Deterministic form of the two scatters (voxelize forward, devoxelize backward): entries
+ * sorted by destination row (CSR: seg_offsets [nv+1]); out[v] = sum_e w[e] * src[row[e]]
+ * (entry_w NULL = 1; mean != 0 divides by the segment length).  No atomics.             */
+int u2mkd_segment_sum(const float *src /*[*,c]*/, int32_t c, const int32_t *entry_row /*[E]*/,
+                      const float *entry_w /*[E] or NULL*/, const int32_t *seg_offsets /*[nv+1]*/, int64_t nv,
+                      int32_t mean, float *out /*[nv,c]*/, u2mkd_stream_t s);
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 

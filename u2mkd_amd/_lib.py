@@ -55,6 +55,7 @@ SIGNATURES = {
     'u2mkd_voxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_devoxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_devoxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    'u2mkd_segment_sum': (C.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),
 }
 

@@ -19,7 +19,7 @@
 namespace u2mkd {
 
 constexpr int kBnThreads = 256;
-constexpr int kBnSlabRows = 512;   // rows per workgroup in the partial passes
+constexpr int kBnSlabRows = 128;   // rows per workgroup in the partial passes (>= 600 workgroups at 80k rows)
 
 // thread layout for a [rows, C4 float4] slab: j = float4 column, ry = row lane
 struct BnLayout {
@@ -87,20 +87,36 @@ bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
-                                         float momentum, float *__restrict__ running_mean,
-                                         float *__restrict__ running_var, float *__restrict__ mean_out,
-                                         float *__restrict__ invstd_out) {
-    int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+// 16 channels x 16 slab lanes per block: lane g merges slabs g, g+16, ... with Chan's update,
+// the 16 partial (n, mean, M2) triples are then merged in lane order through LDS (fixed order).
+__global__ void __launch_bounds__(256)
+bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
+                         float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                         float *__restrict__ mean_out, float *__restrict__ invstd_out) {
+    __shared__ float s_n[16][16], s_m[16][16], s_q[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     float na = 0.f, mean = 0.f, m2 = 0.f;
-    for (int b = 0; b < nslab; ++b) {
-        float nb = (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows);
-        float mb = partial[(size_t)b * 2 * c + ch], m2b = partial[(size_t)b * 2 * c + c + ch];
+    if (ch < c)
+        for (int b = g; b < nslab; b += 16) {
+            float nb = (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows);
+            float mb = partial[(size_t)b * 2 * c + ch], m2b = partial[(size_t)b * 2 * c + c + ch];
+            float tot = na + nb;
+            float delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += m2b + delta * delta * (na * nb / tot);
+            na = tot;
+        }
+    s_n[g][cl] = na; s_m[g][cl] = mean; s_q[g][cl] = m2;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+    for (int i = 1; i < 16; ++i) {
+        float nb = s_n[i][cl];
+        if (nb == 0.f) continue;
         float tot = na + nb;
-        float delta = mb - mean;
+        float delta = s_m[i][cl] - mean;
         mean += delta * (nb / tot);
-        m2 += m2b + delta * delta * (na * nb / tot);
+        m2 += s_q[i][cl] + delta * delta * (na * nb / tot);
         na = tot;
     }
     float var = m2 / (float)n;
@@ -190,15 +206,22 @@ bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c,
-                                       float *__restrict__ dbeta, float *__restrict__ dgamma) {
-    int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, float *__restrict__ dbeta,
+                       float *__restrict__ dgamma) {
+    __shared__ float s_1[16][16], s_2[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nslab; ++b) {
-        s1 += partial[(size_t)b * 2 * c + ch];
-        s2 += partial[(size_t)b * 2 * c + c + ch];
-    }
+    if (ch < c)
+        for (int b = g; b < nslab; b += 16) {
+            s1 += partial[(size_t)b * 2 * c + ch];
+            s2 += partial[(size_t)b * 2 * c + c + ch];
+        }
+    s_1[g][cl] = s1; s_2[g][cl] = s2;
+    __syncthreads();
+    if (g != 0 || ch >= c) return;
+    for (int i = 1; i < 16; ++i) { s1 += s_1[i][cl]; s2 += s_2[i][cl]; }
     dbeta[ch] = s1;
     dgamma[ch] = s2;
 }
@@ -287,7 +310,7 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
     hipStream_t st = as_stream(s);
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, partial, nslab, n, c,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, 16)), dim3(256), 0, st, partial, nslab, n, c,
                        eps, momentum, running_mean, running_var, mean, invstd);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
@@ -319,7 +342,7 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
                        invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, partial, nslab, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, 16)), dim3(256), 0, st, partial, nslab, c,
                        dbeta, dgamma);
     int64_t total4 = n * (c / 4);
     if (training)

@@ -137,6 +137,31 @@ __global__ void devoxelize_bwd_kernel(const float *__restrict__ gout, const int3
     }
 }
 
+// Deterministic scatter replacement: out[v] = sum over the entries e of segment v of
+// w[e] * src[row[e]] (optionally / segment length).  Entries are pre-sorted by destination
+// (CSR built once per point<->voxel map), so there are no atomics, every output row is
+// written once, and the summation order is fixed.  One thread = 16 B of one output row.
+__global__ void segment_sum_kernel(const float *__restrict__ src, int c4, const int32_t *__restrict__ erow,
+                                   const float *__restrict__ ew, const int32_t *__restrict__ seg, int64_t nv,
+                                   int mean, float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t v = t / c4;
+    if (v >= nv) return;
+    int j = (int)(t - v * c4);
+    const int e0 = seg[v], e1 = seg[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; ++e) {
+        float w = ew ? ew[e] : 1.f;
+        float4 f = reinterpret_cast<const float4 *>(src)[(int64_t)erow[e] * c4 + j];
+        acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
+    }
+    if (mean && e1 > e0) {
+        float inv = (float)(e1 - e0);
+        acc.x /= inv; acc.y /= inv; acc.z /= inv; acc.w /= inv;
+    }
+    reinterpret_cast<float4 *>(out)[t] = acc;
+}
+
 // F.calc_ti_weights fused with the [8,N] -> [N,8] transposes of
 // core/models/utils.py:94-95.  Same operation order as the reference:
 // products of differences, / scale^3, zero where idx == -1, / (sum + 1e-8).
@@ -236,6 +261,17 @@ int u2mkd_devoxelize_backward(const float *grad_out, const int32_t *idx, const f
     U2_REQUIRE(grad_out && idx && w && grad_feats, "u2mkd_devoxelize_backward: null pointer");
     LAUNCH_ROWS(devoxelize_bwd_kernel, n, c, grad_out, idx, w, n, nv, c, grad_feats);
     return check_launch("u2mkd_devoxelize_backward");
+}
+
+int u2mkd_segment_sum(const float *src, int32_t c, const int32_t *entry_row, const float *entry_w,
+                      const int32_t *seg_offsets, int64_t nv, int32_t mean, float *out, u2mkd_stream_t s) {
+    if (nv == 0 || c == 0) return 0;
+    U2_REQUIRE(src && entry_row && seg_offsets && out, "u2mkd_segment_sum: null pointer");
+    U2_REQUIRE(c % 4 == 0, "u2mkd_segment_sum: c=%d must be a multiple of 4", c);
+    int64_t total = nv * (c / 4);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), src, c / 4,
+                       entry_row, entry_w, seg_offsets, nv, mean, out);
+    return check_launch("u2mkd_segment_sum");
 }
 
 int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, float scale, float *w_n8,

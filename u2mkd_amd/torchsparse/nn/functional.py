@@ -83,6 +83,35 @@ def spcount(coords: torch.Tensor, num: int) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------- destination-sorted scatter plans
+def _csr_by_destination(keys: torch.Tensor, nv: int):
+    """(entry order int32 [E'], segment offsets int32 [nv+1]) of the entries with key >= 0, sorted
+    by key (stable).  No host sync: dropped entries sort to the end and are never addressed."""
+    k32 = _i32(keys).contiguous().view(-1)
+    counts = spcount(k32, nv)
+    seg = torch.zeros(nv + 1, dtype=torch.int32, device=keys.device)
+    torch.cumsum(counts, 0, out=seg[1:])
+    order = torch.argsort(torch.where(k32 >= 0, k32, nv), stable=True).int()
+    return order, seg
+
+
+def _plan(t: torch.Tensor, name: str, build):
+    """Cache a derived index structure on the index tensor it was derived from (the point<->voxel
+    index tensors are themselves cached by the model in z.idx_query / z.additional_features)."""
+    cache = t.__dict__.setdefault('_u2mkd_plans', {})
+    if name not in cache:
+        cache[name] = build()
+    return cache[name]
+
+
+def _segment_sum(src, erow, ew, seg, nv, mean):
+    c = src.shape[1]
+    out = torch.empty(nv, c, dtype=torch.float32, device=src.device)
+    L.call('u2mkd_segment_sum', L.ptr(src), c, L.ptr(erow), L.ptr(ew), L.ptr(seg), nv, int(mean), L.ptr(out),
+           L.stream())
+    return out
+
+
 # ----------------------------------------------------------------- voxelize
 class VoxelizeFunction(Function):
     @staticmethod
@@ -93,8 +122,14 @@ class VoxelizeFunction(Function):
         counts = _i32(counts).contiguous()
         n, c = feats.shape
         nv = counts.shape[0]
-        out = torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
-        L.call('u2mkd_voxelize_forward', L.ptr(feats), L.ptr(coords), L.ptr(counts), n, nv, c, L.ptr(out), L.stream())
+        if c % 4 == 0:
+            # deterministic scatter-mean: points grouped by voxel once per map, then a gather-sum
+            order, seg = _plan(coords, 'vox_csr_%d' % nv, lambda: _csr_by_destination(coords, nv))
+            out = _segment_sum(feats, order, None, seg, nv, True)
+        else:
+            out = torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
+            L.call('u2mkd_voxelize_forward', L.ptr(feats), L.ptr(coords), L.ptr(counts), n, nv, c, L.ptr(out),
+                   L.stream())
         ctx.for_backwards = (coords, counts, n)
         return out
 
@@ -109,6 +144,10 @@ class VoxelizeFunction(Function):
 
 
 def spvoxelize(feats, coords, counts):
+    # the model caches idx_query (int64, from sphashquery) per stride; keep its int32 form -- and the
+    # destination-sorted plan hung on it -- alive on that cached tensor instead of re-deriving per call
+    if coords.dtype != torch.int32 or not coords.is_contiguous():
+        coords = _plan(coords, 'i32', lambda: coords.int().contiguous())
     return VoxelizeFunction.apply(feats, coords, counts)
 
 
@@ -133,8 +172,17 @@ class DevoxelizeFunction(Function):
         coords, weights, nv = ctx.for_backwards
         g = grad_output.contiguous().float()
         n, c = g.shape
-        gi = torch.zeros(nv, c, dtype=torch.float32, device=g.device)
-        L.call('u2mkd_devoxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(weights), n, nv, c, L.ptr(gi), L.stream())
+        if c % 4 == 0:
+            def build():
+                keys = torch.where(weights != 0, coords, -1).view(-1)          # [n*8], zero-weight corners dropped
+                order, seg = _csr_by_destination(keys, nv)
+                return (order >> 3).contiguous(), weights.view(-1)[order.long()].contiguous(), seg
+            erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build)
+            gi = _segment_sum(g, erow, ew, seg, nv, False)
+        else:
+            gi = torch.zeros(nv, c, dtype=torch.float32, device=g.device)
+            L.call('u2mkd_devoxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(weights), n, nv, c, L.ptr(gi),
+                   L.stream())
         return gi, None, None
 
 
