@@ -15,6 +15,8 @@
 //   * wgrad scans the table, compacts the valid (gather,row) pairs of 256 rows
 //     with wave ballots + prefix sums into LDS and feeds them as the MFMA
 //     reduction dimension; partial slabs + ordered reduce (bitwise reproducible).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace u2mkd {
@@ -181,6 +183,200 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 if (col0 + 16 * n + r < cout) out[(size_t)rid * cout + col0 + 16 * n + r] = acc[n][reg];
         }
     }
+}
+
+// ---- output-stationary kernel, both operands through LDS, column-split waves -----------------
+// Same contraction as conv_os2_kernel; different work split.  The 4 waves of a workgroup share
+// the 64 (mask-sorted) output rows and split the 64*NBW output COLUMNS, so for every offset all
+// waves do the same amount of work (in conv_os2 a wave idles whenever its own 16 rows lack the
+// offset the workgroup is visiting).  Per (offset, KC-channel chunk) stage:
+//   * the gathered A rows of the ACTIVE 16-row blocks (whole 16-byte-coalesced row segments)
+//     and the weight tile are loaded into registers while the previous stage computes, then
+//     written to LDS ([row][KC+8] images, conflict-free ds_read_b128 fragments);
+//   * every wave multiplies each active row block with its NBW column blocks.
+// Row blocks without any neighbour at the offset are neither loaded nor multiplied.
+template <int RB, int NBW, int KC>
+__global__ void __launch_bounds__(256)
+conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
+                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, int64_t n_out, int K, int kflip,
+                float *__restrict__ out) {
+    constexpr int TM = 16 * RB, TN = 64 * NBW;   // RB 16-row blocks per workgroup tile
+    constexpr int S = KC + 8;                 // LDS row stride (floats)
+    constexpr int F4 = KC / 4;                // float4 per staged row
+    constexpr int AP = TM * F4 / 256;         // A float4 per thread per stage
+    constexpr int BP = TN * F4 / 256;         // B float4 per thread per stage
+    constexpr int NJ = KC / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);            // [TM][S]
+    float *Bs = As + TM * S;                                // [TN][S]
+    int *s_idx = reinterpret_cast<int *>(Bs + TN * S);      // [K][TM]
+    int *s_rid = s_idx + K * TM;                            // [TM]
+    unsigned *s_act = reinterpret_cast<unsigned *>(s_rid + TM);   // [K] active-row-block bits
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int col0 = blockIdx.y * TN;
+
+    for (int e = tid; e < TM; e += 256) {
+        int64_t row = row0 + e;
+        s_rid[e] = row < n_out ? (order ? order[row] : (int)row) : -1;
+    }
+    // neighbour indices of the tile + per-offset active-row-block bits.  A wave covers 64 consecutive
+    // rows of ONE offset, so a ballot gives the block bits with no LDS atomics.
+    for (int e0 = wave * 64; e0 < K * TM; e0 += 256) {
+        int e = e0 + lane;
+        int k = e0 / TM, rr = e - k * TM;            // e0 is a multiple of 64 and TM is 64 or 128
+        int64_t row = row0 + rr;
+        int v = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+        s_idx[e] = v;
+        unsigned long long bal = __ballot(v >= 0);
+        if (lane == 0) {
+            unsigned bits = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if ((bal >> (16 * g)) & 0xFFFFULL) bits |= 1u << g;
+            if (TM == 64) s_act[k] = bits;
+            else reinterpret_cast<unsigned char *>(s_act)[4 * k + ((e0 % TM) >> 6)] = (unsigned char)bits;
+        }
+    }
+    __syncthreads();
+    if (TM == 128) {   // fold the two half-tile nibbles into one 8-bit mask per offset
+        for (int kk = tid; kk < K; kk += 256) {
+            unsigned w = s_act[kk];
+            s_act[kk] = (w & 0xFu) | (((w >> 8) & 0xFu) << 4);
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc[RB][NBW];
+#pragma unroll
+    for (int m = 0; m < RB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = (cin + KC - 1) / KC;
+    float4 ra[AP], rb[BP];
+
+    // timing-only knobs (tools/ab_conv.py): kflip bit 1 = always read offset 0's weights (B stays
+    // L2-hot), bit 2 = gather A from the tile's own rows (A stays local).  Results are wrong then.
+    const bool dbg_same_b = (kflip & 2) != 0, dbg_local_a = (kflip & 4) != 0;
+    const int kf = kflip & 1;
+    auto load_stage = [&](int k, int c, unsigned act) {
+        const float *wk = wt + (size_t)(dbg_same_b ? 0 : (kf ? K - 1 - k : k)) * cout * cin;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            int f = tid + 256 * p;
+            int col = f / F4, ci = c * KC + (f % F4) * 4;
+            rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + col < cout && ci < cin)
+                rb[p] = *reinterpret_cast<const float4 *>(wk + (size_t)(col0 + col) * cin + ci);
+        }
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int f = tid + 256 * p;
+            int row = f / F4, ci = c * KC + (f % F4) * 4;
+            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((act >> (row >> 4)) & 1u) {
+                int idx = s_idx[k * TM + row];
+                if (dbg_local_a && idx >= 0) idx = (int)min((int64_t)(row0 + row), n_out - 1);
+                if (idx >= 0 && ci < cin) ra[p] = *reinterpret_cast<const float4 *>(in + (size_t)idx * cin + ci);
+            }
+        }
+    };
+    auto store_stage = [&](unsigned act) {
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            int f = tid + 256 * p;
+            *reinterpret_cast<float4 *>(Bs + (f / F4) * S + (f % F4) * 4) = rb[p];
+        }
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int f = tid + 256 * p;
+            int row = f / F4;
+            if ((act >> (row >> 4)) & 1u) *reinterpret_cast<float4 *>(As + row * S + (f % F4) * 4) = ra[p];
+        }
+    };
+
+    // first offset with any active block
+    int k = 0;
+    while (k < K && s_act[k] == 0u) ++k;
+    if (k < K) {
+        int c = 0;
+        unsigned act = s_act[k];
+        load_stage(k, 0, act);
+        store_stage(act);
+        __syncthreads();
+        while (true) {
+            int kn = k, cn = c + 1;
+            unsigned actn = act;
+            bool have_next = true;
+            if (cn == nchunk) {
+                cn = 0;
+                kn = k + 1;
+                while (kn < K && s_act[kn] == 0u) ++kn;
+                if (kn < K) actn = s_act[kn]; else have_next = false;
+            }
+            if (have_next) load_stage(kn, cn, actn);
+            // ---- compute stage (k, c): B fragments of this wave's column blocks, then every active row block
+            {
+                float4 b[NJ][NBW];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+                        b[j][n] = *reinterpret_cast<const float4 *>(Bs + (16 * (NBW * wave + n) + r) * S + 16 * j + 4 * q);
+#pragma unroll
+                for (int m = 0; m < RB; ++m) {
+                    if (!((act >> m) & 1u)) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float4 a = *reinterpret_cast<const float4 *>(As + (16 * m + r) * S + 16 * j + 4 * q);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j][n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[j][n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[j][n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[j][n].w, acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            if (!have_next) break;
+            __syncthreads();          // everyone finished reading the LDS images
+            store_stage(actn);
+            __syncthreads();          // images of the next stage complete
+            k = kn;
+            c = cn;
+            act = actn;
+        }
+    }
+    // epilogue: this wave's columns of all rows of the tile; D row = 4q + reg, col = r
+#pragma unroll
+    for (int m = 0; m < RB; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            int rid = s_rid[16 * m + 4 * q + reg];
+            if (rid >= 0) {
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    int col = col0 + 16 * (NBW * wave + n) + r;
+                    if (col < cout) out[(size_t)rid * cout + col] = acc[m][n][reg];
+                }
+            }
+        }
+}
+
+template <int RB, int NBW, int KC>
+static void launch_conv_os3(dim3 grid, int K, hipStream_t st, const float *in, int cin, const float *wt, int cout,
+                            const int32_t *nbr, const int32_t *order, int64_t n_out, int kflip, float *out) {
+    size_t lds = (size_t)(16 * RB + 64 * NBW) * (KC + 8) * 4 + (size_t)K * 16 * RB * 4 + 16 * RB * 4 + (size_t)K * 4 + 16;
+    if (lds > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_os3_kernel<RB, NBW, KC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_os3_kernel<RB, NBW, KC>), grid, dim3(256), lds, st, in, cin, wt, cout, nbr, order, n_out,
+                       K, kflip, out);
 }
 
 // ---- weight gradient ---------------------------------------------------------
@@ -563,7 +759,36 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
     U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "u2mkd_conv_forward_sorted: kernel volume %d not in 1..32", k);
     const int c16 = (cout + 15) / 16;
     const int nb = pick_nb(c16);
-    // variant: 0 = heuristic; otherwise waves * 100 + kc (e.g. 464 = 4 waves, KC 64)
+    // variant: 0 = heuristic; 3000 + kc = column-split kernel (conv_os3); otherwise waves * 100 + kc
+    if (variant == 0 && cout % 64 == 0 && cin >= 16) {
+        variant = 3000 + (cin % 64 == 0 ? 64 : 32);
+        // measured (tools/ab_conv.py): a 64-row tile walks its offsets serially at ~10k cycles per
+        // stage, so the kernel is latency-bound unless >= ~4 workgroups per CU are resident; with
+        // few row tiles use 64-column workgroups (more of them) even though A is gathered twice
+        if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) < 1024) variant += 10000;
+    }
+    if (variant >= 3000) {
+        // 3000 + RB*100 + KC (RB in {4, 8} row blocks per tile; plain 3000 + KC means RB = 4)
+        const bool narrow = variant >= 13000;        // +10000: 64-column tiles even when cout % 128 == 0
+        if (narrow) variant -= 10000;
+        int rb3 = (variant - 3000) / 100, kc3 = (variant - 3000) % 100;
+        if (rb3 == 0) rb3 = 4;
+        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8),
+                   "u2mkd_conv_forward_sorted: bad variant %d", variant);
+        const int nbw = (cout % 128 == 0 && !narrow) ? 2 : 1;
+        dim3 grid3((unsigned)ceil_div(n_out, 16 * rb3), (unsigned)(cout / (64 * nbw)));
+        hipStream_t st3 = as_stream(s);
+#define U2_O3(RB_, NBW_, KC_) launch_conv_os3<RB_, NBW_, KC_>(grid3, k, st3, in, cin, wt, cout, nbr_sorted, order, n_out, kflip, out)
+        if (rb3 == 4) {
+            if (nbw == 1 && kc3 == 32) U2_O3(4, 1, 32); else if (nbw == 1) U2_O3(4, 1, 64);
+            else if (kc3 == 32) U2_O3(4, 2, 32); else U2_O3(4, 2, 64);
+        } else {
+            if (nbw == 1 && kc3 == 32) U2_O3(8, 1, 32); else if (nbw == 1) U2_O3(8, 1, 64);
+            else if (kc3 == 32) U2_O3(8, 2, 32); else U2_O3(8, 2, 64);
+        }
+#undef U2_O3
+        return check_launch("u2mkd_conv_forward_sorted");
+    }
     int waves, kc;
     if (variant == 0) {
         kc = cin % 64 == 0 ? 64 : 32;   // measured: ab_conv.py (64/128/256/384 -> 64; 32/96 -> 32)
@@ -618,9 +843,15 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     const int tiles_a = (ca + 32 * wm - 1) / (32 * wm), tiles_b = (cb + 32 * wn - 1) / (32 * wn);
     dim3 grid(g, tiles_a * tiles_b);
     float *slabs = reinterpret_cast<float *>(workspace);
-#define U2_WP(WM_, WN_)                                                                                             \
+    // pairs staged per step: fewer pairs = less LDS = more resident workgroups per CU to hide the
+    // gather latency.  Measured (tools/ab_conv.py, U2MKD_WGRAD_CP sweep): 128-wide tiles 16 > 32 > 64
+    // (256x256 at stride 8: 197 / 228 / 333 us), 32/64-wide tiles best at 32.
+    int cp = (wm == 4 || wn == 4) ? 16 : 32;
+    if (const char *e = getenv("U2MKD_WGRAD_CP")) cp = atoi(e);
+    U2_REQUIRE(cp == 16 || cp == 32 || cp == 64, "u2mkd_conv_wgrad_pairs: U2MKD_WGRAD_CP must be 16, 32 or 64");
+#define U2_WPC(WM_, WN_, CPV)                                                                                       \
     do {                                                                                                            \
-        constexpr int CP_ = 64;                                                                                     \
+        constexpr int CP_ = CPV;                                                                                    \
         constexpr int TA_ = 32 * WM_, TB_ = 32 * WN_;                                                               \
         constexpr int SA_ = TA_ + 16 - (TA_ % 32 == 16 ? 16 : 0), SB_ = TB_ + 16 - (TB_ % 32 == 16 ? 16 : 0);       \
         size_t lds = (size_t)2 * CP_ * (SA_ + SB_) * 4;                                                             \
@@ -629,6 +860,12 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
         hipLaunchKernelGGL((conv_wgrad_pairs_kernel<WM_, WN_, CP_>), grid, dim3(256), lds, st, a, ca, b, cb, pairs, \
                            plan, k, swap, tiles_b, slabs);                                                          \
+    } while (0)
+#define U2_WP(WM_, WN_)                                                     \
+    do {                                                                    \
+        if (cp == 16) U2_WPC(WM_, WN_, 16);                                 \
+        else if (cp == 32) U2_WPC(WM_, WN_, 32);                            \
+        else U2_WPC(WM_, WN_, 64);                                          \
     } while (0)
     if (wm == 1 && wn == 1) U2_WP(1, 1);
     else if (wm == 1 && wn == 2) U2_WP(1, 2);
@@ -640,6 +877,7 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     else if (wm == 4 && wn == 2) U2_WP(4, 2);
     else U2_WP(4, 4);
 #undef U2_WP
+#undef U2_WPC
     int64_t tile_elems = (int64_t)ca * cb;
     hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 64), k), dim3(256), 0, st,
                        slabs, plan, k, tile_elems, dw);
