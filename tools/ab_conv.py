@@ -35,7 +35,7 @@ def main():
         t1 = ev(lambda: L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), n, 27, 0, L.ptr(o1), st))
         t1s = ev(lambda: L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), n, 27, 0, L.ptr(o2), st))
         res = [f'ts={ts} N={n} P={p} {cin}->{cout}: v1 {t1*1e3:.0f}us v1-sorted {t1s*1e3:.0f}us']
-        for var in (464, 0):
+        for var in (464, 3064, 13064):
             if var % 100 == 64 and cin < 64: continue
             if var >= 3000 and cout % 64: continue
             t3 = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), n, 27, 0, var, L.ptr(o3), st))

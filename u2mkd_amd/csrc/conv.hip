@@ -760,7 +760,7 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
     const int c16 = (cout + 15) / 16;
     const int nb = pick_nb(c16);
     // variant: 0 = heuristic; 3000 + kc = column-split kernel (conv_os3); otherwise waves * 100 + kc
-    if (variant == 0 && cout % 64 == 0 && cin >= 16) {
+    if (variant == 0 && cout % 128 == 0 && cin >= 16) {   // (cout == 64: conv_os2 is ~8 % faster, ab_conv.py)
         variant = 3000 + (cin % 64 == 0 ? 64 : 32);
         // measured (tools/ab_conv.py): a 64-row tile walks its offsets serially at ~10k cycles per
         // stage, so the kernel is latency-bound unless >= ~4 workgroups per CU are resident; with
