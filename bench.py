@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--image-hw', type=int, nargs=2, default=[360, 640])
     ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-voxels', type=int, default=20000)
+    ap.add_argument('--cpu-sample-voxels', type=int, default=80000)
     return ap.parse_args()
 
 
@@ -117,9 +117,19 @@ def roofline_leg(coords_dev, iters=50):
     total_b, total_t = b_f + b_d + b_w, t_f + t_d + t_w
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
     flops = 6.0 * p * cin * cout
+    # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
+    # only quoted when it was taken on the same map (same N and P)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
+            tj = json.load(f)
+        if tj['N'] == n and tj['P'] == p:
+            traffic = round(tj['group_fwd_dgrad_wgrad'])
+    except Exception:
+        pass
     return {
         'bound': 'hbm', 'achieved': round(gbs(total_b, total_t), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gbs(total_b, total_t) / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(gbs(total_b, total_t) / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_os2_kernel x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
         'ms': {'fwd': round(t_f, 4), 'dgrad': round(t_d, 4), 'wgrad': round(t_w, 4), 'total': round(total_t, 4)},
