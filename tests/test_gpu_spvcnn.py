@@ -60,3 +60,38 @@ def test_spvcnn_logits_and_grads(hip, n_vox, batch, cr):
             rels.append(rel)
             assert rel < 2e-2, f'{name}: L2-relative grad err {rel}'
     assert float(np.median(rels)) < 5e-3
+
+
+def test_ddp_syncbn_path_on_gpu_single_rank(hip):
+    """The N>1 code path (NCCL process group, SyncBatchNorm conversion, DDP wrap, bucketed all-reduce
+    hooks) executed with world_size 1 on the GPU: the HIP autograd ops must work under DDP."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from u2mkd_amd import distributed as D, lidar, train as T
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        b = synth_batch(2500, 2, 5)
+        feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+        model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+        sync = lidar.SparseSyncBatchNorm.convert_sync_batchnorm(model)
+        assert any(isinstance(m, lidar.SparseSyncBatchNorm) for m in sync.modules())
+        net = torch.nn.parallel.DistributedDataParallel(sync, device_ids=[0], gradient_as_bucket_view=True)
+        opt = T.make_optimizer(net.parameters())
+        from u2mkd_amd import torchsparse as ts
+        from u2mkd_amd.losses import MixLovaszCrossEntropy
+        crit = MixLovaszCrossEntropy(ignore_index=0)
+        losses = []
+        for _ in range(3):
+            out = net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+            loss = crit(out, labels)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 1.0
+        assert D.max_over_ranks(1.5) == 1.5
+    finally:
+        dist.destroy_process_group()
