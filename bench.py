@@ -212,7 +212,6 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     from u2mkd_amd import distributed as D
     rank, world, local_rank = D.init_from_env('nccl')
-    torch.backends.cudnn.benchmark = True     # as the reference (train_lc_nusc_tsd_full.py:40): MIOpen picks its fastest conv
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from u2mkd_amd import lidar, torchsparse as ts
