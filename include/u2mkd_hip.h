@@ -70,6 +70,20 @@ int u2mkd_kmap_sizes(const int32_t *nbr, int64_t n_out, int32_t k, int32_t *nbsi
 int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32_t *nbsizes /*[k]*/,
                        int32_t *block_counts /*[k, ceil(n_out/1024)] from u2mkd_kmap_sizes (scanned in place)*/,
                        int32_t *nbmaps /*[P,2]*/, u2mkd_stream_t s);
+
+/* The PAIR SCHEDULE of a map (what torchsparse keeps as nbmaps/nbsizes, laid out for dense
+ * MFMA tiles): all (input i, output j) pairs grouped by offset, every offset's group padded
+ * with -1 to a multiple of 64 entries so that a 64-entry tile belongs to ONE offset.
+ *   pair_in / pair_out [u2mkd_pairs_capacity]  rows of the pair in slot p (or -1)
+ *   pos_out [n_out, k]   slot of the pair (k, j), -1 if none       (written completely)
+ *   pos_in  [n_in,  k]   slot of the pair (k, i), -1 if none       (caller pre-fills -1)
+ *   tile_k  [capacity / 64]  offset of tile t;  meta[0] = padded pair count, meta[1] = tiles
+ * nbsizes / block_counts come from u2mkd_kmap_sizes (block_counts is overwritten).  Entirely
+ * device-side: the host never learns the pair count (buffers are sized by the capacity).   */
+int64_t u2mkd_pairs_capacity(int64_t n_in, int64_t n_out, int32_t k);
+int u2mkd_pairs_build(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int64_t n_in, int32_t k,
+                      const int32_t *nbsizes, int32_t *block_counts, int32_t *pair_in, int32_t *pair_out,
+                      int32_t *pos_out, int32_t *pos_in, int32_t *tile_k, int32_t *meta, u2mkd_stream_t s);
 /* downsample keys: pack floor(xyz / s) * s and b into an order-preserving
  * int64 ((b,x,y,z) lexicographic, as torch.unique(dim=0) sorts) and back.
  * replaces the arithmetic of F.spdownsample (Appendix A-4).                 */
@@ -101,6 +115,27 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
                               const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
                               int64_t n_out, int32_t k, int32_t kflip, int32_t variant,
                               float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* The same kernel on sorted rows [row_begin, row_end) of a table whose rows are ld entries
+ * long (the other rows of `out` are left untouched).  Together with the two entries below
+ * this allows mixed schedules: some sorted rows through the output-stationary tiles, the
+ * others (e.g. rows of rare neighbour masks, which make a 64-row tile walk up to 27 offsets
+ * serially) through the pair schedule.                                                     */
+int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                            const int32_t *nbr_sorted /*[k,ld]*/, int64_t ld, const int32_t *order /*[ld] or NULL*/,
+                            int64_t row_begin, int64_t row_end, int32_t k, int32_t kflip, int32_t variant,
+                            float *out, u2mkd_stream_t s);
+/* y[p] = in[pair_idx[p]] * B_{tile_k[p / 64]} over the pair schedule of u2mkd_pairs_build
+ * (pair_idx = pair_in for a normal conv, pair_out for a transposed conv / the input gradient):
+ * one dense MFMA stage per 64-pair tile, no serial walk over offsets.  meta (device) holds
+ * the tile count; a fixed grid strides over the tiles, so nothing is read back by the host.
+ * y must hold `capacity` rows (only the first meta[0] are written; padding entries give 0).  */
+int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                             const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                             int32_t k, int32_t kflip, int32_t variant, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
+/* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
+ * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
+int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,
+                           float *out /*[n_rows,cout]*/, u2mkd_stream_t s);
 /* neighbour mask of every output row: bit k set iff nbr[k][j] >= 0 (k <= 32). */
 int u2mkd_kmap_rowmask(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t *mask /*[n_out]*/,
                        u2mkd_stream_t s);

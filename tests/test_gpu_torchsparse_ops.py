@@ -188,6 +188,83 @@ def test_strided_and_transposed_conv(F, cin, cout):
     assert _rel(xd.grad, wgi) < 1e-4 and _rel(wd.grad, wgw) < 1e-4
 
 
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (96, 128), (20, 12)])
+@pytest.mark.parametrize('kind', ['subm', 'down', 'up'])
+def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
+    """The tile schedule and the pair schedule (+ gather-sum) compute the same contraction; both are
+    checked against the oracle: forward, transposed and the input gradient."""
+    from u2mkd_amd import _lib as L
+    coords, _ = _scene(2500, 2)
+    torch.manual_seed(11)
+    ks, st_ = (3, 1) if kind == 'subm' else (2, 2)
+    nbmaps, nbsizes, oc, _ = R.build_kmap(coords, 1, ks, st_)
+    km = F.build_kmap(_dev(coords), (1,) * 3, (ks,) * 3, (st_,) * 3)
+    sizes = (len(coords), len(oc))
+    transposed = kind == 'up'
+    n_in, n_out = (sizes[1], sizes[0]) if transposed else sizes
+    x = torch.randn(n_in, cin)
+    w = torch.randn(ks ** 3, cin, cout) / (ks ** 3 * cin) ** 0.5
+    want = R.conv_forward(x, w, nbmaps, nbsizes, sizes, transposed=transposed)
+    ts_, ps = km.schedule(transposed), km.pair_schedule()
+    wt = F._transpose_weights(w.cuda())
+    o_t = torch.full((n_out, cout), float('nan'), device='cuda')
+    o_p = torch.full((n_out, cout), float('nan'), device='cuda')
+    ts_.run(x.cuda(), wt, cout, 0, o_t)
+    ps.run(x.cuda(), wt, cout, transposed, o_p)
+    assert _rel(o_t, want) < 1e-4 and _rel(o_p, want) < 1e-4
+    assert float((o_t - o_p).abs().max()) < 1e-4
+    # input gradient through both schedules
+    g = torch.randn(n_out, cout)
+    wgi, _ = R.conv_backward(x, w, g, nbmaps, nbsizes, transposed=transposed)
+    gi_p = torch.empty(n_in, cin, device='cuda')
+    ps.run(g.cuda(), w.cuda().contiguous(), cin, not transposed, gi_p)
+    assert _rel(gi_p, wgi) < 1e-4
+    gi_t = torch.empty(n_in, cin, device='cuda')
+    if kind == 'subm':
+        ts_.run(g.cuda(), w.cuda().contiguous(), cin, 1, gi_t)          # mirrored offsets on the same table
+    else:
+        km.schedule(not transposed).run(g.cuda(), w.cuda().contiguous(), cin, 0, gi_t)
+    assert _rel(gi_t, wgi) < 1e-4
+    # row-range entry: two launches over [0, m) and [m, n) write exactly the rows of one launch
+    nbr_s, order = ts_.tiles()
+    m = n_out // 3
+    a = torch.empty(n_out, cout, device='cuda')
+    for lo, hi in ((0, m), (m, n_out)):
+        L.call('u2mkd_conv_forward_rows', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), n_out,
+               L.ptr(order), lo, hi, ks ** 3, 0, 0, L.ptr(a), L.stream())
+    assert torch.equal(a, o_t)
+    with pytest.raises(RuntimeError):
+        L.call('u2mkd_conv_forward_rows', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), n_out,
+               L.ptr(order), 0, n_out + 1, ks ** 3, 0, 0, L.ptr(a), L.stream())
+
+
+def test_pair_schedule_is_the_padded_rulebook(F):
+    """u2mkd_pairs_build: the valid slots, in order, are exactly torchsparse's nbmaps (grouped by
+    offset, ascending output); groups are padded to 64; pos_in / pos_out invert the list."""
+    coords, _ = _scene(3000, 2)
+    for ks, st_ in ((3, 1), (2, 2)):
+        nbmaps, nbsizes, oc, res = R.build_kmap(coords, 1, ks, st_)
+        km = F.build_kmap(_dev(coords), (1,) * 3, (ks,) * 3, (st_,) * 3)
+        ps = km.pair_schedule()
+        p_pad, n_tiles = ps.meta.cpu().tolist()
+        pad = (nbsizes + 63) // 64 * 64
+        assert p_pad == int(pad.sum()) and n_tiles == p_pad // 64 and p_pad <= ps.cap
+        pi, po = ps.pair_in.cpu().numpy()[:p_pad], ps.pair_out.cpu().numpy()[:p_pad]
+        assert ((pi >= 0) == (po >= 0)).all()
+        assert (np.stack([pi[pi >= 0], po[po >= 0]], 1) == nbmaps).all()
+        assert (ps.tile_k.cpu().numpy()[:n_tiles] == np.repeat(np.arange(len(pad)), pad // 64)).all()
+        base = np.cumsum(pad) - pad
+        for k in range(len(pad)):
+            seg = slice(base[k], base[k] + pad[k])
+            assert (pi[seg][:nbsizes[k]] >= 0).all() and (pi[seg][nbsizes[k]:] == -1).all()
+        pos_out, pos_in = ps.pos_out.cpu().numpy(), ps.pos_in.cpu().numpy()
+        assert ((pos_out >= 0) == (res.T >= 0)).all()
+        jj, kk = np.nonzero(pos_out >= 0)
+        assert (po[pos_out[jj, kk]] == jj).all() and (pi[pos_out[jj, kk]] == res[kk, jj]).all()
+        ii, kk = np.nonzero(pos_in >= 0)
+        assert len(ii) == len(nbmaps) and (pi[pos_in[ii, kk]] == ii).all()
+
+
 def test_conv_northstar_size_80k_c64(F):
     """BASELINE.json configs[1] micro-shape: 80k voxels, 64->64, k=3, stride 1."""
     b = synth_batch(80000, 1)

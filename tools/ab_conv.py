@@ -35,9 +35,10 @@ def main():
         t1 = ev(lambda: L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), n, 27, 0, L.ptr(o1), st))
         t1s = ev(lambda: L.call('u2mkd_conv_forward', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), n, 27, 0, L.ptr(o2), st))
         res = [f'ts={ts} N={n} P={p} {cin}->{cout}: v1 {t1*1e3:.0f}us v1-sorted {t1s*1e3:.0f}us']
-        for var in (464, 3064, 13064):
+        for var in (464, 0, 54464, 53464, 52464, 51464, 52432, 53432):
             if var % 100 == 64 and cin < 64: continue
-            if var >= 3000 and cout % 64: continue
+            if 3000 <= var < 50000 and cout % 64: continue
+            if var >= 50000 and (var - 50000) // 1000 * 16 > cout: continue
             t3 = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), n, 27, 0, var, L.ptr(o3), st))
             e3 = float((o3 - o1).abs().max())
             tf = 2.0 * p * cin * cout / (t3 * 1e-3) / 1e12

@@ -34,6 +34,11 @@ SIGNATURES = {
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_rows': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_pairs': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
+    'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_kmap_rowmask': (C.c_int, [_p, _i64, _i32, _p, _p]),
     'u2mkd_conv_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'u2mkd_conv_wgrad': (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p, _p]),

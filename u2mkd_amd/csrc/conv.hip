@@ -35,6 +35,17 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
     wt[t] = w[(k * cin + ci) * cout + co];
 }
 
+// Rows a forward launch covers.  Table mode (tile_k == nullptr): sorted rows [begin, end) of the
+// neighbour table nbr[k * ld + row].  Pair mode: "rows" are entries of a pair list nbr[row]
+// (input index or -1), grouped by offset and padded so that the 64 entries of tile t all belong
+// to offset tile_k[t]; the output row of entry p is p.  The tile count lives on the device
+// (*n_tiles): the grid is a fixed number of workgroups that stride over the tiles.
+struct RowRange {
+    int64_t ld, begin, end;
+    const int32_t *tile_k;
+    const int32_t *n_tiles;   // pair mode: device-side tile count; workgroups stride over the tiles
+};
+
 // ---- output-stationary kernel, LDS-staged weights -----------------------------------
 // Workgroup = WAVES waves = 16*WAVES output rows (mask-sorted order) x 16*NB output columns;
 // every wave owns one 16-row MFMA block and all NB column blocks.
@@ -51,7 +62,7 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
 template <int WAVES, int NB, int KC>
 __global__ void __launch_bounds__(64 * WAVES)
 conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
-                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, int64_t n_out, int K, int kflip,
+                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, RowRange rr_, int K, int kflip,
                 float *__restrict__ out) {
     constexpr int NT = 64 * WAVES;
     constexpr int TM = 16 * WAVES, TN = 16 * NB;
@@ -67,8 +78,13 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * TM;
     const int col0 = blockIdx.y * TN;
+    const int64_t ld = rr_.ld;
+    const int ntile = rr_.n_tiles ? *rr_.n_tiles : (int)gridDim.x;
+    const int64_t n_out = rr_.n_tiles ? (int64_t)ntile * TM : rr_.end;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t row0 = rr_.begin + (int64_t)tile * TM;
+    const int kt = rr_.tile_k ? rr_.tile_k[tile] : -1;   // pair mode: the tile's only offset
 
     if (tid == 0) *s_mask = 0u;
     for (int e = tid; e < TM; e += NT) {
@@ -77,12 +93,31 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     }
     __syncthreads();
     unsigned mymask = 0u;
-    for (int e = tid; e < K * TM; e += NT) {
-        int k = e / TM, rr = e - k * TM;
-        int64_t row = row0 + rr;
-        int v = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
-        s_idx[e] = v;
-        if (v >= 0) mymask |= 1u << k;
+    {
+        // all of the tile's neighbour indices in ONE burst of independent loads (K <= 32): a rolled
+        // load -> LDS-store loop serialises ceil(K*TM/NT) global round trips per tile, which was the
+        // dominant fixed cost of the kernel (tools/ab_kscan.py)
+        constexpr int IT = (32 * TM + NT - 1) / NT;
+        int v[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int e = tid + i * NT;
+            int k = e / TM, rr = e - k * TM;
+            int64_t row = row0 + rr;
+            v[i] = -1;
+            if (e < K * TM && row < n_out) {
+                if (kt < 0) v[i] = nbr[(int64_t)k * ld + row];
+                else if (k == kt) v[i] = nbr[row];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            int e = tid + i * NT;
+            if (e < K * TM) {
+                s_idx[e] = v[i];
+                if (v[i] >= 0) mymask |= 1u << (e / TM);
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mymask |= __shfl_xor(mymask, off);
@@ -183,6 +218,8 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 if (col0 + 16 * n + r < cout) out[(size_t)rid * cout + col0 + 16 * n + r] = acc[n][reg];
         }
     }
+    __syncthreads();   // the LDS tables are rebuilt by the next tile
+    }
 }
 
 // ---- output-stationary kernel, both operands through LDS, column-split waves -----------------
@@ -198,7 +235,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 template <int RB, int NBW, int KC>
 __global__ void __launch_bounds__(256)
 conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
-                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, int64_t n_out, int K, int kflip,
+                const int32_t *__restrict__ nbr, const int32_t *__restrict__ order, RowRange rr_, int K, int kflip,
                 float *__restrict__ out) {
     constexpr int TM = 16 * RB, TN = 64 * NBW;   // RB 16-row blocks per workgroup tile
     constexpr int S = KC + 8;                 // LDS row stride (floats)
@@ -215,7 +252,7 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int64_t row0 = rr_.begin + (int64_t)blockIdx.x * TM, n_out = rr_.end, ld = rr_.ld;
     const int col0 = blockIdx.y * TN;
 
     for (int e = tid; e < TM; e += 256) {
@@ -224,11 +261,22 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     }
     // neighbour indices of the tile + per-offset active-row-block bits.  A wave covers 64 consecutive
     // rows of ONE offset, so a ballot gives the block bits with no LDS atomics.
-    for (int e0 = wave * 64; e0 < K * TM; e0 += 256) {
-        int e = e0 + lane;
-        int k = e0 / TM, rr = e - k * TM;            // e0 is a multiple of 64 and TM is 64 or 128
+    constexpr int IT = 32 * TM / 256;                // K <= 32
+    int vv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {                   // one burst of independent loads (see conv_os2)
+        int e = wave * 64 + i * 256 + lane;
+        int k = e / TM, rr = e - k * TM;
         int64_t row = row0 + rr;
-        int v = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+        vv[i] = (e < K * TM && row < n_out) ? nbr[(int64_t)k * ld + row] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        int e0 = wave * 64 + i * 256;
+        if (e0 >= K * TM) break;
+        int e = e0 + lane;
+        int k = e0 / TM;                             // e0 is a multiple of 64 and TM is 64 or 128
+        int v = vv[i];
         s_idx[e] = v;
         unsigned long long bal = __ballot(v >= 0);
         if (lane == 0) {
@@ -370,7 +418,7 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 
 template <int RB, int NBW, int KC>
 static void launch_conv_os3(dim3 grid, int K, hipStream_t st, const float *in, int cin, const float *wt, int cout,
-                            const int32_t *nbr, const int32_t *order, int64_t n_out, int kflip, float *out) {
+                            const int32_t *nbr, const int32_t *order, RowRange n_out, int kflip, float *out) {
     size_t lds = (size_t)(16 * RB + 64 * NBW) * (KC + 8) * 4 + (size_t)K * 16 * RB * 4 + 16 * RB * 4 + (size_t)K * 4 + 16;
     if (lds > 65536)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_os3_kernel<RB, NBW, KC>),
@@ -697,9 +745,34 @@ static WgradPlan wgrad_plan(int64_t n_rows, int ca, int cb, int K, int centre_de
     return p;
 }
 
+// out[j] = sum over offsets (ascending) of y[pos[j][k]] (pos < 0: no pair); one float4 per
+// thread, a row's K slots are read first (contiguous), then all of its y rows are in flight.
+__global__ void __launch_bounds__(256)
+pairs_gather_sum_kernel(const float *__restrict__ y, const int32_t *__restrict__ pos, int64_t n_rows, int K, int c4,
+                        float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rows * c4) return;
+    int64_t r = t / c4;
+    int c = (int)(t - r * c4);
+    const int32_t *pr = pos + r * K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int p[8];
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = k0 + i < K ? pr[k0 + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = p[i] >= 0 ? reinterpret_cast<const float4 *>(y)[(int64_t)p[i] * c4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    reinterpret_cast<float4 *>(out)[r * c4 + c] = acc;
+}
+
 template <int WAVES, int KC>
 static int launch_conv_os2(int nb, dim3 grid, int K, hipStream_t st, const float *in, int cin, const float *wt,
-                           int cout, const int32_t *nbr, const int32_t *order, int64_t n_out, int kflip, float *out) {
+                           int cout, const int32_t *nbr, const int32_t *order, RowRange n_out, int kflip, float *out) {
     const int tm = 16 * WAVES, tn = 16 * nb;
     size_t lds = (size_t)2 * tn * (KC + 8) * 4 + (size_t)K * tm * 4 + (size_t)tm * 4 + 16;
 #define U2_CASE(N)                                                                                                 \
@@ -740,32 +813,32 @@ int u2mkd_transpose_weights(const float *w, int32_t k, int32_t cin, int32_t cout
     return check_launch("u2mkd_transpose_weights");
 }
 
-int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
-                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
-                               int32_t variant, float *out, u2mkd_stream_t s);
-
-int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
-                       int64_t n_out, int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
-    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, n_out, k, kflip, 0, out, s);
-}
-
-int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
-                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
-                               int32_t variant, float *out, u2mkd_stream_t s) {
-    if (n_out == 0) return 0;
-    U2_REQUIRE(in && wt && nbr_sorted && out, "u2mkd_conv_forward_sorted: null pointer");
-    U2_REQUIRE(cin > 0 && cin % 4 == 0, "u2mkd_conv_forward_sorted: cin=%d must be a positive multiple of 4", cin);
-    U2_REQUIRE(cout > 0, "u2mkd_conv_forward_sorted: cout=%d must be positive", cout);
-    U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "u2mkd_conv_forward_sorted: kernel volume %d not in 1..32", k);
+static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int32_t cin, const float *wt,
+                             int32_t cout, const int32_t *nbr, const int32_t *order, RowRange rr, int32_t k,
+                             int32_t kflip, int32_t variant, float *out, u2mkd_stream_t s) {
+    const int64_t n_rows = rr.end - rr.begin;
+    if (n_rows <= 0) return 0;
+    U2_REQUIRE(in && wt && nbr && out, "%s: null pointer", who);
+    U2_REQUIRE(cin > 0 && cin % 4 == 0, "%s: cin=%d must be a positive multiple of 4", who, cin);
+    U2_REQUIRE(cout > 0, "%s: cout=%d must be positive", who, cout);
+    U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "%s: kernel volume %d not in 1..32", who, k);
+    const bool pair_mode = rr.tile_k != nullptr;
+    U2_REQUIRE(!pair_mode || (rr.begin == 0 && rr.end % 64 == 0 && rr.n_tiles), "%s: a pair list is padded to 64 entries per offset", who);
     const int c16 = (cout + 15) / 16;
-    const int nb = pick_nb(c16);
+    int nb = pick_nb(c16);
+    if (variant >= 50000) {   // 50000 + nb * 1000 + waves * 100 + kc: conv_os2 with nb 16-column blocks per workgroup
+        nb = (variant - 50000) / 1000;
+        variant = (variant - 50000) % 1000;
+        U2_REQUIRE(nb >= 1 && nb <= 8, "%s: bad column block count %d", who, nb);
+    }
+    if (variant == 0 && pair_mode) variant = 432;   // measured best for every layer shape (tools/ab_hybrid.py)
     // variant: 0 = heuristic; 3000 + kc = column-split kernel (conv_os3); otherwise waves * 100 + kc
     if (variant == 0 && cout % 128 == 0 && cin >= 16) {   // (cout == 64: conv_os2 is ~8 % faster, ab_conv.py)
         variant = 3000 + (cin % 64 == 0 ? 64 : 32);
         // measured (tools/ab_conv.py): a 64-row tile walks its offsets serially at ~10k cycles per
         // stage, so the kernel is latency-bound unless >= ~4 workgroups per CU are resident; with
         // few row tiles use 64-column workgroups (more of them) even though A is gathered twice
-        if (cout % 128 == 0 && ceil_div(n_out, 64) * (cout / 128) < 1024) variant += 10000;
+        if (cout % 128 == 0 && ceil_div(n_rows, 64) * (cout / 128) < 1024) variant += 10000;
     }
     if (variant >= 3000) {
         // 3000 + RB*100 + KC (RB in {4, 8} row blocks per tile; plain 3000 + KC means RB = 4)
@@ -773,12 +846,12 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
         if (narrow) variant -= 10000;
         int rb3 = (variant - 3000) / 100, kc3 = (variant - 3000) % 100;
         if (rb3 == 0) rb3 = 4;
-        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8),
-                   "u2mkd_conv_forward_sorted: bad variant %d", variant);
+        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8) && !pair_mode,
+                   "%s: bad variant %d", who, variant);
         const int nbw = (cout % 128 == 0 && !narrow) ? 2 : 1;
-        dim3 grid3((unsigned)ceil_div(n_out, 16 * rb3), (unsigned)(cout / (64 * nbw)));
+        dim3 grid3((unsigned)ceil_div(n_rows, 16 * rb3), (unsigned)(cout / (64 * nbw)));
         hipStream_t st3 = as_stream(s);
-#define U2_O3(RB_, NBW_, KC_) launch_conv_os3<RB_, NBW_, KC_>(grid3, k, st3, in, cin, wt, cout, nbr_sorted, order, n_out, kflip, out)
+#define U2_O3(RB_, NBW_, KC_) launch_conv_os3<RB_, NBW_, KC_>(grid3, k, st3, in, cin, wt, cout, nbr, order, rr, kflip, out)
         if (rb3 == 4) {
             if (nbw == 1 && kc3 == 32) U2_O3(4, 1, 32); else if (nbw == 1) U2_O3(4, 1, 64);
             else if (kc3 == 32) U2_O3(4, 2, 32); else U2_O3(4, 2, 64);
@@ -787,7 +860,7 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
             else if (kc3 == 32) U2_O3(8, 2, 32); else U2_O3(8, 2, 64);
         }
 #undef U2_O3
-        return check_launch("u2mkd_conv_forward_sorted");
+        return check_launch(who);
     }
     int waves, kc;
     if (variant == 0) {
@@ -797,12 +870,14 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
         waves = variant / 100;
         kc = variant % 100;
     }
-    U2_REQUIRE((waves == 4 || waves == 8 || waves == 16) && (kc == 32 || kc == 64),
-               "u2mkd_conv_forward_sorted: bad variant %d", variant);
-    dim3 grid((unsigned)ceil_div(n_out, 16 * waves), (unsigned)ceil_div(c16, nb));
+    U2_REQUIRE((waves == 4 || ((waves == 8 || waves == 16) && !pair_mode)) && (kc == 32 || kc == 64),
+               "%s: bad variant %d", who, variant);
+    int64_t gx = ceil_div(n_rows, 16 * waves);
+    if (pair_mode && gx > 2048) gx = 2048;   // 8 workgroups per CU stride over the device-side tile count
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(c16, nb));
     hipStream_t st = as_stream(s);
     int rc;
-#define U2_V(W, KCV) rc = launch_conv_os2<W, KCV>(nb, grid, k, st, in, cin, wt, cout, nbr_sorted, order, n_out, kflip, out)
+#define U2_V(W, KCV) rc = launch_conv_os2<W, KCV>(nb, grid, k, st, in, cin, wt, cout, nbr, order, rr, kflip, out)
     if (waves == 4 && kc == 32) U2_V(4, 32);
     else if (waves == 4) U2_V(4, 64);
     else if (waves == 8 && kc == 32) U2_V(8, 32);
@@ -811,7 +886,49 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
     else U2_V(16, 64);
 #undef U2_V
     if (rc) return rc;
-    return check_launch("u2mkd_conv_forward_sorted");
+    return check_launch(who);
+}
+
+int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
+                               int32_t variant, float *out, u2mkd_stream_t s) {
+    return conv_forward_impl("u2mkd_conv_forward_sorted", in, n_in, cin, wt, cout, nbr_sorted, order,
+                             RowRange{n_out, 0, n_out, nullptr, nullptr}, k, kflip, variant, out, s);
+}
+
+int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
+                       int64_t n_out, int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
+    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, n_out, k, kflip, 0, out, s);
+}
+
+int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                             const int32_t *nbr_sorted, int64_t ld, const int32_t *order, int64_t row_begin,
+                             int64_t row_end, int32_t k, int32_t kflip, int32_t variant, float *out, u2mkd_stream_t s) {
+    U2_REQUIRE(row_begin >= 0 && row_end <= ld, "u2mkd_conv_forward_rows: rows [%lld, %lld) outside the table of %lld",
+               (long long)row_begin, (long long)row_end, (long long)ld);
+    return conv_forward_impl("u2mkd_conv_forward_rows", in, n_in, cin, wt, cout, nbr_sorted, order,
+                             RowRange{ld, row_begin, row_end, nullptr, nullptr}, k, kflip, variant, out, s);
+}
+
+int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                              const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                              int32_t k, int32_t kflip, int32_t variant, float *y, u2mkd_stream_t s) {
+    if (capacity == 0) return 0;
+    U2_REQUIRE(tile_k && meta, "u2mkd_conv_forward_pairs: null pointer");
+    return conv_forward_impl("u2mkd_conv_forward_pairs", in, n_in, cin, wt, cout, pair_idx, nullptr,
+                             RowRange{capacity, 0, capacity, tile_k, meta + 1}, k, kflip, variant, y, s);
+}
+
+int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,
+                            u2mkd_stream_t s) {
+    if (n_rows == 0) return 0;
+    U2_REQUIRE(y && pos && out, "u2mkd_pairs_gather_sum: null pointer");
+    U2_REQUIRE(cout > 0 && cout % 4 == 0 && k > 0, "u2mkd_pairs_gather_sum: cout=%d must be a positive multiple of 4", cout);
+    const int c4 = cout / 4;
+    const int64_t total = n_rows * c4;
+    hipLaunchKernelGGL(pairs_gather_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), y, pos,
+                       n_rows, k, c4, out);
+    return check_launch("u2mkd_pairs_gather_sum");
 }
 
 int32_t u2mkd_wgrad_plan_ints(int32_t k) { return 4 + 2 * k; }

@@ -155,6 +155,62 @@ kmap_compact_kernel(const int32_t *__restrict__ nbr, int64_t n_out, const int32_
     }
 }
 
+
+// ---- pair schedule: offset-grouped, 64-padded pair list + slot tables ------------------
+// One block: kbase[k] = padded prefix (each offset's pair count rounded up to 64), block bases
+// in (k, block) order, tile_k for every 64-entry tile, -1 into the padding entries, and
+// meta = {P_pad, n_tiles}.  Nothing of this is read back by the host.
+__global__ void pairs_scan_kernel(const int32_t *__restrict__ nbsizes, int32_t *__restrict__ block_counts, int k_total,
+                                  int nblocks, int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out,
+                                  int32_t *__restrict__ tile_k, int32_t *__restrict__ meta) {
+    __shared__ int kbase[257];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < k_total; ++k) { kbase[k] = acc; acc += (nbsizes[k] + 63) / 64 * 64; }
+        kbase[k_total] = acc;
+        meta[0] = acc;
+        meta[1] = acc / 64;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < k_total; k += blockDim.x) {
+        int acc = kbase[k];
+        int32_t *row = block_counts + (int64_t)k * nblocks;
+        for (int b = 0; b < nblocks; ++b) { int c = row[b]; row[b] = acc; acc += c; }
+    }
+    for (int k = 0; k < k_total; ++k) {
+        for (int t = kbase[k] / 64 + threadIdx.x; t < kbase[k + 1] / 64; t += blockDim.x) tile_k[t] = k;
+        for (int p = kbase[k] + nbsizes[k] + threadIdx.x; p < kbase[k + 1]; p += blockDim.x) {
+            pair_in[p] = -1;
+            pair_out[p] = -1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kCompactBlock)
+pairs_build_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int K, const int32_t *__restrict__ block_base,
+                   int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, int32_t *__restrict__ pos_out,
+                   int32_t *__restrict__ pos_in) {
+    __shared__ int wave_cnt[kCompactBlock / kWave];
+    int k = blockIdx.y;
+    int64_t j = (int64_t)blockIdx.x * kCompactBlock + threadIdx.x;
+    int i = (j < n_out) ? nbr[(int64_t)k * n_out + j] : -1;
+    bool valid = i >= 0;
+    unsigned long long m = __ballot(valid);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int p = -1;
+    if (valid) {
+        int base = block_base[(int64_t)k * gridDim.x + blockIdx.x];
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+        p = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        pair_in[p] = i;
+        pair_out[p] = (int)j;
+        pos_in[(int64_t)i * K + k] = p;
+    }
+    if (j < n_out) pos_out[j * K + k] = p;
+}
+
 // ---- downsample keys: order-preserving (b,x,y,z) pack -----------------------
 // b: 10 bits, x/y/z: 18 bits each with bias 2^17 (|coord| < 131072).
 __global__ void downsample_keys_kernel(const int4 *__restrict__ coords, int64_t n, int sx, int sy, int sz,
@@ -285,6 +341,30 @@ int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32
     hipLaunchKernelGGL(kmap_compact_kernel, dim3(nblocks, k), dim3(kCompactBlock), 0, as_stream(s), nbr, n_out,
                        block_counts, nbmaps);
     return check_launch("u2mkd_kmap_compact");
+}
+
+int64_t u2mkd_pairs_capacity(int64_t n_in, int64_t n_out, int32_t k) {
+    int64_t m = n_in < n_out ? n_in : n_out;
+    return ((int64_t)k * m + 63) / 64 * 64 + 64 * (int64_t)k;
+}
+
+int u2mkd_pairs_build(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, const int32_t *nbsizes,
+                      int32_t *block_counts, int32_t *pair_in, int32_t *pair_out, int32_t *pos_out, int32_t *pos_in,
+                      int32_t *tile_k, int32_t *meta, u2mkd_stream_t s) {
+    U2_REQUIRE(meta, "u2mkd_pairs_build: null pointer");
+    if (n_out == 0 || k == 0) {
+        (void)hipMemsetAsync(meta, 0, 2 * sizeof(int32_t), as_stream(s));
+        return 0;
+    }
+    U2_REQUIRE(nbr && nbsizes && block_counts && pair_in && pair_out && pos_out && pos_in && tile_k,
+               "u2mkd_pairs_build: null pointer");
+    U2_REQUIRE(k <= 256 && n_in > 0, "u2mkd_pairs_build: k=%d > 256 or no input rows", k);
+    int nblocks = (int)ceil_div(n_out, kCompactBlock);
+    hipLaunchKernelGGL(pairs_scan_kernel, dim3(1), dim3(256), 0, as_stream(s), nbsizes, block_counts, k, nblocks, pair_in,
+                       pair_out, tile_k, meta);
+    hipLaunchKernelGGL(pairs_build_kernel, dim3(nblocks, k), dim3(kCompactBlock), 0, as_stream(s), nbr, n_out, k,
+                       block_counts, pair_in, pair_out, pos_out, pos_in);
+    return check_launch("u2mkd_pairs_build");
 }
 
 int u2mkd_downsample_keys(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,

@@ -13,6 +13,8 @@ GPU only: CPU tensors raise (there is no fallback path).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -236,6 +238,112 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
 
 
 # -------------------------------------------------------------- kernel maps
+def _pairs_mode(cin, cout):
+    """Schedule choice, measured on MI355X over the SPVCNN layer shapes (tools/ab_hybrid.py):
+    the pair schedule wins from 96x96 channels up (2x at 256x256), the tile schedule below
+    (the pair schedule's extra round trip of P x cout floats costs more than it saves)."""
+    env = os.environ.get('U2MKD_CONV_SCHEDULE')
+    if env in ('tiles', 'pairs'):
+        return env == 'pairs'
+    return cin * cout >= 8192 and cout % 4 == 0
+
+
+_SCRATCH = {}
+
+
+def _scratch(nbytes, device):
+    """Grow-only per-device scratch (the pair schedule's y rows).  It is produced and consumed by
+    two launches that follow each other on one stream, so one buffer serves every layer."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+class TileSchedule:
+    """Output-stationary walk of a neighbour table [K, N]: 64-row tiles of the table in SORTED
+    row order, each tile visits the union of its rows' offsets serially.  Rows are sorted by
+    (number of rows sharing their 27-bit neighbour mask, mask): tiles of one mask skip empty
+    (block, offset) slots, and the tiles of rare masks -- which walk up to 27 offsets with ~2
+    useful rows each and are the kernel's critical path (in-kernel timestamps, DESIGN.md
+    section 6) -- start first.  Built without host synchronisation.
+        nbr_s int32 [K, N], order int32 [N] (original row of sorted row)"""
+
+    def __init__(self, tbl):
+        self.k, self.n = tbl.shape
+        k, n = tbl.shape
+        mask = torch.empty(n, dtype=torch.int32, device=tbl.device)
+        if n:
+            L.call('u2mkd_kmap_rowmask', L.ptr(tbl), n, k, L.ptr(mask), L.stream())
+        m64 = mask.long()
+        srt, _ = torch.sort(m64)
+        share = torch.searchsorted(srt, m64, right=True) - torch.searchsorted(srt, m64, right=False)
+        order = torch.argsort((share << 32) | m64, stable=True)
+        self.nbr_s = tbl.index_select(1, order).contiguous()
+        self.order = order.int()
+
+    def tiles(self):
+        return self.nbr_s, self.order
+
+    def run(self, feats, wt, cout, kflip, out, variant=0):
+        """out[j] = sum_k feats[tbl[k][j]] @ B_k,  B_k = wt[kflip ? K-1-k : k] as [cout][cin]."""
+        n_in, cin = feats.shape
+        L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(self.nbr_s),
+               L.ptr(self.order), self.n, self.k, int(kflip), variant, L.ptr(out), L.stream())
+        return out
+
+
+class PairSchedule:
+    """Offset-grouped pair list of a kernel map (u2mkd_pairs_build): every (input i, output j)
+    pair, grouped by offset and padded to 64 entries per offset.  A conv is two launches: one
+    dense MFMA stage per 64-pair tile into a scratch y (all tiles independent -- no serial
+    walk), then a gather-sum over each row's <= K slots in ascending offset order
+    (deterministic, no atomics).  One schedule serves the forward (gather inputs, sum per
+    output), the transposed conv and the input gradient (gather outputs, sum per input).
+    Everything is sized by the capacity K * min(n_in, n_out); the host never reads the
+    pair count."""
+
+    def __init__(self, nbr, n_in):
+        k, n_out = nbr.shape
+        dev = nbr.device
+        lib = L.load()
+        self.k, self.n_in, self.n_out = k, n_in, n_out
+        self.cap = int(lib.u2mkd_pairs_capacity(n_in, n_out, k))
+        nblocks = max((n_out + 1023) // 1024, 1)
+        nbsizes = torch.zeros(k, dtype=torch.int32, device=dev)
+        block_counts = torch.empty(k, nblocks, dtype=torch.int32, device=dev)
+        self.pair_in = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.pair_out = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.pos_out = torch.empty(n_out, k, dtype=torch.int32, device=dev)
+        self.pos_in = torch.full((n_in, k), -1, dtype=torch.int32, device=dev)
+        self.tile_k = torch.empty(self.cap // 64, dtype=torch.int32, device=dev)
+        self.meta = torch.zeros(2, dtype=torch.int32, device=dev)
+        if n_out and n_in:
+            st = L.stream()
+            L.call('u2mkd_kmap_sizes', L.ptr(nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts), st)
+            L.call('u2mkd_pairs_build', L.ptr(nbr), n_out, n_in, k, L.ptr(nbsizes), L.ptr(block_counts),
+                   L.ptr(self.pair_in), L.ptr(self.pair_out), L.ptr(self.pos_out), L.ptr(self.pos_in),
+                   L.ptr(self.tile_k), L.ptr(self.meta), st)
+        self.nbsizes = nbsizes
+
+    def run(self, feats, wt, cout, swap, out, variant=0):
+        """swap = False: out[j] = sum_k feats[in_k(j)] @ B_k  (rows of out = the map's outputs)
+        swap = True:  out[i] = sum_k feats[out_k(i)] @ B_k (rows of out = the map's inputs);
+        B_k = wt[k] as [cout][cin]."""
+        n, cin = feats.shape
+        st = L.stream()
+        idx, pos, n_rows = (self.pair_out, self.pos_in, self.n_in) if swap else (self.pair_in, self.pos_out, self.n_out)
+        if n_rows == 0:
+            return out
+        y = _scratch(self.cap * cout * 4, feats.device)
+        L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
+               L.ptr(self.meta), self.cap, self.k, 0, variant, L.ptr(y), st)
+        L.call('u2mkd_pairs_gather_sum', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
+        return out
+
+
 class KernelMap:
     """Kernel map of one (tensor_stride, kernel_size, stride, dilation) key.
 
@@ -257,21 +365,25 @@ class KernelMap:
         self._rulebook = None
         self._pairs = None
         self._sorted = {}
+        self._pair_schedule = None
 
     def sorted_table(self, inverse=False):
-        """(table with its rows permuted into neighbour-mask order, order int32 [rows]).
-        Mask-sorted rows make the kernel's 16-row MFMA blocks mask-homogeneous so
-        (block, offset) slots without any neighbour are skipped."""
+        """(table with its rows permuted into schedule order, order int32 [rows])."""
+        return self.schedule(inverse).tiles()
+
+    def schedule(self, inverse=False):
+        """The tile schedule of the (inverse) neighbour table (cached)."""
         hit = self._sorted.get(inverse)
         if hit is None:
-            tbl = self.nbr_inv if inverse else self.nbr
-            k, n = tbl.shape
-            mask = torch.empty(n, dtype=torch.int32, device=tbl.device)
-            L.call('u2mkd_kmap_rowmask', L.ptr(tbl), n, k, L.ptr(mask), L.stream())
-            order = torch.argsort(mask, stable=True).int()
-            hit = (tbl.index_select(1, order.long()).contiguous(), order)
+            hit = TileSchedule(self.nbr_inv if inverse else self.nbr)
             self._sorted[inverse] = hit
         return hit
+
+    def pair_schedule(self):
+        """The pair schedule of the map (cached; serves forward, transposed and dgrad)."""
+        if self._pair_schedule is None:
+            self._pair_schedule = PairSchedule(self.nbr, self.n_in)
+        return self._pair_schedule
 
     def pairs_plan(self):
         """(pairs int32 [cap,2] rows (in,out) grouped by offset, nbsizes int32 [K], plan int32):
@@ -346,15 +458,17 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> Kern
 # --------------------------------------------------------------------- conv
 def _conv_os(feats, wt, cout, kmap, inverse, n_rows, kflip):
     """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin];
-    tbl = the kernel map's (inverse) neighbour table, walked in mask-sorted row order."""
-    n_in, cin = feats.shape
-    nbr_s, order = kmap.sorted_table(inverse)
-    k = nbr_s.shape[0]
-    assert nbr_s.shape[1] == n_rows
+    tbl = the kernel map's (inverse) neighbour table.  kflip = 1 is the input gradient of a
+    symmetric (submanifold) map computed on the forward table with mirrored offsets -- in the
+    pair schedule that is simply the swapped-role walk."""
     out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
-    L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order),
-           n_rows, k, int(kflip), 0, L.ptr(out), L.stream())
-    return out
+    if _pairs_mode(feats.shape[1], cout):
+        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
+    if inverse and kmap.nbr_inv is None:      # symmetric map: the inverse table is the mirrored forward table
+        inverse, kflip = False, 1 - int(kflip)
+    sch = kmap.schedule(inverse)
+    assert sch.n == n_rows
+    return sch.run(feats, wt, cout, kflip, out)
 
 
 def _transpose_weights(weight):
