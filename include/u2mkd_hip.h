@@ -127,11 +127,12 @@ int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const fl
 /* y[p] = in[pair_idx[p]] * B_{tile_k[p / 64]} over the pair schedule of u2mkd_pairs_build
  * (pair_idx = pair_in for a normal conv, pair_out for a transposed conv / the input gradient):
  * one dense MFMA stage per 64-pair tile, no serial walk over offsets.  meta (device) holds
- * the tile count; a fixed grid strides over the tiles, so nothing is read back by the host.
+ * the tile count; a fixed grid splits the tiles into contiguous runs, so nothing is read back
+ * by the host.  variant: 0 = heuristic, 32 / 64 = channels per pipeline stage.
  * y must hold `capacity` rows (only the first meta[0] are written; padding entries give 0).  */
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                              const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
-                             int32_t k, int32_t kflip, int32_t variant, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
+                             int32_t k, int32_t variant, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
 /* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
  * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,

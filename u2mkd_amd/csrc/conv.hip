@@ -35,15 +35,10 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
     wt[t] = w[(k * cin + ci) * cout + co];
 }
 
-// Rows a forward launch covers.  Table mode (tile_k == nullptr): sorted rows [begin, end) of the
-// neighbour table nbr[k * ld + row].  Pair mode: "rows" are entries of a pair list nbr[row]
-// (input index or -1), grouped by offset and padded so that the 64 entries of tile t all belong
-// to offset tile_k[t]; the output row of entry p is p.  The tile count lives on the device
-// (*n_tiles): the grid is a fixed number of workgroups that stride over the tiles.
+// Rows a table-walking forward launch covers: sorted rows [begin, end) of the neighbour table
+// nbr[k * ld + row].
 struct RowRange {
     int64_t ld, begin, end;
-    const int32_t *tile_k;
-    const int32_t *n_tiles;   // pair mode: device-side tile count; workgroups stride over the tiles
 };
 
 // ---- output-stationary kernel, LDS-staged weights -----------------------------------
@@ -79,12 +74,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int col0 = blockIdx.y * TN;
-    const int64_t ld = rr_.ld;
-    const int ntile = rr_.n_tiles ? *rr_.n_tiles : (int)gridDim.x;
-    const int64_t n_out = rr_.n_tiles ? (int64_t)ntile * TM : rr_.end;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int64_t row0 = rr_.begin + (int64_t)tile * TM;
-    const int kt = rr_.tile_k ? rr_.tile_k[tile] : -1;   // pair mode: the tile's only offset
+    const int64_t row0 = rr_.begin + (int64_t)blockIdx.x * TM, n_out = rr_.end, ld = rr_.ld;
 
     if (tid == 0) *s_mask = 0u;
     for (int e = tid; e < TM; e += NT) {
@@ -104,11 +94,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
             int e = tid + i * NT;
             int k = e / TM, rr = e - k * TM;
             int64_t row = row0 + rr;
-            v[i] = -1;
-            if (e < K * TM && row < n_out) {
-                if (kt < 0) v[i] = nbr[(int64_t)k * ld + row];
-                else if (k == kt) v[i] = nbr[row];
-            }
+            v[i] = (e < K * TM && row < n_out) ? nbr[(int64_t)k * ld + row] : -1;
         }
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
@@ -217,8 +203,6 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
             for (int n = 0; n < NB; ++n)
                 if (col0 + 16 * n + r < cout) out[(size_t)rid * cout + col0 + 16 * n + r] = acc[n][reg];
         }
-    }
-    __syncthreads();   // the LDS tables are rebuilt by the next tile
     }
 }
 
@@ -745,6 +729,161 @@ static WgradPlan wgrad_plan(int64_t n_rows, int ca, int cb, int K, int centre_de
     return p;
 }
 
+// ---- pair-schedule kernel: one offset per 64-pair tile, pipelined across tiles ------------
+// The pair schedule (u2mkd_pairs_build) makes every tile a plain [64 x cin] x [cin x 16*NB]
+// product with gathered A rows: no neighbour table, no offset walk.  A workgroup (4 waves, one
+// 16-pair MFMA block each) strides over the tiles with a fixed grid; (tile, channel chunk)
+// stages form ONE software pipeline -- the loads of the next stage, including the first
+// stage of the NEXT tile, are in flight while the current stage multiplies, and the pair
+// indices of the next tile are fetched a whole tile ahead.  B goes through a double-buffered
+// LDS image ([col][KC+8], conflict-free ds_read_b128), A straight into MFMA operand registers.
+template <int NB, int KC>
+__global__ void __launch_bounds__(256)
+conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
+                  const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
+                  const int32_t *__restrict__ n_tiles, float *__restrict__ y) {
+    constexpr int NT = 256, TN = 16 * NB, BS = KC + 8, F4ROW = KC / 4;
+    constexpr int BPASS = (TN * F4ROW + NT - 1) / NT, NJ = KC / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Bs = reinterpret_cast<float *>(smem);   // [2][TN][BS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int col0 = blockIdx.y * TN;
+    const int ntile = *n_tiles;
+    const int nchunk = (cin + KC - 1) / KC;
+    // a contiguous run of tiles per workgroup: consecutive tiles mostly share their offset, and
+    // with a single channel chunk the weight image then simply stays in LDS (no reload, no barrier)
+    const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per;
+    const int tile_end = min(tile + per, ntile);
+    if (tile >= tile_end) return;
+
+    float4 a_cur[NJ], a_nxt[NJ], breg[BPASS];
+    auto load_stage = [&](int k, int c, int idx, float4 (&a)[NJ], bool with_b) {
+        if (with_b) {
+            const float *wk = wt + (size_t)k * cout * cin;
+#pragma unroll
+            for (int p = 0; p < BPASS; ++p) {
+                int f = tid + NT * p;
+                int col = f / F4ROW, ci = c * KC + (f % F4ROW) * 4;
+                breg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col < TN && col0 + col < cout && ci < cin)
+                    breg[p] = *reinterpret_cast<const float4 *>(wk + (size_t)(col0 + col) * cin + ci);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int ci = c * KC + 16 * j + 4 * q;
+            a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx >= 0 && ci < cin) a[j] = *reinterpret_cast<const float4 *>(in + (size_t)idx * cin + ci);
+        }
+    };
+    auto store_B = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int f = tid + NT * p;
+            int col = f / F4ROW;
+            if (col < TN)
+                *reinterpret_cast<float4 *>(Bs + ((size_t)buf * TN + col) * BS + (f % F4ROW) * 4) = breg[p];
+        }
+    };
+
+    int idx = pair_idx[(int64_t)tile * 64 + 16 * wave + r];
+    int k = tile_k[tile];
+    int tile_n = tile + 1;
+    int idx_n = -1, k_n = k;
+    if (tile_n < tile_end) {
+        idx_n = pair_idx[(int64_t)tile_n * 64 + 16 * wave + r];
+        k_n = tile_k[tile_n];
+    }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_stage(k, 0, idx, a_cur, true);
+    store_B(0);
+    __syncthreads();
+    int buf = 0, c = 0;
+    while (true) {
+        const bool last_chunk = c + 1 == nchunk;
+        const bool have_next = !last_chunk || tile_n < tile_end;
+        const bool new_b = have_next && (nchunk > 1 || k_n != k);   // workgroup-uniform
+        if (have_next) {
+            if (!last_chunk) load_stage(k, c + 1, idx, a_nxt, new_b);
+            else load_stage(k_n, 0, idx_n, a_nxt, new_b);
+        }
+        if (__ballot(idx >= 0) != 0ULL) {
+            const float *bb = Bs + (size_t)buf * TN * BS + r * BS + 4 * q;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float4 b[NB];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) b[n] = *reinterpret_cast<const float4 *>(bb + 16 * n * BS + 16 * j);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, b[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, b[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, b[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, b[n].w, acc[n], 0, 0, 0);
+            }
+        }
+        if (last_chunk) {   // D row = 4q + reg, col = r; y row = the pair's slot
+            float *yr = y + ((size_t)tile * 64 + 16 * wave + 4 * q) * cout + col0 + r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    if (col0 + 16 * n + r < cout) yr[(size_t)reg * cout + 16 * n] = acc[n][reg];
+                    acc[n][reg] = 0.f;
+                }
+        }
+        if (!have_next) break;
+        if (new_b) {
+            // the other buffer was last read before the previous flip's barrier: free to overwrite
+            store_B(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (last_chunk) {
+            tile = tile_n;
+            idx = idx_n;
+            k = k_n;
+            c = 0;
+            ++tile_n;
+            idx_n = -1;
+            if (tile_n < tile_end) {
+                idx_n = pair_idx[(int64_t)tile_n * 64 + 16 * wave + r];
+                k_n = tile_k[tile_n];
+            }
+        } else {
+            ++c;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a_cur[j] = a_nxt[j];
+    }
+}
+
+template <int KC>
+static int launch_conv_pairs(int nb, dim3 grid, hipStream_t st, const float *in, int cin, const float *wt, int cout,
+                             const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y) {
+    size_t lds = (size_t)2 * 16 * nb * (KC + 8) * 4;
+#define U2_CASE(N)                                                                                                 \
+    case N:                                                                                                        \
+        if (lds > 65536)                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pairs_kernel<N, KC>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((conv_pairs_kernel<N, KC>), grid, dim3(256), lds, st, in, cin, wt, cout, pair_idx,      \
+                           tile_k, n_tiles, y);                                                                    \
+        break;
+    switch (nb) {
+        U2_CASE(1) U2_CASE(2) U2_CASE(3) U2_CASE(4) U2_CASE(5) U2_CASE(6) U2_CASE(7) U2_CASE(8)
+        default: set_error("conv pairs: unsupported column block count %d", nb); return 2;
+    }
+#undef U2_CASE
+    return 0;
+}
+
 // out[j] = sum over offsets (ascending) of y[pos[j][k]] (pos < 0: no pair); one float4 per
 // thread, a row's K slots are read first (contiguous), then all of its y rows are in flight.
 __global__ void __launch_bounds__(256)
@@ -822,8 +961,6 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
     U2_REQUIRE(cin > 0 && cin % 4 == 0, "%s: cin=%d must be a positive multiple of 4", who, cin);
     U2_REQUIRE(cout > 0, "%s: cout=%d must be positive", who, cout);
     U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "%s: kernel volume %d not in 1..32", who, k);
-    const bool pair_mode = rr.tile_k != nullptr;
-    U2_REQUIRE(!pair_mode || (rr.begin == 0 && rr.end % 64 == 0 && rr.n_tiles), "%s: a pair list is padded to 64 entries per offset", who);
     const int c16 = (cout + 15) / 16;
     int nb = pick_nb(c16);
     if (variant >= 50000) {   // 50000 + nb * 1000 + waves * 100 + kc: conv_os2 with nb 16-column blocks per workgroup
@@ -831,7 +968,6 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
         variant = (variant - 50000) % 1000;
         U2_REQUIRE(nb >= 1 && nb <= 8, "%s: bad column block count %d", who, nb);
     }
-    if (variant == 0 && pair_mode) variant = 432;   // measured best for every layer shape (tools/ab_hybrid.py)
     // variant: 0 = heuristic; 3000 + kc = column-split kernel (conv_os3); otherwise waves * 100 + kc
     if (variant == 0 && cout % 128 == 0 && cin >= 16) {   // (cout == 64: conv_os2 is ~8 % faster, ab_conv.py)
         variant = 3000 + (cin % 64 == 0 ? 64 : 32);
@@ -846,7 +982,7 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
         if (narrow) variant -= 10000;
         int rb3 = (variant - 3000) / 100, kc3 = (variant - 3000) % 100;
         if (rb3 == 0) rb3 = 4;
-        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8) && !pair_mode,
+        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8),
                    "%s: bad variant %d", who, variant);
         const int nbw = (cout % 128 == 0 && !narrow) ? 2 : 1;
         dim3 grid3((unsigned)ceil_div(n_rows, 16 * rb3), (unsigned)(cout / (64 * nbw)));
@@ -870,11 +1006,9 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
         waves = variant / 100;
         kc = variant % 100;
     }
-    U2_REQUIRE((waves == 4 || ((waves == 8 || waves == 16) && !pair_mode)) && (kc == 32 || kc == 64),
+    U2_REQUIRE((waves == 4 || waves == 8 || waves == 16) && (kc == 32 || kc == 64),
                "%s: bad variant %d", who, variant);
-    int64_t gx = ceil_div(n_rows, 16 * waves);
-    if (pair_mode && gx > 2048) gx = 2048;   // 8 workgroups per CU stride over the device-side tile count
-    dim3 grid((unsigned)gx, (unsigned)ceil_div(c16, nb));
+    dim3 grid((unsigned)ceil_div(n_rows, 16 * waves), (unsigned)ceil_div(c16, nb));
     hipStream_t st = as_stream(s);
     int rc;
 #define U2_V(W, KCV) rc = launch_conv_os2<W, KCV>(nb, grid, k, st, in, cin, wt, cout, nbr, order, rr, kflip, out)
@@ -893,7 +1027,7 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
                                const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
                                int32_t variant, float *out, u2mkd_stream_t s) {
     return conv_forward_impl("u2mkd_conv_forward_sorted", in, n_in, cin, wt, cout, nbr_sorted, order,
-                             RowRange{n_out, 0, n_out, nullptr, nullptr}, k, kflip, variant, out, s);
+                             RowRange{n_out, 0, n_out}, k, kflip, variant, out, s);
 }
 
 int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
@@ -907,16 +1041,28 @@ int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const fl
     U2_REQUIRE(row_begin >= 0 && row_end <= ld, "u2mkd_conv_forward_rows: rows [%lld, %lld) outside the table of %lld",
                (long long)row_begin, (long long)row_end, (long long)ld);
     return conv_forward_impl("u2mkd_conv_forward_rows", in, n_in, cin, wt, cout, nbr_sorted, order,
-                             RowRange{ld, row_begin, row_end, nullptr, nullptr}, k, kflip, variant, out, s);
+                             RowRange{ld, row_begin, row_end}, k, kflip, variant, out, s);
 }
 
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                               const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
-                              int32_t k, int32_t kflip, int32_t variant, float *y, u2mkd_stream_t s) {
+                              int32_t k, int32_t variant, float *y, u2mkd_stream_t s) {
     if (capacity == 0) return 0;
-    U2_REQUIRE(tile_k && meta, "u2mkd_conv_forward_pairs: null pointer");
-    return conv_forward_impl("u2mkd_conv_forward_pairs", in, n_in, cin, wt, cout, pair_idx, nullptr,
-                             RowRange{capacity, 0, capacity, tile_k, meta + 1}, k, kflip, variant, y, s);
+    U2_REQUIRE(in && wt && pair_idx && tile_k && meta && y, "u2mkd_conv_forward_pairs: null pointer");
+    U2_REQUIRE(cin > 0 && cin % 4 == 0 && cout > 0 && k > 0 && n_in >= 0 && capacity % 64 == 0,
+               "u2mkd_conv_forward_pairs: cin=%d must be a positive multiple of 4, the capacity a multiple of 64", cin);
+    // variant: 0 = heuristic, 32 / 64 = channels per stage (measured: tools/ab_hybrid.py)
+    if (variant == 0) variant = ((int64_t)cin * cout >= 16384 && cin % 64 == 0) ? 64 : 32;
+    U2_REQUIRE(variant == 32 || variant == 64, "u2mkd_conv_forward_pairs: bad variant %d", variant);
+    const int c16 = (cout + 15) / 16;
+    const int nb = pick_nb(c16);
+    int64_t gx = capacity / 64;
+    if (gx > 2048) gx = 2048;   // 8 workgroups per CU, each a contiguous run of the device-side tile count
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(c16, nb));
+    int rc = variant == 32 ? launch_conv_pairs<32>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, y)
+                           : launch_conv_pairs<64>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, y);
+    if (rc) return rc;
+    return check_launch("u2mkd_conv_forward_pairs");
 }
 
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,

@@ -339,7 +339,7 @@ class PairSchedule:
             return out
         y = _scratch(self.cap * cout * 4, feats.device)
         L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
-               L.ptr(self.meta), self.cap, self.k, 0, variant, L.ptr(y), st)
+               L.ptr(self.meta), self.cap, self.k, variant, L.ptr(y), st)
         L.call('u2mkd_pairs_gather_sum', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
         return out
 
