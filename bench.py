@@ -92,6 +92,7 @@ def roofline_leg(coords_dev, iters=50):
     wt = F._transpose_weights(w)
     lib = L.load()
     nbr_s, order = km.sorted_table(False)
+    tile_order = km.schedule(False).tile_order
     pairs, _, plan = km.pairs_plan()
     nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
@@ -101,11 +102,11 @@ def roofline_leg(coords_dev, iters=50):
     st = L.stream()
 
     def fwd():
-        L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), n, 27, 0,
+        L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), L.ptr(tile_order), n, 27, 0,
                0, L.ptr(out), st)
 
     def dgrad():
-        L.call('u2mkd_conv_forward_sorted', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(nbr_s), L.ptr(order), n, 27, 1,
+        L.call('u2mkd_conv_forward_sorted', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(nbr_s), L.ptr(order), L.ptr(tile_order), n, 27, 1,
                0, L.ptr(dx), st)
 
     def wgrad():

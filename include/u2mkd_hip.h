@@ -110,11 +110,13 @@ int u2mkd_conv_forward(const float *in /*[n_in,cin]*/, int64_t n_in, int32_t cin
  * original row order[p] (order == NULL: identity).  Sorting rows by their 27-bit
  * neighbour mask makes 16-row MFMA blocks mask-homogeneous, so empty (block, offset)
  * slots are skipped.  variant: 0 = built-in heuristic, else waves*100 + KC (tuning knob:
- * waves in {4,8,16} = 64/128/256-row workgroup tiles, KC in {32,64} channels per stage).  */
+ * waves in {4,8,16} = 64/128/256-row workgroup tiles, KC in {32,64} channels per stage).
+ * tile_order: launch order of the 64-row tiles -- a tile visits the union of its rows' offsets
+ * serially, so tiles with the most offsets should start first (NULL: ascending).            */
 int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                               const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
-                              int64_t n_out, int32_t k, int32_t kflip, int32_t variant,
-                              float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+                              const int32_t *tile_order /*[ceil(n_out/64)] or NULL*/, int64_t n_out, int32_t k,
+                              int32_t kflip, int32_t variant, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
 /* The same kernel on sorted rows [row_begin, row_end) of a table whose rows are ld entries
  * long (the other rows of `out` are left untouched).  Together with the two entries below
  * this allows mixed schedules: some sorted rows through the output-stationary tiles, the
@@ -133,6 +135,12 @@ int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const fl
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                              const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
                              int32_t k, int32_t variant, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
+/* y = x * w^T (+ bias): nn.Linear on the rows of a feature matrix (the point-branch MLPs of
+ * core/models/semantickitti/spvcnn.py:58-74 and the 1x1x1 convs of ResidualBlock.downsample,
+ * build_blocks.py:69-72), on the pair kernel's pipeline with the identity schedule.  w is
+ * nn.Linear's [cout, cin]; y must hold ceil(n / 64) * 64 rows (rows >= n receive the bias). */
+int u2mkd_linear_forward(const float *x /*[n,cin]*/, int64_t n, int32_t cin, const float *w /*[cout,cin]*/, int32_t cout,
+                         const float *bias /*[cout] or NULL*/, int32_t variant, float *y, u2mkd_stream_t s);
 /* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
  * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,

@@ -265,6 +265,32 @@ def test_pair_schedule_is_the_padded_rulebook(F):
         assert len(ii) == len(nbmaps) and (pi[pos_in[ii, kk]] == ii).all()
 
 
+@pytest.mark.parametrize('n,cin,cout,bias', [(5000, 32, 256, True), (80000, 256, 128, True), (777, 128, 96, False),
+                                             (64, 4, 4, True), (1, 96, 20, True), (130, 48, 64, False)])
+def test_linear_matches_torch_cpu(F, n, cin, cout, bias):
+    """LinearFunction (pair kernel dense mode + pair-list wgrad) vs nn.functional.linear in fp32 on the CPU."""
+    torch.manual_seed(n + cin)
+    x = torch.randn(n, cin)
+    w = torch.randn(cout, cin) / cin ** 0.5
+    b = torch.randn(cout) if bias else None
+    g = torch.randn(n, cout)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    want = torch.nn.functional.linear(xr, wr, br)
+    want.backward(g)
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True) if bias else None
+    out = F.linear(xd, wd, bd)
+    assert out.shape == (n, cout) and out.is_contiguous()
+    assert _rel(out, want.detach()) < 1e-5
+    out.backward(g.cuda())
+    assert _rel(xd.grad, xr.grad) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-4
+    if bias:
+        assert _rel(bd.grad, br.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        F.linear(x, w, b)                      # CPU tensors: no fallback
+
+
 def test_conv_northstar_size_80k_c64(F):
     """BASELINE.json configs[1] micro-shape: 80k voxels, 64->64, k=3, stride 1."""
     b = synth_batch(80000, 1)

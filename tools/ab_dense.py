@@ -15,6 +15,6 @@ for cin, cout in ((64, 64), (128, 128), (256, 256)):
     o = torch.empty(n, cout, device='cuda')
     res = [f'dense N={n} P={p} {cin}->{cout}:']
     for var in (432, 464, 832, 864, 3032, 3064):
-        t = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), None, n, 27, 0, var, L.ptr(o), st), 10)
+        t = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(km.nbr), None, None, n, 27, 0, var, L.ptr(o), st), 10)
         res.append(f'{var}: {t*1e3:.0f}us {2.0*p*cin*cout/(t*1e-3)/1e12:.1f}TF')
     print(' | '.join(res), flush=True)

@@ -18,7 +18,7 @@ valid = (nbr_s >= 0)
 for var in (464, 3064):
     res = []
     for k in (1, 2, 4, 8, 13, 14, 20, 27):
-        t = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), n, k, 0, var, L.ptr(o), st), 20)
+        t = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), None, n, k, 0, var, L.ptr(o), st), 20)
         pairs = int(valid[:k].sum())
         # active (64-row tile, offset) stages
         nt = (n + 63) // 64

@@ -33,9 +33,10 @@ SIGNATURES = {
     'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
-    'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward_rows': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward_pairs': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_linear_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _p, _p]),
     'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

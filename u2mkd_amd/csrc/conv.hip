@@ -39,6 +39,7 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
 // nbr[k * ld + row].
 struct RowRange {
     int64_t ld, begin, end;
+    const int32_t *tile_order;   // launch order of the 64-row tiles (heaviest first) or nullptr
 };
 
 // ---- output-stationary kernel, LDS-staged weights -----------------------------------
@@ -74,7 +75,8 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int col0 = blockIdx.y * TN;
-    const int64_t row0 = rr_.begin + (int64_t)blockIdx.x * TM, n_out = rr_.end, ld = rr_.ld;
+    const int64_t row0 = rr_.begin + (int64_t)(rr_.tile_order ? rr_.tile_order[blockIdx.x] : (int)blockIdx.x) * TM;
+    const int64_t n_out = rr_.end, ld = rr_.ld;
 
     if (tid == 0) *s_mask = 0u;
     for (int e = tid; e < TM; e += NT) {
@@ -236,7 +238,8 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t row0 = rr_.begin + (int64_t)blockIdx.x * TM, n_out = rr_.end, ld = rr_.ld;
+    const int64_t row0 = rr_.begin + (int64_t)(rr_.tile_order ? rr_.tile_order[blockIdx.x] : (int)blockIdx.x) * TM;
+    const int64_t n_out = rr_.end, ld = rr_.ld;
     const int col0 = blockIdx.y * TN;
 
     for (int e = tid; e < TM; e += 256) {
@@ -741,7 +744,8 @@ template <int NB, int KC>
 __global__ void __launch_bounds__(256)
 conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wt, int cout,
                   const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
-                  const int32_t *__restrict__ n_tiles, float *__restrict__ y) {
+                  const int32_t *__restrict__ n_tiles, int64_t n_dense, const float *__restrict__ bias,
+                  float *__restrict__ y) {
     constexpr int NT = 256, TN = 16 * NB, BS = KC + 8, F4ROW = KC / 4;
     constexpr int BPASS = (TN * F4ROW + NT - 1) / NT, NJ = KC / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -749,8 +753,14 @@ conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int col0 = blockIdx.y * TN;
-    const int ntile = *n_tiles;
+    // dense mode (pair_idx == nullptr): y = in * B_0 (+ bias) over rows [0, n_dense) -- a plain
+    // linear layer on the same pipeline (entry p is row p, every tile uses offset 0)
+    const int ntile = pair_idx ? *n_tiles : (int)((n_dense + 63) / 64);
     const int nchunk = (cin + KC - 1) / KC;
+    auto entry = [&](int t) -> int {
+        int64_t p = (int64_t)t * 64 + 16 * wave + r;
+        return pair_idx ? pair_idx[p] : (p < n_dense ? (int)p : -1);
+    };
     // a contiguous run of tiles per workgroup: consecutive tiles mostly share their offset, and
     // with a single channel chunk the weight image then simply stays in LDS (no reload, no barrier)
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -788,17 +798,21 @@ conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict
         }
     };
 
-    int idx = pair_idx[(int64_t)tile * 64 + 16 * wave + r];
-    int k = tile_k[tile];
+    int idx = entry(tile);
+    int k = tile_k ? tile_k[tile] : 0;
     int tile_n = tile + 1;
     int idx_n = -1, k_n = k;
     if (tile_n < tile_end) {
-        idx_n = pair_idx[(int64_t)tile_n * 64 + 16 * wave + r];
-        k_n = tile_k[tile_n];
+        idx_n = entry(tile_n);
+        k_n = tile_k ? tile_k[tile_n] : 0;
     }
+    float bv[NB];
     f32x4 acc[NB];
 #pragma unroll
-    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NB; ++n) {
+        bv[n] = (bias && col0 + 16 * n + r < cout) ? bias[col0 + 16 * n + r] : 0.f;
+        acc[n] = (f32x4){bv[n], bv[n], bv[n], bv[n]};
+    }
     load_stage(k, 0, idx, a_cur, true);
     store_B(0);
     __syncthreads();
@@ -835,7 +849,7 @@ conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict
 #pragma unroll
                 for (int n = 0; n < NB; ++n) {
                     if (col0 + 16 * n + r < cout) yr[(size_t)reg * cout + 16 * n] = acc[n][reg];
-                    acc[n][reg] = 0.f;
+                    acc[n][reg] = bv[n];
                 }
         }
         if (!have_next) break;
@@ -853,8 +867,8 @@ conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict
             ++tile_n;
             idx_n = -1;
             if (tile_n < tile_end) {
-                idx_n = pair_idx[(int64_t)tile_n * 64 + 16 * wave + r];
-                k_n = tile_k[tile_n];
+                idx_n = entry(tile_n);
+                k_n = tile_k ? tile_k[tile_n] : 0;
             }
         } else {
             ++c;
@@ -866,7 +880,8 @@ conv_pairs_kernel(const float *__restrict__ in, int cin, const float *__restrict
 
 template <int KC>
 static int launch_conv_pairs(int nb, dim3 grid, hipStream_t st, const float *in, int cin, const float *wt, int cout,
-                             const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y) {
+                             const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, int64_t n_dense,
+                             const float *bias, float *y) {
     size_t lds = (size_t)2 * 16 * nb * (KC + 8) * 4;
 #define U2_CASE(N)                                                                                                 \
     case N:                                                                                                        \
@@ -874,7 +889,7 @@ static int launch_conv_pairs(int nb, dim3 grid, hipStream_t st, const float *in,
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pairs_kernel<N, KC>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
         hipLaunchKernelGGL((conv_pairs_kernel<N, KC>), grid, dim3(256), lds, st, in, cin, wt, cout, pair_idx,      \
-                           tile_k, n_tiles, y);                                                                    \
+                           tile_k, n_tiles, n_dense, bias, y);                                                     \
         break;
     switch (nb) {
         U2_CASE(1) U2_CASE(2) U2_CASE(3) U2_CASE(4) U2_CASE(5) U2_CASE(6) U2_CASE(7) U2_CASE(8)
@@ -982,7 +997,7 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
         if (narrow) variant -= 10000;
         int rb3 = (variant - 3000) / 100, kc3 = (variant - 3000) % 100;
         if (rb3 == 0) rb3 = 4;
-        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || rb3 == 8),
+        U2_REQUIRE(cout % 64 == 0 && (kc3 == 32 || kc3 == 64) && (rb3 == 4 || (rb3 == 8 && !rr.tile_order)),
                    "%s: bad variant %d", who, variant);
         const int nbw = (cout % 128 == 0 && !narrow) ? 2 : 1;
         dim3 grid3((unsigned)ceil_div(n_rows, 16 * rb3), (unsigned)(cout / (64 * nbw)));
@@ -1006,7 +1021,7 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
         waves = variant / 100;
         kc = variant % 100;
     }
-    U2_REQUIRE((waves == 4 || waves == 8 || waves == 16) && (kc == 32 || kc == 64),
+    U2_REQUIRE((waves == 4 || ((waves == 8 || waves == 16) && !rr.tile_order)) && (kc == 32 || kc == 64),
                "%s: bad variant %d", who, variant);
     dim3 grid((unsigned)ceil_div(n_rows, 16 * waves), (unsigned)ceil_div(c16, nb));
     hipStream_t st = as_stream(s);
@@ -1024,15 +1039,15 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
 }
 
 int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
-                               const int32_t *nbr_sorted, const int32_t *order, int64_t n_out, int32_t k, int32_t kflip,
-                               int32_t variant, float *out, u2mkd_stream_t s) {
+                               const int32_t *nbr_sorted, const int32_t *order, const int32_t *tile_order, int64_t n_out,
+                               int32_t k, int32_t kflip, int32_t variant, float *out, u2mkd_stream_t s) {
     return conv_forward_impl("u2mkd_conv_forward_sorted", in, n_in, cin, wt, cout, nbr_sorted, order,
-                             RowRange{n_out, 0, n_out}, k, kflip, variant, out, s);
+                             RowRange{n_out, 0, n_out, tile_order}, k, kflip, variant, out, s);
 }
 
 int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
                        int64_t n_out, int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
-    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, n_out, k, kflip, 0, out, s);
+    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, nullptr, n_out, k, kflip, 0, out, s);
 }
 
 int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
@@ -1041,7 +1056,7 @@ int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const fl
     U2_REQUIRE(row_begin >= 0 && row_end <= ld, "u2mkd_conv_forward_rows: rows [%lld, %lld) outside the table of %lld",
                (long long)row_begin, (long long)row_end, (long long)ld);
     return conv_forward_impl("u2mkd_conv_forward_rows", in, n_in, cin, wt, cout, nbr_sorted, order,
-                             RowRange{ld, row_begin, row_end}, k, kflip, variant, out, s);
+                             RowRange{ld, row_begin, row_end, nullptr}, k, kflip, variant, out, s);
 }
 
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
@@ -1059,10 +1074,28 @@ int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const f
     int64_t gx = capacity / 64;
     if (gx > 2048) gx = 2048;   // 8 workgroups per CU, each a contiguous run of the device-side tile count
     dim3 grid((unsigned)gx, (unsigned)ceil_div(c16, nb));
-    int rc = variant == 32 ? launch_conv_pairs<32>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, y)
-                           : launch_conv_pairs<64>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, y);
+    int rc = variant == 32 ? launch_conv_pairs<32>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, 0, nullptr, y)
+                           : launch_conv_pairs<64>(nb, grid, as_stream(s), in, cin, wt, cout, pair_idx, tile_k, meta + 1, 0, nullptr, y);
     if (rc) return rc;
     return check_launch("u2mkd_conv_forward_pairs");
+}
+
+int u2mkd_linear_forward(const float *x, int64_t n, int32_t cin, const float *w, int32_t cout, const float *bias,
+                         int32_t variant, float *y, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(x && w && y, "u2mkd_linear_forward: null pointer");
+    U2_REQUIRE(cin > 0 && cin % 4 == 0 && cout > 0, "u2mkd_linear_forward: cin=%d must be a positive multiple of 4", cin);
+    if (variant == 0) variant = ((int64_t)cin * cout >= 16384 && cin % 64 == 0) ? 64 : 32;
+    U2_REQUIRE(variant == 32 || variant == 64, "u2mkd_linear_forward: bad variant %d", variant);
+    const int c16 = (cout + 15) / 16;
+    const int nb = pick_nb(c16);
+    int64_t gx = ceil_div(n, 64);
+    if (gx > 2048) gx = 2048;
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(c16, nb));
+    int rc = variant == 32 ? launch_conv_pairs<32>(nb, grid, as_stream(s), x, cin, w, cout, nullptr, nullptr, nullptr, n, bias, y)
+                           : launch_conv_pairs<64>(nb, grid, as_stream(s), x, cin, w, cout, nullptr, nullptr, nullptr, n, bias, y);
+    if (rc) return rc;
+    return check_launch("u2mkd_linear_forward");
 }
 
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,
@@ -1101,7 +1134,8 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     const int g = wgrad_g_target(n_rows, k) + k;
     U2_REQUIRE(workspace_bytes >= (size_t)g * ca * cb * sizeof(float), "u2mkd_conv_wgrad_pairs: workspace too small");
     hipStream_t st = as_stream(s);
-    auto pick = [](int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); };
+    // 32*W-channel tiles per operand: 96-channel layers get exact 96-wide tiles (W = 3)
+    auto pick = [](int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : (c <= 96 ? 3 : 4)); };
     const int wm = pick(ca), wn = pick(cb);
     const int tiles_a = (ca + 32 * wm - 1) / (32 * wm), tiles_b = (cb + 32 * wn - 1) / (32 * wn);
     dim3 grid(g, tiles_a * tiles_b);
@@ -1109,9 +1143,9 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     // pairs staged per step: fewer pairs = less LDS = more resident workgroups per CU to hide the
     // gather latency.  Measured (tools/ab_conv.py, U2MKD_WGRAD_CP sweep): 128-wide tiles 16 > 32 > 64
     // (256x256 at stride 8: 197 / 228 / 333 us), 32/64-wide tiles best at 32.
-    int cp = (wm == 4 || wn == 4) ? 16 : 32;
+    int cp = (wm >= 3 || wn >= 3) ? 16 : 32;
     if (const char *e = getenv("U2MKD_WGRAD_CP")) cp = atoi(e);
-    U2_REQUIRE(cp == 16 || cp == 32 || cp == 64, "u2mkd_conv_wgrad_pairs: U2MKD_WGRAD_CP must be 16, 32 or 64");
+    U2_REQUIRE(cp == 16 || cp == 32, "u2mkd_conv_wgrad_pairs: U2MKD_WGRAD_CP must be 16 or 32");
 #define U2_WPC(WM_, WN_, CPV)                                                                                       \
     do {                                                                                                            \
         constexpr int CP_ = CPV;                                                                                    \
@@ -1127,18 +1161,20 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
 #define U2_WP(WM_, WN_)                                                     \
     do {                                                                    \
         if (cp == 16) U2_WPC(WM_, WN_, 16);                                 \
-        else if (cp == 32) U2_WPC(WM_, WN_, 32);                            \
-        else U2_WPC(WM_, WN_, 64);                                          \
+        else U2_WPC(WM_, WN_, 32);                                          \
     } while (0)
-    if (wm == 1 && wn == 1) U2_WP(1, 1);
-    else if (wm == 1 && wn == 2) U2_WP(1, 2);
-    else if (wm == 1 && wn == 4) U2_WP(1, 4);
-    else if (wm == 2 && wn == 1) U2_WP(2, 1);
-    else if (wm == 2 && wn == 2) U2_WP(2, 2);
-    else if (wm == 2 && wn == 4) U2_WP(2, 4);
-    else if (wm == 4 && wn == 1) U2_WP(4, 1);
-    else if (wm == 4 && wn == 2) U2_WP(4, 2);
-    else U2_WP(4, 4);
+#define U2_WN(WM_)                                                          \
+    do {                                                                    \
+        if (wn == 1) U2_WP(WM_, 1);                                         \
+        else if (wn == 2) U2_WP(WM_, 2);                                    \
+        else if (wn == 3) U2_WP(WM_, 3);                                    \
+        else U2_WP(WM_, 4);                                                 \
+    } while (0)
+    if (wm == 1) U2_WN(1);
+    else if (wm == 2) U2_WN(2);
+    else if (wm == 3) U2_WN(3);
+    else U2_WN(4);
+#undef U2_WN
 #undef U2_WP
 #undef U2_WPC
     int64_t tile_elems = (int64_t)ca * cb;

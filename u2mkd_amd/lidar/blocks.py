@@ -10,7 +10,17 @@ from ..torchsparse.nn import functional as spf
 from ..torchsparse.nn.utils import fapply
 
 __all__ = ['BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock', 'FusedSequential',
-           'PointBatchNorm1d']
+           'PointBatchNorm1d', 'PointLinear']
+
+
+class PointLinear(nn.Linear):
+    """nn.Linear over point features [N, C] on the HIP MFMA pipeline (the reference's
+    point_transforms use plain nn.Linear, spvcnn.py:58-74; same parameters / state-dict keys).
+    rocBLAS picks a 32x32 macro-tile kernel for these tall-skinny fp32 products (~10 TFLOP/s at
+    80k x 256 x 128); the pair kernel's dense mode runs them at the conv's rate."""
+
+    def forward(self, input):
+        return spf.linear(input, self.weight, self.bias)
 
 
 class PointBatchNorm1d(nn.BatchNorm1d):

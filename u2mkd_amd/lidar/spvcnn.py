@@ -8,7 +8,8 @@ from torch import nn
 from .. import torchsparse
 from ..torchsparse import PointTensor
 from ..torchsparse import nn as spnn
-from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d,
+from ..torchsparse.nn import functional as spf
+from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                      ResidualBlock)
 from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
 
@@ -51,7 +52,7 @@ class SPVCNN(nn.Module):
         self.classifier_vox = nn.Sequential(nn.Linear(cs[8], self.num_classes))
 
         self.point_transforms = nn.ModuleList([
-            FusedSequential(nn.Linear(cs[a], cs[b]), PointBatchNorm1d(cs[b]), nn.ReLU(True))
+            FusedSequential(PointLinear(cs[a], cs[b]), PointBatchNorm1d(cs[b]), nn.ReLU(True))
             for a, b in ((0, 4), (4, 6), (6, 8))])
 
         self.weight_initialization()
@@ -67,6 +68,8 @@ class SPVCNN(nn.Module):
         x = in_mod['lidar']
         z = PointTensor(x.F, x.C.float())
         x0 = initial_voxelize(z, self.pres, self.vres)
+        # all kernel maps up front: stem k3 at stride 1, then (k2 s2 down, k3) per encoder stage
+        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
 

@@ -13,7 +13,8 @@ from torch import nn
 from .. import torchsparse
 from ..torchsparse import PointTensor
 from ..torchsparse import nn as spnn
-from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d,
+from ..torchsparse.nn import functional as spf
+from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                      ResidualBlock)
 from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
 from .sphereformer import SphereFormer
@@ -82,7 +83,7 @@ class SPVCNN_SPFORMER(nn.Module):
             for i in range(4, len(cs) - 1)])
         self.classifier_vox = nn.Sequential(nn.Linear(cs[8], num_classes))
         self.point_transforms = nn.ModuleList([
-            FusedSequential(nn.Linear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
+            FusedSequential(PointLinear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
             for a_, b_ in ((0, 4), (4, 6), (6, 8))])
         for m in self.modules():
             if isinstance(m, nn.BatchNorm1d):
@@ -95,6 +96,7 @@ class SPVCNN_SPFORMER(nn.Module):
         z = PointTensor(x.F, x.C.float())
         x0 = initial_voxelize(z, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())          # carries the metric xyz of every stride-1 voxel
+        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
 

@@ -14,8 +14,12 @@ import torch.nn.functional as F
 __all__ = ['lovasz_softmax_flat', 'Lovasz_softmax', 'MixLovaszCrossEntropy']
 
 
-def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-    """probas [P, C] (rows of valid points only), labels [P]; classes='present'.
+def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, valid: torch.Tensor = None) -> torch.Tensor:
+    """probas [P, C], labels [P]; classes='present'.  ``valid`` (bool [P]) marks the rows that
+    count; the reference compacts them first (``probas[valid]``, a host synchronisation) -- here
+    ignored rows get error -1, which sorts them behind every valid row (errors >= 0), their
+    foreground flag is 0 and their error enters the dot product as 0: the prefix sums of the
+    valid rows, hence value and gradient, are exactly those of the compacted input.
 
     Works on the [C, P] transpose so that the sort and the two cumulative sums
     run along the contiguous dimension (a dim-0 cumsum of a [P, C] tensor is a
@@ -24,8 +28,13 @@ def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor) -> torch.Ten
         return probas.sum() * 0.
     P, C = probas.shape
     pt = probas.t().contiguous()                                 # [C, P]
-    fg = (labels.unsqueeze(0) == torch.arange(C, device=labels.device).unsqueeze(1)).to(probas.dtype)
+    fg = (labels.unsqueeze(0) == torch.arange(C, device=labels.device).unsqueeze(1))
+    if valid is not None:
+        fg = fg & valid.unsqueeze(0)
+    fg = fg.to(probas.dtype)
     errors = (fg - pt).abs()
+    if valid is not None:
+        errors = torch.where(valid.unsqueeze(0), errors, errors.new_full((), -1.))
     errors_sorted, perm = torch.sort(errors, 1, descending=True)
     fg_sorted = torch.gather(fg, 1, perm)
     gts = fg_sorted.sum(1, keepdim=True)                         # [C, 1]
@@ -34,7 +43,7 @@ def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor) -> torch.Ten
     union = gts + (torch.arange(1, P + 1, device=probas.device, dtype=probas.dtype).unsqueeze(0) - cs)
     jaccard = 1. - intersection / union
     jaccard = torch.cat([jaccard[:, :1], jaccard[:, 1:] - jaccard[:, :-1]], 1)
-    per_class = (errors_sorted * jaccard).sum(1)                 # [C]
+    per_class = (errors_sorted.clamp(min=0.) * jaccard).sum(1)   # [C]
     present = (gts.squeeze(1) > 0).to(probas.dtype)
     return (per_class * present).sum() / present.sum().clamp(min=1.)
 
@@ -46,8 +55,7 @@ class Lovasz_softmax(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, probas, labels):
-        valid = labels != self.ignore_index
-        return lovasz_softmax_flat(probas[valid], labels[valid])
+        return lovasz_softmax_flat(probas, labels, labels != self.ignore_index)
 
 
 class MixLovaszCrossEntropy(nn.Module):

@@ -265,24 +265,29 @@ def _scratch(nbytes, device):
 class TileSchedule:
     """Output-stationary walk of a neighbour table [K, N]: 64-row tiles of the table in SORTED
     row order, each tile visits the union of its rows' offsets serially.  Rows are sorted by
-    (number of rows sharing their 27-bit neighbour mask, mask): tiles of one mask skip empty
-    (block, offset) slots, and the tiles of rare masks -- which walk up to 27 offsets with ~2
+    their 27-bit neighbour mask (tiles of one mask skip empty (block, offset) slots), and the
+    tiles are LAUNCHED heaviest-first: tiles made of rare masks walk up to 27 offsets with ~2
     useful rows each and are the kernel's critical path (in-kernel timestamps, DESIGN.md
-    section 6) -- start first.  Built without host synchronisation.
-        nbr_s int32 [K, N], order int32 [N] (original row of sorted row)"""
+    section 6), so they must not be the last to start.  Built without host synchronisation.
+        nbr_s int32 [K, N], order int32 [N] (original row of sorted row),
+        tile_order int32 [ceil(N / 64)] (tile ids by descending offset count)"""
 
     def __init__(self, tbl):
         self.k, self.n = tbl.shape
         k, n = tbl.shape
-        mask = torch.empty(n, dtype=torch.int32, device=tbl.device)
+        dev = tbl.device
+        mask = torch.empty(n, dtype=torch.int32, device=dev)
         if n:
             L.call('u2mkd_kmap_rowmask', L.ptr(tbl), n, k, L.ptr(mask), L.stream())
-        m64 = mask.long()
-        srt, _ = torch.sort(m64)
-        share = torch.searchsorted(srt, m64, right=True) - torch.searchsorted(srt, m64, right=False)
-        order = torch.argsort((share << 32) | m64, stable=True)
+        order = torch.argsort(mask, stable=True)
         self.nbr_s = tbl.index_select(1, order).contiguous()
         self.order = order.int()
+        t = (n + 63) // 64
+        ms = torch.zeros(t * 64, dtype=torch.int32, device=dev)
+        ms[:n] = mask[order]
+        bits = (ms.view(t, 64, 1) >> torch.arange(k, dtype=torch.int32, device=dev)) & 1
+        stages = bits.amax(1).sum(1)
+        self.tile_order = torch.argsort(stages, descending=True, stable=True).int()
 
     def tiles(self):
         return self.nbr_s, self.order
@@ -291,7 +296,7 @@ class TileSchedule:
         """out[j] = sum_k feats[tbl[k][j]] @ B_k,  B_k = wt[kflip ? K-1-k : k] as [cout][cin]."""
         n_in, cin = feats.shape
         L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(self.nbr_s),
-               L.ptr(self.order), self.n, self.k, int(kflip), variant, L.ptr(out), L.stream())
+               L.ptr(self.order), L.ptr(self.tile_order), self.n, self.k, int(kflip), variant, L.ptr(out), L.stream())
         return out
 
 
@@ -455,6 +460,31 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> Kern
     return KernelMap(nbr, nbr_inv, n_in, n_out, symmetric, out_coords)
 
 
+def prefetch_kmaps(x: SparseTensor, specs) -> None:
+    """Build the kernel maps a network is about to ask for, in one go.
+
+    ``specs`` lists (kernel_size, stride) of the convs that create maps, in forward order.
+    Maps depend on coordinates only, but a strided map needs the unique down-sampled
+    coordinates -- a host synchronisation (output size).  torchsparse (and this drop-in's
+    ``conv3d``) build maps lazily at the first conv of each stride, i.e. the host stops
+    four times in the middle of the encoder and cannot queue work ahead of the GPU there.
+    Prefetching moves those stops to the start of the step, where the GPU queue is empty
+    anyway; everything after is queued without waiting.  Results land in ``x.kmaps`` /
+    ``x.cmaps`` exactly as the lazy path would leave them."""
+    coords, ts = x.coords, x.stride
+    x.cmaps.setdefault(ts, coords)
+    one = (1, 1, 1)
+    for kernel_size, stride in specs:
+        kernel_size, stride = make_ntuple(kernel_size, ndim=3), make_ntuple(stride, ndim=3)
+        key = (ts, kernel_size, stride, one)
+        kmap = x.kmaps.get(key)
+        if kmap is None:
+            kmap = x.kmaps[key] = build_kmap(coords, ts, kernel_size, stride)
+        if stride != one:
+            coords, ts = kmap.out_coords, tuple(ts[k] * stride[k] for k in range(3))
+            x.cmaps.setdefault(ts, coords)
+
+
 # --------------------------------------------------------------------- conv
 def _conv_os(feats, wt, cout, kmap, inverse, n_rows, kflip):
     """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin];
@@ -472,10 +502,101 @@ def _conv_os(feats, wt, cout, kmap, inverse, n_rows, kflip):
 
 
 def _transpose_weights(weight):
+    """kernel [K, cin, cout] -> [K, cout, cin] (reduction dim contiguous for the MFMA B operand).
+    For FROZEN weights (requires_grad False: the KD teacher, inference) the result is cached on
+    the tensor object together with its in-place version; trained weights are transposed per call
+    (an optimizer that writes through ``.data`` would not bump the version)."""
     k, cin, cout = weight.shape
+    frozen = not weight.requires_grad
+    if frozen:
+        hit = weight.__dict__.get('_u2mkd_wt')
+        if hit is not None and hit[0] == weight._version and hit[1].shape == (k, cout, cin):
+            return hit[1]
     wt = torch.empty(k, cout, cin, dtype=torch.float32, device=weight.device)
     L.call('u2mkd_transpose_weights', L.ptr(weight), k, cin, cout, L.ptr(wt), L.stream())
+    if frozen:
+        weight.__dict__['_u2mkd_wt'] = (weight._version, wt)
     return wt
+
+
+_IDENTITY_PAIRS = {}
+
+
+def _identity_pairs(n, device):
+    """(pairs int32 [n,2] = (i,i), plan) of the one-offset identity map: lets the pair-list weight
+    gradient kernel compute dW = dY^T X of a linear layer.  Cached per row count."""
+    key = (n, device.index)
+    hit = _IDENTITY_PAIRS.get(key)
+    if hit is None:
+        if len(_IDENTITY_PAIRS) > 64:
+            _IDENTITY_PAIRS.clear()
+        i = torch.arange(n, dtype=torch.int32, device=device)
+        pairs = torch.stack([i, i], 1).contiguous()
+        nbsizes = torch.full((1,), n, dtype=torch.int32, device=device)
+        plan = torch.empty(L.load().u2mkd_wgrad_plan_ints(1), dtype=torch.int32, device=device)
+        L.call('u2mkd_wgrad_plan', L.ptr(nbsizes), 1, n, L.ptr(plan), L.stream())
+        hit = _IDENTITY_PAIRS[key] = (pairs, plan)
+    return hit
+
+
+def _dense(x, w_oc_ic, bias=None):
+    """rows of x [n, cin] times w^T, w = [cout, cin] (+ bias) on the MFMA pair pipeline."""
+    n, cin = x.shape
+    cout = w_oc_ic.shape[0]
+    y = torch.empty((n + 63) // 64 * 64, cout, dtype=torch.float32, device=x.device)
+    L.call('u2mkd_linear_forward', L.ptr(x), n, cin, L.ptr(w_oc_ic), cout, L.ptr(bias), 0, L.ptr(y), L.stream())
+    return y[:n]
+
+
+class LinearFunction(Function):
+    """y = x @ weight.T + bias (nn.Linear semantics) on the conv pipeline: forward and input
+    gradient on the pair kernel's dense mode, weight gradient on the pair-list wgrad kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L.require_cuda(x, weight)
+        x = x.contiguous().float()
+        weight = weight.contiguous().float()
+        if x.dim() != 2 or x.shape[1] != weight.shape[1]:
+            raise RuntimeError(f'linear: input {tuple(x.shape)} does not match weight {tuple(weight.shape)}')
+        if weight.shape[1] % 4 != 0 or weight.shape[0] % 4 != 0:
+            raise RuntimeError('linear: in/out features must be multiples of 4 on the HIP path')
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if x.shape[0] == 0:
+            return x.new_zeros(0, weight.shape[0])
+        return _dense(x, weight, bias.contiguous().float() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous().float()
+        n = x.shape[0]
+        cout, cin = weight.shape
+        gx = gw = gb = None
+        if n == 0:
+            return x.new_zeros(x.shape), torch.zeros_like(weight), (weight.new_zeros(cout) if ctx.has_bias else None)
+        if ctx.needs_input_grad[0]:
+            w_t = torch.empty(1, cin, cout, dtype=torch.float32, device=g.device)     # [cin][cout] = W^T rows
+            L.call('u2mkd_transpose_weights', L.ptr(weight), 1, cout, cin, L.ptr(w_t), L.stream())
+            gx = _dense(g, w_t[0])
+        if ctx.needs_input_grad[1]:
+            pairs, plan = _identity_pairs(n, g.device)
+            lib = L.load()
+            nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cout, cin, 1)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+            gw = torch.empty_like(weight)
+            L.call('u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin, L.ptr(pairs), L.ptr(plan), n, 1, 0,
+                   L.ptr(ws), nbytes, L.ptr(gw), L.stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """nn.functional.linear for [N, C] feature matrices on the HIP path (in / out features must be
+    multiples of 4; CPU tensors raise)."""
+    return LinearFunction.apply(x, weight, bias)
 
 
 class ConvolutionFunction(Function):
@@ -543,9 +664,13 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, st
     dilation = make_ntuple(dilation, ndim=3)
 
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
-        feats = feats.matmul(weight)
-        if bias is not None:
-            feats = feats + bias
+        w = weight[0] if weight.dim() == 3 else weight          # kernel [1, cin, cout] or [cin, cout]
+        if w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+            feats = linear(feats, w.t(), bias)
+        else:
+            feats = feats.matmul(w)
+            if bias is not None:
+                feats = feats + bias
         output = SparseTensor(coords=coords, feats=feats, stride=input.stride)
     elif not transposed:
         key = (input.stride, kernel_size, stride, dilation)
