@@ -7,8 +7,8 @@
 //   pass 1  each workgroup takes a slab of rows and computes, per channel, its local
 //           mean and the centred second moment M2 around that mean (the slab is re-read
 //           from L2), float4 columns x row lanes, LDS tree over the row lanes;
-//   pass 2  one thread per channel merges the slabs with Chan's parallel update in slab
-//           order (no atomics -> bitwise reproducible), writes mean / invstd and updates
+//   pass 2  64 lanes per channel merge the slabs with Chan's parallel update in a fixed
+//           order (no atomics -> bitwise reproducible), write mean / invstd and update
 //           the running statistics (unbiased variance, momentum) like nn.BatchNorm1d;
 //   pass 3  y = (x - mean) * invstd * gamma + beta [, ReLU]  (float4 elementwise).
 // Backward mirrors it: slab partial sums of dy' and dy'*xhat (dy' = dy masked by the fused
@@ -87,30 +87,45 @@ bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__
     }
 }
 
-// 16 channels x 16 slab lanes per block: lane g merges slabs g, g+16, ... with Chan's update,
-// the 16 partial (n, mean, M2) triples are then merged in lane order through LDS (fixed order).
+// 4 channels x 64 slab lanes per block: lane g merges slabs g, g+64, ... with Chan's update
+// (the loads of a lane's slabs are independent of the update chain and issued four at a time --
+// with 16 lanes the 40 dependent round trips to L2 made this tiny kernel cost 10 us), the 64
+// partial (n, mean, M2) triples are then merged in lane order through LDS (fixed order).
+constexpr int kBnFinLanes = 64, kBnFinCh = 4;
+
 __global__ void __launch_bounds__(256)
 bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
                          float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
                          float *__restrict__ mean_out, float *__restrict__ invstd_out) {
-    __shared__ float s_n[16][16], s_m[16][16], s_q[16][16];
-    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + cl;
+    __shared__ float s_n[kBnFinLanes][kBnFinCh], s_m[kBnFinLanes][kBnFinCh], s_q[kBnFinLanes][kBnFinCh];
+    const int cl = threadIdx.x & (kBnFinCh - 1), g = threadIdx.x / kBnFinCh;
+    const int ch = blockIdx.x * kBnFinCh + cl;
     float na = 0.f, mean = 0.f, m2 = 0.f;
-    if (ch < c)
-        for (int b = g; b < nslab; b += 16) {
-            float nb = (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows);
-            float mb = partial[(size_t)b * 2 * c + ch], m2b = partial[(size_t)b * 2 * c + c + ch];
-            float tot = na + nb;
-            float delta = mb - mean;
-            mean += delta * (nb / tot);
-            m2 += m2b + delta * delta * (na * nb / tot);
-            na = tot;
+    if (ch < c) {
+        for (int b0 = g; b0 < nslab; b0 += 4 * kBnFinLanes) {
+            float mb[4], qb[4], nb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int b = b0 + u * kBnFinLanes;
+                nb[u] = b < nslab ? (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows) : 0.f;
+                mb[u] = b < nslab ? partial[(size_t)b * 2 * c + ch] : 0.f;
+                qb[u] = b < nslab ? partial[(size_t)b * 2 * c + c + ch] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (nb[u] == 0.f) continue;
+                float tot = na + nb[u];
+                float delta = mb[u] - mean;
+                mean += delta * (nb[u] / tot);
+                m2 += qb[u] + delta * delta * (na * nb[u] / tot);
+                na = tot;
+            }
         }
+    }
     s_n[g][cl] = na; s_m[g][cl] = mean; s_q[g][cl] = m2;
     __syncthreads();
     if (g != 0 || ch >= c) return;
-    for (int i = 1; i < 16; ++i) {
+    for (int i = 1; i < kBnFinLanes; ++i) {
         float nb = s_n[i][cl];
         if (nb == 0.f) continue;
         float tot = na + nb;
@@ -209,19 +224,27 @@ bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, float *__restrict__ dbeta,
                        float *__restrict__ dgamma) {
-    __shared__ float s_1[16][16], s_2[16][16];
-    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + cl;
+    __shared__ float s_1[kBnFinLanes][kBnFinCh], s_2[kBnFinLanes][kBnFinCh];
+    const int cl = threadIdx.x & (kBnFinCh - 1), g = threadIdx.x / kBnFinCh;
+    const int ch = blockIdx.x * kBnFinCh + cl;
     float s1 = 0.f, s2 = 0.f;
-    if (ch < c)
-        for (int b = g; b < nslab; b += 16) {
-            s1 += partial[(size_t)b * 2 * c + ch];
-            s2 += partial[(size_t)b * 2 * c + c + ch];
+    if (ch < c) {
+        for (int b0 = g; b0 < nslab; b0 += 4 * kBnFinLanes) {
+            float p1[4], p2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int b = b0 + u * kBnFinLanes;
+                p1[u] = b < nslab ? partial[(size_t)b * 2 * c + ch] : 0.f;
+                p2[u] = b < nslab ? partial[(size_t)b * 2 * c + c + ch] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += p1[u]; s2 += p2[u]; }
         }
+    }
     s_1[g][cl] = s1; s_2[g][cl] = s2;
     __syncthreads();
     if (g != 0 || ch >= c) return;
-    for (int i = 1; i < 16; ++i) { s1 += s_1[i][cl]; s2 += s_2[i][cl]; }
+    for (int i = 1; i < kBnFinLanes; ++i) { s1 += s_1[i][cl]; s2 += s_2[i][cl]; }
     dbeta[ch] = s1;
     dgamma[ch] = s2;
 }
@@ -310,7 +333,7 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
     hipStream_t st = as_stream(s);
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, 16)), dim3(256), 0, st, partial, nslab, n, c,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
                        eps, momentum, running_mean, running_var, mean, invstd);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
@@ -342,7 +365,7 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
                        invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, 16)), dim3(256), 0, st, partial, nslab, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
                        dbeta, dgamma);
     int64_t total4 = n * (c / 4);
     if (training)

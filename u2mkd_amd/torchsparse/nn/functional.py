@@ -599,6 +599,18 @@ def linear(x, weight, bias=None):
     return LinearFunction.apply(x, weight, bias)
 
 
+_OVERLAP_WGRAD = os.environ.get('U2MKD_OVERLAP_WGRAD', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 class ConvolutionFunction(Function):
     """Sparse conv forward / backward on the neighbour tables of a KernelMap."""
 
@@ -634,7 +646,28 @@ class ConvolutionFunction(Function):
         g = grad_output.contiguous().float()
         k, cin, cout = weight.shape
         grad_input = grad_weight = None
-        if ctx.needs_input_grad[0]:
+        # The two gradients are independent: the weight gradient runs on a side stream next to
+        # the input gradient (each is a short grid with a long tail; together they fill the
+        # chip) and is joined before this function returns, so autograd sees ordinary tensors.
+        do_w = ctx.needs_input_grad[1]
+        do_x = ctx.needs_input_grad[0]
+        side = _side_stream(g.device) if (do_w and do_x and _OVERLAP_WGRAD) else None
+        if do_w:
+            # dW[k] = sum over the offset's pairs of X[in]^T dY[out] (transposed conv: roles swapped)
+            pairs, _, plan = kmap.pairs_plan()
+            lib = L.load()
+            nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(kmap.n_out, cin, cout, k)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+            grad_weight = torch.empty_like(weight)
+            if side is not None:
+                main = torch.cuda.current_stream(g.device)
+                side.wait_stream(main)
+                st = side.cuda_stream
+            else:
+                st = L.stream()
+            L.call('u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout, L.ptr(pairs), L.ptr(plan), kmap.n_out,
+                   k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), st)
+        if do_x:
             # dX[i] = sum_k dY[out_k(i)] @ W[k]^T : same kernel on the swapped-role table,
             # B_k = W[k] read as [cin][cout] (reduction over cout contiguous).
             if not transposed:
@@ -644,15 +677,8 @@ class ConvolutionFunction(Function):
             if cout % 4 != 0:
                 raise RuntimeError(f'conv3d backward: out_channels={cout} must be a multiple of 4')
             grad_input = _conv_os(g, weight, cin, kmap, inverse, input.shape[0], kflip)
-        if ctx.needs_input_grad[1]:
-            # dW[k] = sum over the offset's pairs of X[in]^T dY[out] (transposed conv: roles swapped)
-            pairs, _, plan = kmap.pairs_plan()
-            lib = L.load()
-            nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(kmap.n_out, cin, cout, k)
-            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
-            grad_weight = torch.empty_like(weight)
-            L.call('u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout, L.ptr(pairs), L.ptr(plan), kmap.n_out,
-                   k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), L.stream())
+        if side is not None:
+            torch.cuda.current_stream(g.device).wait_stream(side)
         return grad_input, grad_weight, None, None
 
 
