@@ -48,6 +48,50 @@ def test_c2l_gather_equals_reference_loop():
     assert float(got[~fov].abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('idx', [0, 2, 3])
+def test_hip_l2c_scatter_matches_reference_loop(hip, idx):
+    """Segment-sum form of the pixel mean (and its gradient) on the GPU vs the reference loop in fp64."""
+    b = synth_kd_batch(700, 2, seed=3, image_hw=(64, 112))
+    pc, ms = _kd_tensors(b)
+    ms[1][2] = False
+    torch.manual_seed(idx)
+    n = sum(m.shape[1] for m in ms)
+    feats = torch.randn(n, 24, dtype=torch.float64, requires_grad=True)
+    ifh, ifw = (32, 56) if idx == 0 else (8, 14)
+    want = FR.l2c_loop(feats, [c.double() for c in pc], ms, ifh, ifw, 4, idx)
+    g = torch.randn_like(want)
+    want.backward(g)
+    fd = feats.detach().float().cuda().requires_grad_(True)
+    got = PF.l2c_scatter(fd, [c.cuda() for c in pc], [m.cuda() for m in ms], ifh, ifw, 4 - idx)
+    assert got.shape == want.shape
+    assert float((got.detach().cpu().double() - want.detach()).abs().max()) < 1e-5
+    got.backward(g.float().cuda())
+    assert float((fd.grad.cpu().double() - feats.grad).abs().max()) < 1e-5
+    # deterministic: no atomics anywhere in the map or its gradient
+    fd2 = feats.detach().float().cuda().requires_grad_(True)
+    got2 = PF.l2c_scatter(fd2, [c.cuda() for c in pc], [m.cuda() for m in ms], ifh, ifw, 4 - idx)
+    got2.backward(g.float().cuda())
+    assert torch.equal(got, got2) and torch.equal(fd.grad, fd2.grad)
+
+
+@pytest.mark.gpu
+def test_hip_c2l_gather_matches_reference_loop(hip):
+    b = synth_kd_batch(700, 2, seed=4, image_hw=(64, 112))
+    pc, ms = _kd_tensors(b)
+    fmaps = torch.randn(2, 6, 12, 16, 28, dtype=torch.float64, requires_grad=True)
+    want = FR.c2l_loop(fmaps, [c.double() for c in pc], ms)
+    g = torch.randn_like(want)
+    want.backward(g)
+    fm = fmaps.detach().float().cuda().requires_grad_(True)
+    got = PF.c2l_gather(fm, [c.cuda() for c in pc], [m.cuda() for m in ms])
+    assert float((got.detach().cpu().double() - want.detach()).abs().max()) < 1e-5
+    got.backward(g.float().cuda())
+    assert float((fm.grad.cpu().double() - fmaps.grad).abs().max()) < 1e-4
+    fov = torch.from_numpy(b['student']['fov_mask'])
+    assert float(got[~fov.cuda()].abs().max()) == 0.0
+
+
 def test_teacher_to_student_equals_reference_loop():
     from u2mkd_amd.kd import teacher_to_student
     b = synth_kd_batch(900, 3, seed=5, image_hw=(32, 56))
