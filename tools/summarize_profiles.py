@@ -1,0 +1,43 @@
+"""gpurun_out/{prof_<tag>, prof_<tag>_ko, pmc_<tag>_*} -> profiles/<round>_*: rocprofv3 kernel
+stats of the default bench and of `bench.py --kernel-only`, the PMC means per kernel, and the HBM
+traffic per launch of the roofline group (FETCH_SIZE/WRITE_SIZE are in KiB-like units of 1024 B
+on this counter set; FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes).
+usage: python tools/summarize_profiles.py <tag> <round>"""
+import csv, json, os, shutil, sys, collections
+tag, rnd = sys.argv[1], sys.argv[2]
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(R, 'gpurun_out'), os.path.join(R, 'profiles')
+shutil.copy(os.path.join(G, f'prof_{tag}', 'bench_kernel_stats.csv'), os.path.join(P, f'{rnd}_default_kernel_stats.csv'))
+shutil.copy(os.path.join(G, f'prof_{tag}_ko', 'bench_kernel_stats.csv'), os.path.join(P, f'{rnd}_kernel_only_kernel_stats.csv'))
+line = open(os.path.join(G, f'prof_{tag}', 'bench_stdout.txt')).read().strip().splitlines()[-1]
+json.loads(line)
+open(os.path.join(P, f'{rnd}_bench_under_rocprof.json'), 'w').write(line + '\n')
+acc = collections.defaultdict(lambda: [0.0, 0])
+for sub in ('sq', 'fetch', 'write'):
+    f = os.path.join(G, f'pmc_{tag}_{sub}', 'pmc_counter_collection.csv')
+    for r in csv.DictReader(open(f)):
+        a = acc[(r['Kernel_Name'], r['Counter_Name'])]
+        a[0] += float(r['Counter_Value']); a[1] += 1
+with open(os.path.join(P, f'{rnd}_kernel_only_pmc_summary.csv'), 'w') as f:
+    f.write('kernel,counter,dispatches,mean\n')
+    for (k, c), (s, n) in acc.items():
+        kk = k.split('(')[0]
+        f.write(f'"{kk}",{c},{n},{s / n}\n')
+def mean(kpat, counter):
+    tot = [v for (k, c), v in acc.items() if kpat in k and c == counter]
+    return sum(s for s, n in tot) / max(sum(n for s, n in tot), 1)
+def traffic(kpat):   # bytes per launch
+    return (2.0 * mean(kpat, 'FETCH_SIZE') + mean(kpat, 'WRITE_SIZE')) * 1024.0
+meta = json.loads(line)['roofline']
+t = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --kernel-only`; '
+               'bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction of MI355X_MICROARCH.md)',
+     'N': meta['N'], 'P': meta['P'],
+     'conv_os2_fwd_or_dgrad': traffic('conv_os2_kernel'),
+     'conv_wgrad_pairs': traffic('conv_wgrad_pairs_kernel'),
+     'wgrad_reduce': traffic('wgrad_pairs_reduce_kernel')}
+t['group_fwd_dgrad_wgrad'] = 2 * t['conv_os2_fwd_or_dgrad'] + t['conv_wgrad_pairs'] + t['wgrad_reduce']
+json.dump(t, open(os.path.join(P, f'{rnd}_traffic.json'), 'w'), indent=1)
+print(json.dumps(t, indent=1))
+for k in ('conv_os2_kernel', 'conv_wgrad_pairs_kernel'):
+    busy, wave, mf = mean(k, 'SQ_BUSY_CYCLES'), mean(k, 'SQ_WAVE_CYCLES'), mean(k, 'SQ_VALU_MFMA_BUSY_CYCLES')
+    print(k, 'MFMA_BUSY/WAVE_CYCLES', mf / max(wave, 1), 'WAIT_ANY/WAVE', mean(k, 'SQ_WAIT_ANY') / max(wave, 1), 'WAIT_INST/WAVE', mean(k, 'SQ_WAIT_INST_ANY') / max(wave, 1))
