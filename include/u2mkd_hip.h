@@ -241,13 +241,19 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
                                  const float *tq, const float *tk, const float *tv, int32_t L, int32_t qgl,
                                  float split_a, int64_t n, int32_t h, int32_t hdim, float *out, float *lse,
                                  u2mkd_stream_t s);
+/* Table gradients: per-token scalar histograms in private LDS strips, contracted with the token
+ * vectors on the MFMA unit, one slab per wave in `workspace`, summed in a fixed order
+ * (deterministic, no atomics; dtq/dtk/dtv are fully written, no pre-zeroing).  qc_span = host-known
+ * bound on the quantised in-window coordinates of the affine axes (ceil(window / quant_size));
+ * spans above 24 (never on the U2MKD configs) take the generic kernel with LDS atomics.       */
+size_t u2mkd_sptr_backward_workspace_bytes(int64_t n, int32_t h, int32_t L);
 int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
                                   const float *lse, const int32_t *sort_idx, const int32_t *wstart,
                                   const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
-                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n,
-                                  int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/, float *dq, float *dk,
-                                  float *dv, float *dtq /*pre-zeroed*/, float *dtk /*pre-zeroed*/,
-                                  float *dtv /*pre-zeroed*/, u2mkd_stream_t s);
+                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a,
+                                  int32_t qc_span, int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
+                                  void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
+                                  float *dtk, float *dtv, u2mkd_stream_t s);
 
 #ifdef __cplusplus
 }

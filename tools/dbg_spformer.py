@@ -46,7 +46,7 @@ for name, coords, window, quant, a in (('cubic', xyz.float(), att_r.window_size,
     same = torch.equal(c_ref[order], c_ref[order][ws])
     cnt_ref = torch.unique(c_ref, return_counts=True)[1]
     print(name, 'partition consistent', same, 'n windows', len(cnt_ref), int((ws == torch.arange(len(ws))).sum()), 'n_max', int(cnt_ref.max()), int(wl.max()))
-    qc, radial = plan.quant_coords(coords.cuda(), quant, a is not None)
+    qc, radial, _ = plan.quant_coords(coords.cuda(), quant, a is not None)
     wsz = torch.as_tensor(np.asarray(window)).float(); q = torch.as_tensor(np.asarray(quant)).float()
     qc_ref = torch.div((coords - coords.min(0)[0]) % wsz, q, rounding_mode='floor')[order]
     print(name, 'qc mismatches', int((qc.cpu().float() != qc_ref).any(1).sum()), 'qc max', qc.max(0)[0].tolist(), qc_ref.max(0)[0].tolist())

@@ -21,6 +21,7 @@ namespace u2mkd {
 constexpr int kHd = 16;        // head dim (asserted by the reference, sptr/functional.py:355)
 constexpr int kTabRow = 20;    // LDS floats per table row (16 + 4 pad against bank conflicts)
 constexpr int kSptrThreads = 128;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // c10::div_floor_floating (torch.div(rounding_mode='floor') for floats)
 __device__ __forceinline__ float div_floor(float a, float b) {
@@ -106,6 +107,7 @@ __device__ __forceinline__ int exp_split(float d, float a) {
 struct RelCtx {
     int qgl;        // quant_grid_length
     float a;        // > 0: spherical branch (exponential radial split + clamp)
+    int dbg;        // timing experiments only (U2MKD_SPTR_DEBUG): 1 = skip the table-gradient atomics
 };
 
 __device__ __forceinline__ void rel_rows(const RelCtx &c, const int qi[3], float ri, const int qj[3], float rj,
@@ -240,7 +242,6 @@ __device__ __forceinline__ void lds_add_rows(float *tab, const int r[3], float s
         for (int d = 0; d < kHd; ++d) atomicAdd(row + d, scale * vec[d]);
     }
 }
-
 // ---- backward: every (sorted position, head) thread acts as query (dq, table grads) and as key (dk, dv)
 __global__ void __launch_bounds__(kSptrThreads)
 sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
@@ -249,8 +250,7 @@ sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
                      const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
                      const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
                      const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
-                     float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ dtq, float *__restrict__ dtk,
-                     float *__restrict__ dtv) {
+                     float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
     const int hh = blockIdx.y;
     const int tabf = L * 3 * kTabRow;
@@ -260,8 +260,11 @@ sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
     __syncthreads();
     const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
     float *Gq = g_tab, *Gk = g_tab + tabf, *Gv = g_tab + 2 * tabf;
-    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // a fixed grid walks the token blocks; the table gradients of all its blocks stay in LDS
+    const int64_t nblk = (n + blockDim.x - 1) / blockDim.x;
     const size_t hc = (size_t)h * kHd;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t p = blk * blockDim.x + threadIdx.x;
     if (p < n) {
         const int64_t t = sort_idx[p];
         int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
@@ -301,9 +304,11 @@ sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
             float ds = pr * (dp - del_i);
 #pragma unroll
             for (int d = 0; d < kHd; ++d) dqi[d] += ds * (xj[d] + ts[d]);
-            lds_add_rows(Gq, r, ds, qi);
-            lds_add_rows(Gk, r, ds, xj);
-            lds_add_rows(Gv, r, pr, doi);
+            if (!(rc.dbg & 1)) {
+                lds_add_rows(Gq, r, ds, qi);
+                lds_add_rows(Gk, r, ds, xj);
+                lds_add_rows(Gv, r, pr, doi);
+            }
             // ---- this thread as KEY j = p against query i = pj
             rel_rows(rc, qcj, rj, qci, ri, r);
             float qj[kHd], doj[kHd];
@@ -330,17 +335,317 @@ sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
 #pragma unroll
         for (int d = 0; d < kHd; ++d) { o1[d] = dqi[d]; o2[d] = dki[d]; o3[d] = dvi[d]; }
     }
-    __syncthreads();
-    // flush table gradients: [L,3,h,16] global layout
-    float *dst[3] = {dtq, dtk, dtv};
-    const int rows = L * 3;
-    for (int e = threadIdx.x; e < 3 * rows * kHd; e += blockDim.x) {
-        int tb = e / (rows * kHd);
-        int rem = e - tb * rows * kHd;
-        int row = rem / kHd, d = rem - row * kHd;
-        float g = g_tab[(tb * rows + row) * kTabRow + d];
-        if (g != 0.f) atomicAdd(dst[tb] + ((size_t)row * h + hh) * kHd + d, g);
     }
+    __syncthreads();
+    // this workgroup's table gradients -> its slab [3][L*3][16] (plain stores; summed in a fixed
+    // order by sptr_table_reduce_kernel: float atomics from every workgroup to the same few
+    // thousand addresses ran at ~1.5 G atomics/s and were 90 % of the backward time)
+    const int rows = L * 3;
+    float *slab = slabs + ((size_t)blockIdx.x * h + hh) * 3 * rows * kHd;
+    for (int e = threadIdx.x; e < 3 * rows * kHd; e += blockDim.x) {
+        int row = e / kHd, d = e - row * kHd;     // row over [3 tables][rows]
+        slab[e] = g_tab[row * kTabRow + d];
+    }
+}
+
+
+// ---- backward, histogram form (the default) ----------------------------------------------------
+// LDS float atomics run at a small fraction of the LDS rate on gfx950 (144 of them per (query, key)
+// pair were 90 % of the backward above; tools/ab_sptr.py).  The table gradients are bilinear:
+//     dTq[ax][r] = sum_i q_i  (x) Hq_i[ax][r],   Hq_i[ax][r] = sum_{j : rel_ax(i,j) = r} ds_ij
+//     dTv[ax][r] = sum_i do_i (x) Hv_i[ax][r],   Hv_i = the same with p_ij
+//     dTk[ax][r] = sum_j k_j  (x) Hk_j[ax][r],   Hk_j[ax][r] = sum_{i : rel_ax(i,j) = r} ds_ij
+// i.e. the VECTOR is constant for the thread that owns the token and only a SCALAR goes to a row
+// chosen per pair.  Each thread keeps its scalar histograms in a private strip of LDS (plain
+// read-add-write, no atomics: for an affine axis the reachable rows of a token are the 24 values
+// base..base+23, for the radial exponential split all 2*qgl), and after the window walk the wave
+// contracts histograms with the token vectors on the MFMA unit: G[r][d] += sum_i P_i[r] * vec_i[d]
+// (16x16x4 f32, m = row, k = token, n = channel), accumulating in registers over all the tokens
+// the wave ever sees.  One slab of [3][L*3][16] per wave at the end, summed in a fixed order.
+constexpr int kNB = 25;                       // quantised coordinates per affine axis the strips can hold (0..24: the
+                                              // configs give window / quant = 24 up to float rounding)
+constexpr int kHistAx = 2 * kNB;              // offset of axis 2's bins; axis 2 gets 2*kNB bins (radial split)
+constexpr int kHistTab = 4 * kNB;             // bins of one table: 24 + 24 + 48
+constexpr int kVecRow = kHd + 1;              // LDS stride of a staged token vector
+
+__device__ __forceinline__ int hist_base(const RelCtx &c, int coord, bool as_query) {
+    // smallest row a token with quantised coordinate `coord` can reach on an affine axis
+    int b = as_query ? coord - (kNB - 1) + c.qgl - 1 : 0 - coord + c.qgl - 1;
+    if (c.a > 0.f) b = min(max(b, 0), 2 * c.qgl - 1);
+    return b;
+}
+
+// P_i[r] of one table/axis from a private histogram strip
+__device__ __forceinline__ float hist_row(const float *hist, int ax, int base, int r, bool sphere) {
+    if (ax == 2 && sphere) return r < 2 * kNB ? hist[kHistAx + r] : 0.f;
+    int bin = r - base;
+    return (bin >= 0 && bin < kNB) ? hist[ax * kNB + bin] : 0.f;
+}
+
+// wave-private contraction of the 64 tokens of this wave: acc[ax][rb] += P^T vec
+template <int NT>
+__device__ __forceinline__ void hist_contract(const float *s_hist, int hs, const float *s_vec, const int *s_base,
+                                              int wave, int lane, bool sphere, f32x4 (&acc)[NT][3][3]) {
+    const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int tb = 0; tb < NT; ++tb) {
+        for (int ks = 0; ks < 16; ++ks) {
+            const int i = 64 * wave + 4 * ks + kq;               // token (thread) index in the workgroup
+            const float bvec = s_vec[(tb * kSptrThreads + i) * kVecRow + col];
+            const float *hist = s_hist + (size_t)i * hs + tb * kHistTab;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const int base = s_base[i * 3 + ax];
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) {
+                    float a = hist_row(hist, ax, base, 16 * rb + col, sphere);
+                    acc[tb][ax][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bvec, acc[tb][ax][rb], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void hist_store_slab(float *slab, const int (&table_of)[NT], int L, int lane,
+                                                const f32x4 (&acc)[NT][3][3]) {
+    const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    int r = 16 * rb + 4 * kq + reg;
+                    if (r < L) slab[((size_t)table_of[tb] * L * 3 + r * 3 + ax) * kHd + col] = acc[tb][ax][rb][reg];
+                }
+}
+
+// query role: dq_i, and the Tq / Tv table gradients
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                      const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
+                      const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
+                      const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
+                      const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
+                      const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
+                      float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    constexpr int NT = 2, HS = NT * kHistTab + 1;
+    const int hh = blockIdx.y;
+    const int tabf = L * 3 * kTabRow;
+    float *s_hist = s_tab + 3 * tabf;                              // [threads][HS]
+    float *s_vec = s_hist + kSptrThreads * HS;                     // [NT][threads][kVecRow]
+    int *s_base = reinterpret_cast<int *>(s_vec + NT * kSptrThreads * kVecRow);   // [threads][3]
+    load_tables(s_tab, tq, tk, tv, L, h, hh);
+    __syncthreads();
+    const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool sphere = rc.a > 0.f;
+    const size_t hc = (size_t)h * kHd;
+    float *hist = s_hist + (size_t)tid * HS;
+    f32x4 acc[NT][3][3];
+#pragma unroll
+    for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) acc[tb][ax][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t nblk = (n + kSptrThreads - 1) / kSptrThreads;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t p = blk * kSptrThreads + tid;
+        for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        float qi[kHd], doi[kHd];
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) { qi[d] = 0.f; doi[d] = 0.f; }
+        int base[3] = {0, 0, 0};
+        if (p < n) {
+            const int64_t t = sort_idx[p];
+            int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
+            float ri = radial ? radial[p] : 0.f;
+            const int ws = wstart[p], wl = wlen[p];
+            load16(q + t * hc + hh * kHd, qi);
+            load16(dout + t * hc + hh * kHd, doi);
+            const float lse_i = lse[p * h + hh], del_i = delta[p * h + hh];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) base[ax] = hist_base(rc, qci[ax], true);
+            float dqi[kHd];
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) dqi[d] = 0.f;
+            for (int jj = 0; jj < wl; ++jj) {
+                const int pj = ws + jj;
+                const int64_t tj = sort_idx[pj];
+                int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
+                float rj = radial ? radial[pj] : 0.f;
+                float xj[kHd], ts[kHd], tks[kHd];
+                int r[3];
+                rel_rows(rc, qci, ri, qcj, rj, r);
+                load16(k + tj * hc + hh * kHd, xj);
+                tab_sum(Tq, r, ts);
+                tab_sum(Tk, r, tks);
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) s += qi[d] * (xj[d] + ts[d]) + xj[d] * tks[d];
+                float pr = __expf(s - lse_i);
+                float vj[kHd], tvs[kHd];
+                load16(v + tj * hc + hh * kHd, vj);
+                tab_sum(Tv, r, tvs);
+                float dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) dp += doi[d] * (vj[d] + tvs[d]);
+                float ds = pr * (dp - del_i);
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) dqi[d] += ds * (xj[d] + ts[d]);
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool radial_ax = ax == 2 && sphere;
+                    const int bin = radial_ax ? r[2] : r[ax] - base[ax];
+                    if ((unsigned)bin < (unsigned)(radial_ax ? 2 * kNB : kNB)) {   // always true for qc_span <= kNB
+                        const int off = radial_ax ? kHistAx + bin : ax * kNB + bin;
+                        hist[off] += ds;                    // Hq
+                        hist[kHistTab + off] += pr;         // Hv
+                    }
+                }
+            }
+            float *o1 = dq + t * hc + hh * kHd;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) o1[d] = dqi[d];
+        }
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) {
+            s_vec[(0 * kSptrThreads + tid) * kVecRow + d] = qi[d];
+            s_vec[(1 * kSptrThreads + tid) * kVecRow + d] = doi[d];
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        if (!(rc.dbg & 64)) hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int table_of[NT] = {0, 2};
+    float *slab = slabs + (((size_t)blockIdx.x * 2 + wave) * h + hh) * 3 * L * 3 * kHd;
+    hist_store_slab<NT>(slab, table_of, L, lane, acc);
+}
+
+// key role: dk_j, dv_j and the Tk table gradient
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                    const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
+                    const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
+                    const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
+                    const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
+                    const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dk,
+                    float *__restrict__ dv, float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    constexpr int NT = 1, HS = NT * kHistTab + 1;
+    const int hh = blockIdx.y;
+    const int tabf = L * 3 * kTabRow;
+    float *s_hist = s_tab + 3 * tabf;
+    float *s_vec = s_hist + kSptrThreads * HS;
+    int *s_base = reinterpret_cast<int *>(s_vec + NT * kSptrThreads * kVecRow);
+    load_tables(s_tab, tq, tk, tv, L, h, hh);
+    __syncthreads();
+    const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool sphere = rc.a > 0.f;
+    const size_t hc = (size_t)h * kHd;
+    float *hist = s_hist + (size_t)tid * HS;
+    f32x4 acc[NT][3][3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) acc[0][ax][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int64_t nblk = (n + kSptrThreads - 1) / kSptrThreads;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t p = blk * kSptrThreads + tid;
+        for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        float ki[kHd];
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) ki[d] = 0.f;
+        int base[3] = {0, 0, 0};
+        if (p < n) {
+            const int64_t t = sort_idx[p];
+            int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
+            float ri = radial ? radial[p] : 0.f;
+            const int ws = wstart[p], wl = wlen[p];
+            float vi[kHd];
+            load16(k + t * hc + hh * kHd, ki);
+            load16(v + t * hc + hh * kHd, vi);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) base[ax] = hist_base(rc, qci[ax], false);
+            float dki[kHd], dvi[kHd];
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) { dki[d] = 0.f; dvi[d] = 0.f; }
+            for (int jj = 0; jj < wl; ++jj) {
+                const int pj = ws + jj;                       // the QUERY of this pair
+                const int64_t tj = sort_idx[pj];
+                int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
+                float rj = radial ? radial[pj] : 0.f;
+                int r[3];
+                rel_rows(rc, qcj, rj, qci, ri, r);
+                float qj[kHd], doj[kHd], ts[kHd], tks[kHd], tvs[kHd];
+                load16(q + tj * hc + hh * kHd, qj);
+                load16(dout + tj * hc + hh * kHd, doj);
+                tab_sum(Tq, r, ts);
+                tab_sum(Tk, r, tks);
+                float s2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) s2 += qj[d] * (ki[d] + ts[d]) + ki[d] * tks[d];
+                float pr2 = __expf(s2 - lse[pj * h + hh]);
+                tab_sum(Tv, r, tvs);
+                float dp2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) dp2 += doj[d] * (vi[d] + tvs[d]);
+                float ds2 = pr2 * (dp2 - delta[pj * h + hh]);
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) {
+                    dki[d] += ds2 * (qj[d] + tks[d]);
+                    dvi[d] += pr2 * doj[d];
+                }
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool radial_ax = ax == 2 && sphere;
+                    const int bin = radial_ax ? r[2] : r[ax] - base[ax];
+                    if ((unsigned)bin < (unsigned)(radial_ax ? 2 * kNB : kNB))
+                        hist[(radial_ax ? kHistAx : ax * kNB) + bin] += ds2;   // Hk
+                }
+            }
+            float *o2 = dk + t * hc + hh * kHd, *o3 = dv + t * hc + hh * kHd;
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) { o2[d] = dki[d]; o3[d] = dvi[d]; }
+        }
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) s_vec[tid * kVecRow + d] = ki[d];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (!(rc.dbg & 64)) hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int table_of[NT] = {1};
+    float *slab = slabs + (((size_t)blockIdx.x * 2 + wave) * h + hh) * 3 * L * 3 * kHd;
+    hist_store_slab<NT>(slab, table_of, L, lane, acc);
+}
+
+// dt[tb][row][hh][d] = sum over the G slabs (ascending) -- deterministic
+__global__ void sptr_table_reduce_kernel(const float *__restrict__ slabs, int G, int L, int h, float *__restrict__ dtq,
+                                         float *__restrict__ dtk, float *__restrict__ dtv) {
+    const int rows = L * 3;
+    const int per = 3 * rows * kHd;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int hh = blockIdx.y;
+    if (e >= per) return;
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc += slabs[((size_t)g * h + hh) * per + e];
+    int tb = e / (rows * kHd);
+    int rem = e - tb * rows * kHd;
+    int row = rem / kHd, d = rem - row * kHd;
+    float *dst = tb == 0 ? dtq : (tb == 1 ? dtk : dtv);
+    dst[((size_t)row * h + hh) * kHd + d] = acc;
 }
 
 }  // namespace u2mkd
@@ -397,7 +702,7 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
                "u2mkd_sptr_attention_forward: null pointer");
     if (int rc = sptr_check("u2mkd_sptr_attention_forward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(split_a <= 0.f || radial, "u2mkd_sptr_attention_forward: spherical branch needs the radial coordinate");
-    RelCtx rc{qgl, split_a};
+    RelCtx rc{qgl, split_a, 0};
     size_t lds = (size_t)3 * L * 3 * kTabRow * sizeof(float);
     hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
                        as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk, tv,
@@ -405,29 +710,69 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
     return check_launch("u2mkd_sptr_attention_forward");
 }
 
+static int sptr_bwd_grid(int64_t n) {
+    int64_t nblk = ceil_div(n, kSptrThreads);
+    return (int)(nblk < 512 ? nblk : 512);
+}
+
+size_t u2mkd_sptr_backward_workspace_bytes(int64_t n, int32_t h, int32_t L) {
+    return (size_t)2 * sptr_bwd_grid(n) * h * 3 * L * 3 * kHd * sizeof(float);   // one slab per wave
+}
+
 int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
                                   const float *lse, const int32_t *sort_idx, const int32_t *wstart,
                                   const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
-                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n,
-                                  int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/, float *dq, float *dk,
-                                  float *dv, float *dtq /*pre-zeroed*/, float *dtk /*pre-zeroed*/,
-                                  float *dtv /*pre-zeroed*/, u2mkd_stream_t s) {
+                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a,
+                                  int32_t qc_span, int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
+                                  void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
+                                  float *dtk, float *dtv, u2mkd_stream_t s) {
     if (n == 0 || h == 0) return 0;
-    U2_REQUIRE(q && k && v && out && dout && lse && sort_idx && wstart && wlen && qc && tq && tk && tv && delta && dq &&
-                   dk && dv && dtq && dtk && dtv,
+    U2_REQUIRE(q && k && v && out && dout && lse && sort_idx && wstart && wlen && qc && tq && tk && tv && delta &&
+                   workspace && dq && dk && dv && dtq && dtk && dtv,
                "u2mkd_sptr_attention_backward: null pointer");
     if (int rc = sptr_check("u2mkd_sptr_attention_backward", n, h, hdim, L, qgl, split_a)) return rc;
-    RelCtx rc{qgl, split_a};
+    U2_REQUIRE(workspace_bytes >= u2mkd_sptr_backward_workspace_bytes(n, h, L),
+               "u2mkd_sptr_attention_backward: workspace too small");
+    const char *dbg_env = getenv("U2MKD_SPTR_DEBUG");
+    RelCtx rc{qgl, split_a, dbg_env ? atoi(dbg_env) : 0};
     hipStream_t st = as_stream(s);
     hipLaunchKernelGGL(sptr_delta_kernel, dim3((unsigned)ceil_div(n * h, 256)), dim3(256), 0, st, dout, out, sort_idx,
                        n, h, delta);
+    const int G = sptr_bwd_grid(n);
+    float *slabs = reinterpret_cast<float *>(workspace);
+    const float *rad = split_a > 0.f ? radial : nullptr;
+    const int per = 3 * L * 3 * kHd;
+    // histogram form: every token reaches at most kNB rows per affine axis (quantised coordinates in
+    // [0, qc_span), qc_span <= kNB) and 2*kNB rows on the radial axis; otherwise the generic kernel
+    const bool hist_ok = qc_span > 0 && qc_span <= kNB && qgl < kNB && L <= 48 && !(rc.dbg & 8);
+    if (hist_ok) {
+        const int tabf = L * 3 * kTabRow;
+        size_t lds_q = ((size_t)3 * tabf + (size_t)kSptrThreads * (2 * kHistTab + 1) + 2 * kSptrThreads * kVecRow +
+                        kSptrThreads * 3) * sizeof(float);
+        size_t lds_k = ((size_t)3 * tabf + (size_t)kSptrThreads * (kHistTab + 1) + kSptrThreads * kVecRow +
+                        kSptrThreads * 3) * sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_query_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+        if (!(rc.dbg & 32))   // (bits 16 / 32: timing experiments, skip one of the two kernels)
+            hipLaunchKernelGGL(sptr_bwd_query_kernel, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse,
+                               delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs);
+        if (!(rc.dbg & 16))
+            hipLaunchKernelGGL(sptr_bwd_key_kernel, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse,
+                               delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs);
+        hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs,
+                           2 * G, L, h, dtq, dtk, dtv);
+        return check_launch("u2mkd_sptr_attention_backward");
+    }
     size_t lds = (size_t)6 * L * 3 * kTabRow * sizeof(float);
     if (lds > 65536)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_attn_bwd_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(sptr_attn_bwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds, st,
-                       q, k, v, dout, lse, delta, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk,
-                       tv, L, rc, n, h, dq, dk, dv, dtq, dtk, dtv);
+    hipLaunchKernelGGL(sptr_attn_bwd_kernel, dim3(G, h), dim3(kSptrThreads), lds, st, q, k, v, dout, lse, delta,
+                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, dk, dv, slabs);
+    hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, G, L, h,
+                       dtq, dtk, dtv);
     return check_launch("u2mkd_sptr_attention_backward");
 }
 

@@ -66,7 +66,11 @@ class WindowPlan:
             w = self.window_size
             L.call('u2mkd_sptr_quant_coords', L.ptr(xyz), L.ptr(self.sort_idx), self.n, L.ptr(self.lo), w[0], w[1],
                    w[2], q[0], q[1], q[2], L.ptr(qc), L.ptr(radial), L.stream())
-            hit = (qc, radial)
+            # host-known bound on the quantised coordinates of the affine axes (x, y and, in the cubic
+            # branch, z): qc = floor((v mod w) / q) <= floor(w / q)
+            axes = (0, 1) if want_radial else (0, 1, 2)
+            span = max(int(np.floor(np.float64(w[d]) / np.float64(q[d]))) + 1 for d in axes)
+            hit = (qc, radial, span)
             self._qc[key] = hit
         return hit
 
@@ -77,7 +81,7 @@ class WindowPlan:
 
 class WindowAttentionFunction(Function):
     @staticmethod
-    def forward(ctx, q, k, v, tq, tk, tv, plan, qc, radial, qgl, split_a):
+    def forward(ctx, q, k, v, tq, tk, tv, plan, qc, radial, qgl, split_a, qc_span=0):
         L.require_cuda(q, k, v, tq, tk, tv)
         q, k, v = (t.contiguous().float() for t in (q, k, v))
         tq, tk, tv = (t.contiguous().float() for t in (tq, tk, tv))
@@ -97,6 +101,7 @@ class WindowAttentionFunction(Function):
                float(split_a), n, h, d, L.ptr(out), L.ptr(lse), L.stream())
         ctx.save_for_backward(q, k, v, out, lse, tq, tk, tv, qc, radial if radial is not None else q.new_empty(0))
         ctx.plan, ctx.qgl, ctx.split_a, ctx.has_radial = plan, int(qgl), float(split_a), radial is not None
+        ctx.qc_span = int(qc_span)
         return out
 
     @staticmethod
@@ -105,7 +110,7 @@ class WindowAttentionFunction(Function):
             qs, ts = ctx.shapes
             z = dout.new_zeros(qs)
             t = dout.new_zeros(ts)
-            return z, z, z, t, t, t, None, None, None, None, None
+            return z, z, z, t, t, t, None, None, None, None, None, None
         q, k, v, out, lse, tq, tk, tv, qc, radial = ctx.saved_tensors
         plan = ctx.plan
         dout = dout.contiguous().float()
@@ -113,12 +118,15 @@ class WindowAttentionFunction(Function):
         tl = tq.shape[0]
         delta = torch.empty(n, h, dtype=torch.float32, device=q.device)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        dtq, dtk, dtv = torch.zeros_like(tq), torch.zeros_like(tk), torch.zeros_like(tv)
+        dtq, dtk, dtv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
+        nbytes = L.load().u2mkd_sptr_backward_workspace_bytes(n, h, tl)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
         L.call('u2mkd_sptr_attention_backward', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse),
                L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(qc),
                L.ptr(radial) if ctx.has_radial else None, L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, ctx.qgl, ctx.split_a,
-               n, h, d, L.ptr(delta), L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dtq), L.ptr(dtk), L.ptr(dtv), L.stream())
-        return dq, dk, dv, dtq, dtk, dtv, None, None, None, None, None
+               ctx.qc_span, n, h, d, L.ptr(delta), L.ptr(ws), nbytes, L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(dtq), L.ptr(dtk), L.ptr(dtv),
+               L.stream())
+        return dq, dk, dv, dtq, dtk, dtv, None, None, None, None, None, None
 
 
 def window_attention(q, k, v, xyz, plan: WindowPlan, quant_size, quant_grid_length, table_q, table_k, table_v,
@@ -126,9 +134,9 @@ def window_attention(q, k, v, xyz, plan: WindowPlan, quant_size, quant_grid_leng
     """softmax over each token's window of (q.k + q.Tq(rel) + k.Tk(rel)) applied to (v + Tv(rel));
     q,k,v [N,h,16] (q pre-scaled), tables [L,3,h,16]; ``split_a`` selects the spherical branch."""
     sphere = split_a is not None
-    qc, radial = plan.quant_coords(xyz, quant_size, sphere)
+    qc, radial, span = plan.quant_coords(xyz, quant_size, sphere)
     return WindowAttentionFunction.apply(q, k, v, table_q, table_k, table_v, plan, qc, radial,
-                                         int(quant_grid_length), float(split_a) if sphere else 0.0)
+                                         int(quant_grid_length), float(split_a) if sphere else 0.0, span)
 
 
 def get_indices_params(xyz, batch, window_size, shift_win: bool):
