@@ -76,10 +76,11 @@ def test_hip_l2c_scatter_matches_reference_loop(hip, idx):
 
 
 @pytest.mark.gpu
-def test_hip_c2l_gather_matches_reference_loop(hip):
+@pytest.mark.parametrize('channels', [12, 17])
+def test_hip_c2l_gather_matches_reference_loop(hip, channels):
     b = synth_kd_batch(700, 2, seed=4, image_hw=(64, 112))
     pc, ms = _kd_tensors(b)
-    fmaps = torch.randn(2, 6, 12, 16, 28, dtype=torch.float64, requires_grad=True)
+    fmaps = torch.randn(2, 6, channels, 16, 28, dtype=torch.float64, requires_grad=True)
     want = FR.c2l_loop(fmaps, [c.double() for c in pc], ms)
     g = torch.randn_like(want)
     want.backward(g)

@@ -129,13 +129,15 @@ def _c2l_plan(pixel_coordinates, masks, h, w):
 def c2l_gather(feature_maps, pixel_coordinates, masks):
     """Camera -> LiDAR gather.  feature_maps [B, ncam, C, h, w]; per sample coordinates
     [ncam, N_b, 2] and masks [ncam, N_b].  Returns [sum N_b, C], zeros outside every camera."""
-    if not (feature_maps.is_cuda and feature_maps.shape[2] % 4 == 0):
+    if not feature_maps.is_cuda:
         return _c2l_gather_torch(feature_maps, pixel_coordinates, masks)
     from .torchsparse.nn import functional as spf
     B, ncam, C, h, w = feature_maps.shape
     idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w))
     rows = feature_maps.permute(0, 1, 3, 4, 2).reshape(B * ncam * h * w, C)
-    return spf.spdevoxelize(rows, idx8, w8)
+    if C % 4:                                   # e.g. the 17-class logit map: pad rows to whole 16-byte segments
+        rows = F.pad(rows, (0, 4 - C % 4))
+    return spf.spdevoxelize(rows, idx8, w8)[:, :C]
 
 
 def _c2l_gather_torch(feature_maps, pixel_coordinates, masks):
