@@ -214,6 +214,24 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
                       const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
                       float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx /*[n,c]*/, u2mkd_stream_t s);
 
+/* SyncBatchNorm (utils.py:138-220, train_spformer.py:79) in pieces, so the caller can put ONE small
+ * collective between them: local (mean, M2, count) -> all_gather -> merge in rank order (Chan) ->
+ * normalise(+ReLU); backward: local (sum dy', sum dy'*xhat) -> all_reduce -> apply with the global
+ * count.  stats rows are [2c+1] = mean[c], M2[c], count.                                        */
+int u2mkd_bn_local_stats(const float *x, int64_t n, int32_t c, float *partial /*[slabs,2,c]*/, float *stats /*[2c+1]*/,
+                         u2mkd_stream_t s);
+int u2mkd_bn_merge_stats(const float *gathered /*[world,2c+1]*/, int32_t world, int32_t c, float eps, float momentum,
+                         float *running_mean, float *running_var, float *mean /*[c]*/, float *invstd /*[c]*/,
+                         float *total /*[1]*/, u2mkd_stream_t s);
+int u2mkd_bn_apply(const float *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
+                   const float *beta, int32_t relu, float *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_local(const float *dy, const float *x, int64_t n, int32_t c, const float *mean,
+                            const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                            float *partial /*[slabs,2,c]*/, float *sums /*[2c]: dbeta, dgamma*/, u2mkd_stream_t s);
+int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t c, const float *total_n /*[1] device*/,
+                            const float *mean, const float *invstd, const float *gamma, const float *beta,
+                            int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx, u2mkd_stream_t s);
+
 /* ---- SphereFormer / sptr window attention ---------------------------------------
  * replaces the extern "C" launchers of third_party/SparseTransformer/src/sptr:
  *   precompute_all_cuda_launcher            (precompute/precompute_cuda_kernel.h)

@@ -83,6 +83,7 @@ def test_ddp_syncbn_path_on_gpu_single_rank(hip):
         from u2mkd_amd import torchsparse as ts
         from u2mkd_amd.losses import MixLovaszCrossEntropy
         crit = MixLovaszCrossEntropy(ignore_index=0)
+        os.environ['U2MKD_FORCE_SYNC_BN'] = '1'     # take the synchronising BatchNorm path although world_size == 1
         losses = []
         for _ in range(3):
             out = net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
@@ -93,5 +94,38 @@ def test_ddp_syncbn_path_on_gpu_single_rank(hip):
             losses.append(float(loss.detach()))
         assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 1.0
         assert D.max_over_ranks(1.5) == 1.5
+        _check_hip_sync_bn_pieces(lidar)
     finally:
+        os.environ.pop('U2MKD_FORCE_SYNC_BN', None)
         dist.destroy_process_group()
+
+
+def _check_hip_sync_bn_pieces(lidar):
+    """The SyncBatchNorm path (local stats | all_gather | merge | apply; local sums | all_reduce | apply)
+    forced on at world_size 1: must reproduce the fused single-GPU BatchNorm(+ReLU) and its running stats."""
+    import os
+    from u2mkd_amd.lidar.blocks import PointBatchNorm1d
+    from u2mkd_amd.lidar.point_voxel import PointSyncBatchNorm1d
+    from u2mkd_amd.torchsparse.nn import functional as spf
+    torch.manual_seed(3)
+    for n, c, relu in ((5000, 32, True), (777, 96, False), (2, 64, True)):
+        ref = PointBatchNorm1d(c).cuda().train()
+        with torch.no_grad():
+            ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+        syn = PointSyncBatchNorm1d(c).cuda().train()
+        syn.load_state_dict(ref.state_dict())
+        x = torch.randn(n, c, device='cuda') * 2 + 1
+        g = torch.randn(n, c, device='cuda')
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya = spf.batch_norm(xa, ref, relu)
+        os.environ['U2MKD_FORCE_SYNC_BN'] = '1'
+        yb = spf.batch_norm(xb, syn, relu)
+        os.environ.pop('U2MKD_FORCE_SYNC_BN')
+        ya.backward(g); yb.backward(g)
+        assert float((ya - yb).abs().max()) < 1e-5
+        assert float((xa.grad - xb.grad).abs().max()) < 1e-5
+        assert float((ref.weight.grad - syn.weight.grad).abs().max()) < 1e-3 * max(1.0, float(ref.weight.grad.abs().max()))
+        assert float((ref.bias.grad - syn.bias.grad).abs().max()) < 1e-3 * max(1.0, float(ref.bias.grad.abs().max()))
+        assert float((ref.running_mean - syn.running_mean).abs().max()) < 1e-6
+        assert float((ref.running_var - syn.running_var).abs().max()) < 1e-5
+        assert int(syn.num_batches_tracked) == 1

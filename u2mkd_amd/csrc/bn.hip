@@ -96,7 +96,7 @@ constexpr int kBnFinLanes = 64, kBnFinCh = 4;
 __global__ void __launch_bounds__(256)
 bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
                          float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
-                         float *__restrict__ mean_out, float *__restrict__ invstd_out) {
+                         float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ m2_out) {
     __shared__ float s_n[kBnFinLanes][kBnFinCh], s_m[kBnFinLanes][kBnFinCh], s_q[kBnFinLanes][kBnFinCh];
     const int cl = threadIdx.x & (kBnFinCh - 1), g = threadIdx.x / kBnFinCh;
     const int ch = blockIdx.x * kBnFinCh + cl;
@@ -136,6 +136,11 @@ bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n
     }
     float var = m2 / (float)n;
     mean_out[ch] = mean;
+    if (m2_out) {   // local statistics only (cross-rank merge follows): stats row = mean[c], M2[c], count
+        m2_out[ch] = m2;
+        if (ch == 0) m2_out[c] = (float)n;
+        return;
+    }
     invstd_out[ch] = 1.f / sqrtf(var + eps);
     if (running_mean) {
         float unbiased = n > 1 ? m2 / (float)(n - 1) : var;
@@ -250,12 +255,14 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, floa
 }
 
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
-                                    float inv_n, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                    float inv_n_host, const float *__restrict__ total_n,
+                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                     const float *__restrict__ dbeta, const float *__restrict__ dgamma,
                                     float *__restrict__ dx) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
+    const float inv_n = total_n ? 1.f / *total_n : inv_n_host;     // SyncBatchNorm: the count of all ranks
     int j = (int)(t % c4) * 4;
     float4 v = reinterpret_cast<const float4 *>(x)[t];
     float4 d = reinterpret_cast<const float4 *>(dy)[t];
@@ -308,6 +315,37 @@ __global__ void bn_invstd_kernel(const float *__restrict__ var, int c, float eps
     if (ch < c) invstd[ch] = 1.f / sqrtf(var[ch] + eps);
 }
 
+// SyncBatchNorm: merge the per-rank (mean, M2, count) triples (rank order, Chan's update), write
+// mean / invstd of the global batch and update the running statistics; stats rows are [2c+1].
+__global__ void bn_sync_merge_kernel(const float *__restrict__ gathered, int world, int c, float eps, float momentum,
+                                     float *__restrict__ running_mean, float *__restrict__ running_var,
+                                     float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                                     float *__restrict__ total_out) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const int row = 2 * c + 1;
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    for (int r = 0; r < world; ++r) {
+        float nb = gathered[(size_t)r * row + 2 * c];
+        if (nb == 0.f) continue;
+        float mb = gathered[(size_t)r * row + ch], qb = gathered[(size_t)r * row + c + ch];
+        float tot = na + nb;
+        float delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += qb + delta * delta * (na * nb / tot);
+        na = tot;
+    }
+    float var = na > 0.f ? m2 / na : 0.f;
+    mean_out[ch] = mean;
+    invstd_out[ch] = 1.f / sqrtf(var + eps);
+    if (ch == 0) *total_out = na;
+    if (running_mean) {
+        float unbiased = na > 1.f ? m2 / (na - 1.f) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+}
+
 static size_t bn_lds_bytes(int c, int arrays) {
     int c4 = c / 4;
     int rl = c4 >= kBnThreads ? 1 : kBnThreads / c4;
@@ -334,7 +372,7 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
-                       eps, momentum, running_mean, running_var, mean, invstd);
+                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
                        invstd, gamma, beta, relu, y);
@@ -370,11 +408,81 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
     int64_t total4 = n * (c / 4);
     if (training)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
-                           c / 4, 1.f / (float)n, mean, invstd, gamma, beta, relu, dbeta, dgamma, dx);
+                           c / 4, 1.f / (float)n, (const float *)nullptr, mean, invstd, gamma, beta, relu, dbeta, dgamma,
+                           dx);
     else
         hipLaunchKernelGGL(bn_bwd_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
                            c / 4, mean, invstd, gamma, beta, relu, dx);
     return check_launch("u2mkd_bn_backward");
+}
+
+/* ---- SyncBatchNorm pieces: local statistics | (all_gather by the caller) | merge | apply, and
+ * local sums | (all_reduce by the caller) | apply in the backward ---- */
+int u2mkd_bn_local_stats(const float *x, int64_t n, int32_t c, float *partial, float *stats /*[2c+1]*/,
+                         u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_local_stats: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(stats && (n == 0 || (x && partial)), "u2mkd_bn_local_stats: null pointer");
+    hipStream_t st = as_stream(s);
+    if (n == 0) {
+        (void)hipMemsetAsync(stats, 0, (size_t)(2 * c + 1) * sizeof(float), st);
+        return check_launch("u2mkd_bn_local_stats");
+    }
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab,
+                       n, c, 0.f, 0.f, (float *)nullptr, (float *)nullptr, stats, (float *)nullptr, stats + c);
+    return check_launch("u2mkd_bn_local_stats");
+}
+
+int u2mkd_bn_merge_stats(const float *gathered /*[world,2c+1]*/, int32_t world, int32_t c, float eps, float momentum,
+                         float *running_mean, float *running_var, float *mean, float *invstd, float *total,
+                         u2mkd_stream_t s) {
+    U2_REQUIRE(gathered && mean && invstd && total && world > 0 && c > 0, "u2mkd_bn_merge_stats: bad arguments");
+    hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, as_stream(s), gathered, world, c,
+                       eps, momentum, running_mean, running_var, mean, invstd, total);
+    return check_launch("u2mkd_bn_merge_stats");
+}
+
+int u2mkd_bn_apply(const float *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
+                   const float *beta, int32_t relu, float *y, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_apply: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(x && mean && invstd && y, "u2mkd_bn_apply: null pointer");
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), x, total4,
+                       c / 4, mean, invstd, gamma, beta, relu, y);
+    return check_launch("u2mkd_bn_apply");
+}
+
+int u2mkd_bn_backward_local(const float *dy, const float *x, int64_t n, int32_t c, const float *mean,
+                            const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
+                            float *sums /*[2c]: dbeta, dgamma of this rank*/, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward_local: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(sums, "u2mkd_bn_backward_local: null pointer");
+    hipStream_t st = as_stream(s);
+    if (n == 0) {
+        (void)hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st);
+        return check_launch("u2mkd_bn_backward_local");
+    }
+    U2_REQUIRE(dy && x && mean && invstd && partial, "u2mkd_bn_backward_local: null pointer");
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
+                       invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
+                       sums, sums + c);
+    return check_launch("u2mkd_bn_backward_local");
+}
+
+int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t c, const float *total_n,
+                            const float *mean, const float *invstd, const float *gamma, const float *beta,
+                            int32_t relu, const float *sums /*[2c] summed over ranks*/, float *dx, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_backward_apply: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(dy && x && total_n && mean && invstd && sums && dx, "u2mkd_bn_backward_apply: null pointer");
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), dy, x,
+                       total4, c / 4, 0.f, total_n, mean, invstd, gamma, beta, relu, sums, sums + c, dx);
+    return check_launch("u2mkd_bn_backward_apply");
 }
 
 }  // extern "C"

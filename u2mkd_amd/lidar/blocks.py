@@ -31,6 +31,10 @@ class PointBatchNorm1d(nn.BatchNorm1d):
         return spf.batch_norm(input, self)
 
 
+# BatchNorm flavours whose forward is spf.batch_norm (plain and the SyncBatchNorm conversions of point_voxel.py)
+_FUSABLE_BN = ('BatchNorm', 'PointBatchNorm1d', 'SparseSyncBatchNorm', 'PointSyncBatchNorm1d')
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential with the reference's layout (same state-dict keys) whose forward
     runs every BatchNorm -> ReLU pair as ONE fused HIP pass (BN statistics, normalise,
@@ -42,7 +46,7 @@ class FusedSequential(nn.Sequential):
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            fusable = (type(m) in (spnn.BatchNorm, PointBatchNorm1d) and type(nxt) in (spnn.ReLU, nn.ReLU))
+            fusable = (type(m).__name__ in _FUSABLE_BN and type(nxt) in (spnn.ReLU, nn.ReLU))
             if fusable:
                 if isinstance(x, SparseTensor):
                     x = fapply(x, spf.batch_norm, m, True)

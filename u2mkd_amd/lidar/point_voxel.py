@@ -98,17 +98,31 @@ def fetch_idx(source_coords: torch.Tensor, target_coords: torch.Tensor) -> torch
     return spf.sphashquery(spf.sphash(source_coords), spf.sphash(target_coords))
 
 
+class PointSyncBatchNorm1d(nn.SyncBatchNorm):
+    """SyncBatchNorm over point features [N, C] (the converted nn.BatchNorm1d of the point branch)
+    on the HIP SyncBatchNorm pieces (one small collective per pass); CPU tensors take torch's."""
+
+    def forward(self, input):
+        if input.is_cuda and input.dim() == 2:
+            return spf.batch_norm(input, self)
+        return super().forward(input)
+
+
 class SparseSyncBatchNorm(nn.SyncBatchNorm):
-    """SyncBatchNorm over SparseTensor features (utils.py:138-220)."""
+    """SyncBatchNorm over SparseTensor features (utils.py:138-220): statistics over the voxels of
+    ALL ranks; on the HIP device through spf.batch_norm (local slab statistics, one all_gather of
+    [2C+1] floats, merge, fused normalise[+ReLU])."""
 
     def forward(self, input: SparseTensor) -> SparseTensor:
+        if input.F.is_cuda:
+            return fapply(input, spf.batch_norm, self)
         return fapply(input, super().forward)
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
         out = module
         if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
-            klass = SparseSyncBatchNorm if isinstance(module, spnn.BatchNorm) else torch.nn.SyncBatchNorm
+            klass = SparseSyncBatchNorm if isinstance(module, spnn.BatchNorm) else PointSyncBatchNorm1d
             out = klass(module.num_features, module.eps, module.momentum, module.affine,
                         module.track_running_stats, process_group)
             if module.affine:

@@ -769,6 +769,79 @@ class BatchNormFunction(Function):
                 None, None, None, None, None, None)
 
 
+class SyncBatchNormFunction(Function):
+    """SyncBatchNorm (+ fused ReLU) over the rows of [N, C] across the ranks of a process group:
+    local slab statistics -> ONE all_gather of [2C+1] floats -> Chan merge in rank order ->
+    normalise; backward: local sums -> ONE all_reduce of [2C] floats -> apply with the global count.
+    Same statistics as torch.nn.SyncBatchNorm (utils.py:138-220 converts every BatchNorm to it,
+    train_spformer.py:79), three kernels + one small collective per pass instead of torch's
+    stats / gather / elemt / ReLU kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world):
+        import torch.distributed as dist
+        L.require_cuda(x)
+        x = x.contiguous().float()
+        n, c = x.shape
+        dev = x.device
+        st = L.stream()
+        slabs = L.load().u2mkd_bn_num_slabs(n)
+        partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
+        stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+        L.call('u2mkd_bn_local_stats', L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
+        gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, stats, group=group)
+        else:
+            gathered.copy_(stats.view(1, -1))
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        total = torch.empty(1, dtype=torch.float32, device=dev)
+        L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(eps), float(momentum), L.ptr(running_mean),
+               L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.ptr(total), L.stream())
+        y = torch.empty_like(x)
+        L.call('u2mkd_bn_apply', L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
+               L.ptr(y), L.stream())
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, total)
+        ctx.relu, ctx.group, ctx.world = bool(relu), group, world
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, gamma, beta, mean, invstd, total = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        n, c = x.shape
+        dev = x.device
+        slabs = L.load().u2mkd_bn_num_slabs(n)
+        partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        L.call('u2mkd_bn_backward_local', L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+               L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
+        local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        if ctx.world > 1:
+            dist.all_reduce(sums, group=ctx.group)
+        dx = torch.empty_like(x)
+        L.call('u2mkd_bn_backward_apply', L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
+               L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.stream())
+        return (dx, local[c:] if gamma is not None else None, local[:c] if beta is not None else None,
+                None, None, None, None, None, None, None)
+
+
+def _sync_group(bn):
+    """(process group, world size) if `bn` is a SyncBatchNorm that has to synchronise, else None."""
+    if not (isinstance(bn, torch.nn.SyncBatchNorm) and bn.training):
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    if world > 1 or os.environ.get('U2MKD_FORCE_SYNC_BN') == '1':     # (the env knob: single-rank tests)
+        return group, world
+    return None
+
+
 def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool = False) -> torch.Tensor:
     """nn.BatchNorm1d semantics (training or eval, running statistics, momentum=None =
     cumulative average) on a [N, C] tensor, optionally fused with ReLU."""
@@ -780,8 +853,11 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
         bn.num_batches_tracked.add_(1)
         if bn.momentum is None:
             factor = 1.0 / float(bn.num_batches_tracked)
-    if training and x.shape[0] < 2:
-        raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
     rm = bn.running_mean if (not training or bn.track_running_stats) else None
     rv = bn.running_var if (not training or bn.track_running_stats) else None
+    sync = _sync_group(bn) if training else None
+    if sync is not None:
+        return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1])
+    if training and x.shape[0] < 2:
+        raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
     return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu)
