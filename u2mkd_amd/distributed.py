@@ -26,11 +26,14 @@ def init_from_env(backend: str | None = None):
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local)
-    if world_size > 1 and not dist.is_initialized():
+    force = os.environ.get('U2MKD_FORCE_DDP') == '1'     # measure the N>1 code path on one GPU
+    if (world_size > 1 or force) and not dist.is_initialized():
         backend = backend or ('nccl' if use_cuda else 'gloo')
         kwargs = {}
         if backend == 'nccl':
             kwargs['device_id'] = torch.device('cuda', local)
+        if force and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'))
         dist.init_process_group(backend, rank=rnk, world_size=world_size, **kwargs)
     return rnk, world_size, local
 
@@ -53,7 +56,7 @@ def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int 
     """DDP + (on GPU) SyncBatchNorm, as train_spformer.py:79-83.  Gradient buckets are
     all-reduced while backward is still running; ``gradient_as_bucket_view`` avoids a
     copy per bucket."""
-    if world() == 1:
+    if world() == 1 and os.environ.get('U2MKD_FORCE_DDP') != '1':
         return model
     on_gpu = next(model.parameters()).is_cuda
     if sync_bn and on_gpu:
