@@ -1,0 +1,128 @@
+"""Edge cases on the HIP path: empty and tiny inputs through every operator family
+(the reference's own tests cover empty / single-element cases for its ops)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ts_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def F(hip):
+    from u2mkd_amd.torchsparse.nn import functional as F
+    return F
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 65])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (96, 128)])
+def test_conv_tiny_maps_both_schedules(F, n, cin, cout):
+    rng = np.random.default_rng(n)
+    c = np.unique(np.concatenate([rng.integers(0, 4, (n, 3)), np.zeros((n, 1), np.int64)], 1), axis=0).astype(np.int32)
+    n = len(c)
+    km = F.build_kmap(_dev(c).view(-1, 4), (1, 1, 1), (3, 3, 3), (1, 1, 1))
+    x = torch.randn(n, cin)
+    w = torch.randn(27, cin, cout) / (27 * cin) ** 0.5
+    if n:
+        nbmaps, nbsizes, _, _ = R.build_kmap(c, 1, 3, 1)
+        want = R.conv_forward(x, w, nbmaps, nbsizes, (n, n))
+    else:
+        want = torch.zeros(0, cout)
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    out = F.ConvolutionFunction.apply(xd, wd, km, False)          # schedule chosen by the channel rule
+    assert out.shape == (n, cout)
+    if n:
+        assert float((out.cpu() - want).abs().max()) < 1e-4
+    out.sum().backward()
+    assert xd.grad.shape == x.shape and wd.grad.shape == w.shape
+    assert torch.isfinite(wd.grad).all() and torch.isfinite(xd.grad).all()
+    if n == 0:
+        assert float(wd.grad.abs().max()) == 0.0
+    # both schedules explicitly
+    wt = F._transpose_weights(w.cuda())
+    o1 = torch.zeros(n, cout, device='cuda')
+    o2 = torch.zeros(n, cout, device='cuda')
+    km.schedule(False).run(x.cuda(), wt, cout, 0, o1)
+    km.pair_schedule().run(x.cuda(), wt, cout, False, o2)
+    if n:
+        assert float((o1.cpu() - want).abs().max()) < 1e-4 and float((o2.cpu() - want).abs().max()) < 1e-4
+
+
+def test_strided_conv_on_single_voxel_and_empty(F):
+    for c in (np.zeros((0, 4), np.int32), np.array([[3, 5, 7, 0]], np.int32)):
+        km = F.build_kmap(_dev(c).view(-1, 4), (1, 1, 1), (2, 2, 2), (2, 2, 2))
+        n = len(c)
+        assert km.n_in == n and km.n_out == n
+        x = torch.randn(n, 32).cuda().requires_grad_(True)
+        w = torch.randn(8, 32, 64).cuda().requires_grad_(True)
+        y = F.ConvolutionFunction.apply(x, w, km, False)
+        assert y.shape == (n, 64)
+        z = F.ConvolutionFunction.apply(y, w.transpose(1, 2).contiguous(), km, True)      # back up
+        assert z.shape == (n, 32)
+        z.sum().backward()
+        assert x.grad.shape == (n, 32) and torch.isfinite(w.grad).all()
+
+
+def test_linear_bn_point_voxel_tiny(F):
+    from u2mkd_amd.lidar.blocks import PointBatchNorm1d
+    w = torch.randn(64, 32).cuda().requires_grad_(True)
+    b = torch.randn(64).cuda().requires_grad_(True)
+    for n in (0, 1, 3):
+        x = torch.randn(n, 32).cuda().requires_grad_(True)
+        y = F.linear(x, w, b)
+        assert y.shape == (n, 64)
+        y.sum().backward()
+        if n:
+            want = torch.nn.functional.linear(x.detach().cpu(), w.detach().cpu(), b.detach().cpu())
+            assert float((y.detach().cpu() - want).abs().max()) < 1e-5
+    bn = PointBatchNorm1d(64).cuda()
+    with pytest.raises(ValueError):
+        F.batch_norm(torch.randn(1, 64).cuda(), bn.train())           # nn.BatchNorm1d raises too
+    y = F.batch_norm(torch.randn(1, 64).cuda(), bn.eval(), relu=True)  # eval mode: any batch size
+    assert y.shape == (1, 64) and float(y.min()) >= 0.0
+    # voxelise / devoxelise with no points
+    counts = F.spcount(torch.zeros(0, dtype=torch.int32, device='cuda'), 5)
+    assert counts.tolist() == [0] * 5
+    out = F.spvoxelize(torch.zeros(0, 8, device='cuda'), torch.zeros(0, dtype=torch.int32, device='cuda'), counts)
+    assert out.shape == (5, 8) and float(out.abs().max()) == 0.0
+    out = F.spdevoxelize(torch.randn(5, 8, device='cuda'), torch.zeros(0, 8, dtype=torch.int32, device='cuda'),
+                         torch.zeros(0, 8, device='cuda'))
+    assert out.shape == (0, 8)
+
+
+def test_window_attention_single_token_windows(hip):
+    """Every token alone in its window: softmax over one key = 1, out = v + Tv(rel = 0)."""
+    from u2mkd_amd import sptr
+    n, h, d, qgl = 40, 2, 16, 24
+    xyz = (torch.arange(n).float().view(-1, 1) * torch.tensor([[10.0, 0.0, 0.0]])).cuda()      # 10 m apart
+    b = torch.zeros(n, dtype=torch.int32).cuda()
+    window, quant = np.array([0.6, 0.6, 0.6]), np.array([0.025] * 3)
+    plan = sptr.WindowPlan(xyz, b, window)
+    assert int(plan.wlen.max()) == 1
+    q, k, v = (torch.randn(n, h, d, device='cuda', requires_grad=True) for _ in range(3))
+    tq, tk, tv = (torch.randn(2 * qgl - 1, 3, h, d, device='cuda', requires_grad=True) for _ in range(3))
+    out = sptr.window_attention(q, k, v, xyz, plan, quant, qgl, tq, tk, tv, None)
+    want = v + tv[qgl - 1].sum(0).unsqueeze(0)
+    assert float((out - want).abs().max()) < 1e-5
+    out.sum().backward()
+    # (scores are recomputed in the backward in a different summation order: p = exp(s' - lse) = 1 +- 1e-5)
+    assert float((v.grad - 1.0).abs().max()) < 1e-4
+    assert float(q.grad.abs().max()) < 1e-4 and float(k.grad.abs().max()) < 1e-4      # softmax over one key
+    assert float((tv.grad[qgl - 1] - n).abs().max()) < 1e-2
+
+
+def test_spvcnn_step_on_a_tiny_scene(hip):
+    from u2mkd_amd import lidar, train as T
+    from u2mkd_amd.synth import synth_batch
+    b = synth_batch(60, 2, 3)
+    feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+    model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+    run = T.LidarStep(model)
+    l0 = float(run(feats, coords, labels))
+    l1 = float(run(feats, coords, labels))
+    assert np.isfinite(l0) and np.isfinite(l1)

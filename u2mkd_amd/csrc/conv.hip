@@ -1127,7 +1127,12 @@ size_t u2mkd_conv_wgrad_pairs_workspace_bytes(int64_t n_rows, int32_t ca, int32_
 int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs,
                            const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
                            size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
-    U2_REQUIRE(a && b && pairs && plan && workspace && dw, "u2mkd_conv_wgrad_pairs: null pointer");
+    U2_REQUIRE(dw, "u2mkd_conv_wgrad_pairs: null pointer");
+    if (n_rows == 0) {   // empty map: the gradient is zero
+        (void)hipMemsetAsync(dw, 0, (size_t)k * ca * cb * sizeof(float), as_stream(s));
+        return check_launch("u2mkd_conv_wgrad_pairs");
+    }
+    U2_REQUIRE(a && b && pairs && plan && workspace, "u2mkd_conv_wgrad_pairs: null pointer");
     U2_REQUIRE(ca > 0 && cb > 0 && ca % 4 == 0 && cb % 4 == 0,
                "u2mkd_conv_wgrad_pairs: ca=%d cb=%d must be positive multiples of 4", ca, cb);
     U2_REQUIRE(k > 0 && k <= 64, "u2mkd_conv_wgrad_pairs: kernel volume %d not in 1..64", k);

@@ -124,6 +124,9 @@ class VoxelizeFunction(Function):
         counts = _i32(counts).contiguous()
         n, c = feats.shape
         nv = counts.shape[0]
+        if n == 0:
+            ctx.for_backwards = (coords, counts, n)
+            return torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
         if c % 4 == 0:
             # deterministic scatter-mean: points grouped by voxel once per map, then a gather-sum
             order, seg = _plan(coords, 'vox_csr_%d' % nv, lambda: _csr_by_destination(coords, nv))
@@ -174,6 +177,8 @@ class DevoxelizeFunction(Function):
         coords, weights, nv = ctx.for_backwards
         g = grad_output.contiguous().float()
         n, c = g.shape
+        if n == 0:
+            return torch.zeros(nv, c, dtype=torch.float32, device=g.device), None, None
         if c % 4 == 0:
             def build():
                 keys = torch.where(weights != 0, coords, -1).view(-1)          # [n*8], zero-weight corners dropped
