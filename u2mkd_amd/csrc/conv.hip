@@ -537,7 +537,7 @@ __global__ void wgrad_plan_kernel(const int32_t *__restrict__ nbsizes, int K, in
     for (int k = 0; k < K; ++k) { plan[2 + k] = P; P += nbsizes[k]; }
     plan[2 + K] = P;
     int ch = (P + g_target - 1) / g_target;
-    if (ch < 256) ch = 256;
+    if (ch < 128) ch = 128;
     ch = (ch + cp - 1) / cp * cp;
     plan[0] = P;
     plan[1] = ch;
@@ -697,7 +697,8 @@ wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__rest
 }
 
 static int wgrad_g_target(int64_t n_rows, int k) {
-    int64_t g = (n_rows * (k < 8 ? k : 8) + 511) / 512;
+    static const int scale = getenv("U2MKD_WGRAD_GSCALE") ? atoi(getenv("U2MKD_WGRAD_GSCALE")) : 2;   // tuning knob (measured: 2 helps the <= 32k-voxel levels 5-10 %)
+    int64_t g = (n_rows * (k < 8 ? k : 8) * scale + 511) / 512;
     if (g < 32) g = 32;
     if (g > 768) g = 768;
     return (int)g;

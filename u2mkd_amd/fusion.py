@@ -231,7 +231,9 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
         up = grid if (ch, cw) == (ifh, ifw) else F.interpolate(grid, (ifh, ifw), mode='bilinear', align_corners=True)
         total = up if total is None else total + up
         cnt *= 2
-    return total / n_scales
+    # the grids are channel-last views; hand the camera branch (NCHW convs) a plain NCHW tensor so
+    # its skip additions do not mix memory formats (strided adds were 5 ms of the KD step)
+    return (total / n_scales).contiguous()
 
 
 def _l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
