@@ -38,7 +38,7 @@ def main():
         res = [f'ts={ts} N={n} P={p} {cin}->{cout}: v1 {t1*1e3:.0f}us v1-sorted {t1s*1e3:.0f}us']
         for var in (0,):
             if var % 100 == 64 and cin < 64: continue
-            if 3000 <= var < 50000 and cout % 64: continue
+            if 3000 <= var < 5000 and cout % 64: continue
             if var >= 50000 and (var - 50000) // 1000 * 16 > cout: continue
             t3 = ev(lambda: L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), tord, n, 27, 0, var, L.ptr(o3), st))
             e3 = float((o3 - o1).abs().max())

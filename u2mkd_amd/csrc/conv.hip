@@ -124,7 +124,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     bool act_cur = false, act_nxt = false;
 
     auto load_stage = [&](int k, int c, float4 (&a)[NJ], bool &active) {
-        const float *wk = wt + (size_t)(kflip ? K - 1 - k : k) * cout * cin;
+        const float *wk = wt + (size_t)((kflip & 1) ? K - 1 - k : k) * cout * cin;
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int f = tid + NT * p;
@@ -168,7 +168,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 if (km) { kn = __builtin_ctz(km); km &= km - 1; } else have_next = false;
             }
             if (have_next) load_stage(kn, cn, a_nxt, act_nxt);
-            if (act_cur) {
+            if (act_cur && !(kflip & 8)) {   // (kflip bit 3: timing experiment, skip the MFMAs)
                 const float *bb = Bs + (size_t)buf * TN * BS + r * BS + 4 * q;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
