@@ -32,9 +32,11 @@ def test_l2c_scatter_equals_reference_loop(idx):
     feats = torch.randn(sum(m.shape[1] for m in ms), 24, dtype=torch.float64)
     ifh, ifw = (32, 56) if idx == 0 else (8, 14)
     want = FR.l2c_loop(feats, [c.double() for c in pc], ms, ifh, ifw, 4, idx)
-    got = PF.l2c_scatter(feats, [c.double() for c in pc], ms, ifh, ifw, 4 - idx)
+    got = PF.l2c_scatter_torch(feats, [c.double() for c in pc], ms, ifh, ifw, 4 - idx)
     assert got.shape == want.shape
     assert float((got - want).abs().max()) < 1e-12
+    with pytest.raises(RuntimeError):
+        PF.l2c_scatter(feats, [c.double() for c in pc], ms, ifh, ifw, 4 - idx)     # product path: HIP device only
 
 
 def test_c2l_gather_equals_reference_loop():
@@ -42,7 +44,7 @@ def test_c2l_gather_equals_reference_loop():
     pc, ms = _kd_tensors(b)
     fmaps = torch.randn(2, 6, 10, 16, 28, dtype=torch.float64)
     want = FR.c2l_loop(fmaps, [c.double() for c in pc], ms)
-    got = PF.c2l_gather(fmaps, [c.double() for c in pc], ms)
+    got = PF.c2l_gather_torch(fmaps, [c.double() for c in pc], ms)
     assert float((got - want).abs().max()) < 1e-12
     fov = torch.from_numpy(b['student']['fov_mask'])
     assert float(got[~fov].abs().max()) == 0.0

@@ -15,15 +15,17 @@ On the HIP device both are the point<->voxel kernels in disguise: the pixel mean
 segment-sum (entries grouped by destination pixel, like spvoxelize), the bilinear gather is
 spdevoxelize with 4 corners, and each one's gradient is the other kind of segment-sum -- no
 atomics, bitwise reproducible.  (torch's ``index_add_`` / ``grid_sample`` backward resolve pixel
-collisions with float atomics: 46 ms + 152 ms of a 392 ms KD step on MI355X, profiles/.)  CPU
-tensors (the host-side tests) take the plain torch formulation of the same maths.
+collisions with float atomics: 46 ms + 152 ms of a 392 ms KD step on MI355X, profiles/.)  The
+plain torch formulations of the same maths are kept as ``l2c_scatter_torch`` / ``c2l_gather_torch``
+(pinned against the reference's loops by the host-side tests); the product functions run on the
+HIP device only.
 Fusion modules keep the reference's parameter names."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 __all__ = ['IA_Layer', 'Atten_Fusion_Conv', 'L2CAILayer', 'L2CFusion', 'feature_gather', 'c2l_gather',
-           'l2c_scatter', 'feature_fetch']
+           'l2c_scatter', 'feature_fetch', 'l2c_scatter_torch', 'c2l_gather_torch']
 
 
 class IA_Layer(nn.Module):
@@ -129,8 +131,8 @@ def _c2l_plan(pixel_coordinates, masks, h, w):
 def c2l_gather(feature_maps, pixel_coordinates, masks):
     """Camera -> LiDAR gather.  feature_maps [B, ncam, C, h, w]; per sample coordinates
     [ncam, N_b, 2] and masks [ncam, N_b].  Returns [sum N_b, C], zeros outside every camera."""
-    if not feature_maps.is_cuda:
-        return _c2l_gather_torch(feature_maps, pixel_coordinates, masks)
+    from . import _lib
+    _lib.require_cuda(feature_maps)                      # HIP device only; there is no CPU fallback
     from .torchsparse.nn import functional as spf
     B, ncam, C, h, w = feature_maps.shape
     idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w))
@@ -140,8 +142,9 @@ def c2l_gather(feature_maps, pixel_coordinates, masks):
     return spf.spdevoxelize(rows, idx8, w8)[:, :C]
 
 
-def _c2l_gather_torch(feature_maps, pixel_coordinates, masks):
-    """The same gather with grid_sample over every camera + a mask-priority select (CPU tensors)."""
+def c2l_gather_torch(feature_maps, pixel_coordinates, masks):
+    """The same gather written with torch ops only (grid_sample over every camera + a mask-priority
+    select): the formulation the host-side tests pin against the reference's Python loop."""
     out = []
     for fmap, coord, mask in zip(feature_maps, pixel_coordinates, masks):
         sampled = feature_gather(fmap, coord)                       # [ncam, C, N_b]
@@ -216,8 +219,10 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
     returns [B*ncam, C, ifh, ifw]: for scale s in 0..n_scales-1 the (masked) points of a camera are
     averaged per pixel of a (round(ifh/2^s + .01), round(ifw/2^s + .01)) grid, the grid is
     bilinearly up-sampled to (ifh, ifw), and the n_scales maps are averaged."""
-    if not (point_feats.is_cuda and point_feats.shape[1] % 4 == 0):
-        return _l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales)
+    from . import _lib
+    _lib.require_cuda(point_feats)                       # HIP device only; there is no CPU fallback
+    if point_feats.shape[1] % 4:
+        return l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales)   # torch ops on the GPU
     from .torchsparse.nn import functional as spf
     B, ncam, C = len(masks), masks[0].shape[0], point_feats.shape[1]
     total = None
@@ -236,8 +241,10 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
     return (total / n_scales).contiguous()
 
 
-def _l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
-    """The same map with index_add_ (CPU tensors / channel counts that are not multiples of 4)."""
+def l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
+    """The same map written with torch ops only (index_add_ per scale): the formulation the host-side
+    tests pin against the reference's Python loop, and the path for channel counts that are not
+    multiples of 4.  Not used by l2c_scatter for anything the HIP kernels cover."""
     B = len(masks)
     ncam = masks[0].shape[0]
     C = point_feats.shape[1]
