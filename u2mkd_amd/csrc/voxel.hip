@@ -150,7 +150,23 @@ __global__ void segment_sum_kernel(const float *__restrict__ src, int c4, const 
     int j = (int)(t - v * c4);
     const int e0 = seg[v], e1 = seg[v + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0; e < e1; ++e) {
+    int e = e0;
+    // four entries in flight (segments reach ~100 entries at stride 16: a one-at-a-time walk is a
+    // chain of dependent L2 round trips); the accumulation order stays e0, e0+1, ...
+    for (; e + 4 <= e1; e += 4) {
+        int r[4];
+        float w[4];
+        float4 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { r[u] = erow[e + u]; w[u] = ew ? ew[e + u] : 1.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = reinterpret_cast<const float4 *>(src)[(int64_t)r[u] * c4 + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x += w[u] * f[u].x; acc.y += w[u] * f[u].y; acc.z += w[u] * f[u].z; acc.w += w[u] * f[u].w;
+        }
+    }
+    for (; e < e1; ++e) {
         float w = ew ? ew[e] : 1.f;
         float4 f = reinterpret_cast<const float4 *>(src)[(int64_t)erow[e] * c4 + j];
         acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
