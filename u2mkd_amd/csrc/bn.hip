@@ -124,16 +124,25 @@ bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n
     }
     s_n[g][cl] = na; s_m[g][cl] = mean; s_q[g][cl] = m2;
     __syncthreads();
-    if (g != 0 || ch >= c) return;
-    for (int i = 1; i < kBnFinLanes; ++i) {
-        float nb = s_n[i][cl];
-        if (nb == 0.f) continue;
-        float tot = na + nb;
-        float delta = s_m[i][cl] - mean;
-        mean += delta * (nb / tot);
-        m2 += s_q[i][cl] + delta * delta * (na * nb / tot);
-        na = tot;
+    // fixed binary tree over the 64 lanes (a serial merge of 64 triples by one lane, two divisions
+    // each, made this kernel slower than the statistics pass it finishes)
+    for (int stride = kBnFinLanes / 2; stride >= 1; stride >>= 1) {
+        if (g < stride) {
+            float nb = s_n[g + stride][cl];
+            if (nb != 0.f) {
+                float na2 = s_n[g][cl], ma = s_m[g][cl];
+                float tot = na2 + nb;
+                float delta = s_m[g + stride][cl] - ma;
+                s_m[g][cl] = ma + delta * (nb / tot);
+                s_q[g][cl] = s_q[g][cl] + s_q[g + stride][cl] + delta * delta * (na2 * nb / tot);
+                s_n[g][cl] = tot;
+            }
+        }
+        __syncthreads();
     }
+    if (g != 0 || ch >= c) return;
+    mean = s_m[0][cl];
+    m2 = s_q[0][cl];
     float var = m2 / (float)n;
     mean_out[ch] = mean;
     if (m2_out) {   // local statistics only (cross-rank merge follows): stats row = mean[c], M2[c], count
