@@ -15,6 +15,6 @@ def install_as_torchsparse():
     import sys
     base = 'u2mkd_amd.torchsparse'
     sys.modules['torchsparse'] = importlib.import_module(base)
-    for sub in ('tensor', 'operators', 'nn', 'nn.functional', 'nn.utils', 'nn.modules',
+    for sub in ('tensor', 'point_tensor', 'operators', 'nn', 'nn.functional', 'nn.utils', 'nn.modules',
                 'utils', 'utils.quantize', 'utils.collate'):
         sys.modules['torchsparse.' + sub] = importlib.import_module(base + '.' + sub)
