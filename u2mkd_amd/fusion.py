@@ -28,7 +28,31 @@ __all__ = ['IA_Layer', 'Atten_Fusion_Conv', 'L2CAILayer', 'L2CFusion', 'feature_
            'l2c_scatter', 'feature_fetch', 'l2c_scatter_torch', 'c2l_gather_torch']
 
 
+def _rows_linear(x, weight, bias):
+    """x [N, Cin] @ weight[Cout, Cin(,1)]^T + bias on the MFMA pipeline when the shapes allow (k = 1 Conv1d
+    weights are [Cout, Cin, 1])."""
+    w = weight.squeeze(-1) if weight.dim() == 3 else weight
+    if x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+        from .torchsparse.nn import functional as spf
+        return spf.linear(x, w, bias)
+    return F.linear(x, w, bias)
+
+
+def _rows_bn(bn, x, relu=False):
+    """BatchNorm1d (+ReLU) over the rows of [N, C] (fused HIP pass on the device; SyncBatchNorm aware)."""
+    if x.is_cuda and x.shape[1] % 4 == 0:
+        from .torchsparse.nn import functional as spf
+        return spf.batch_norm(x, bn, relu)
+    y = bn(x)
+    return F.relu(y) if relu else y
+
+
 class IA_Layer(nn.Module):
+    """fusion_blocks.py:9-46 with the reference's parameters (Conv1d / BatchNorm1d / Linear), evaluated
+    on row-major [N, C] features: a k=1 Conv1d over [1, C, N] is a Linear over rows and BatchNorm1d over
+    [1, C, N] is BatchNorm1d over [N, C], so none of the reference's transposes (strided copies and
+    strided gradients on 80k x 256 tensors) is needed."""
+
     def __init__(self, channels):
         super().__init__()
         self.ic, self.pc = channels
@@ -39,10 +63,13 @@ class IA_Layer(nn.Module):
         self.fc3 = nn.Linear(rc, 1)
 
     def forward(self, img_feats, point_feats):
+        """img_feats [N, ic], point_feats [N, pc] -> attention-weighted image features [N, pc]."""
         img_feats = img_feats.contiguous()
-        att = torch.sigmoid(self.fc3(torch.tanh(self.fc1(img_feats) + self.fc2(point_feats.contiguous()))))
-        att = att.view(1, 1, -1)
-        return self.conv1(img_feats.unsqueeze(0).transpose(1, 2).contiguous()) * att      # [1, pc, N]
+        ri = _rows_linear(_rows_bn(self.fc1[0], img_feats, relu=True), self.fc1[2].weight, self.fc1[2].bias)
+        rp = _rows_linear(point_feats.contiguous(), self.fc2.weight, self.fc2.bias)
+        att = torch.sigmoid(F.linear(torch.tanh(ri + rp), self.fc3.weight, self.fc3.bias))          # [N, 1]
+        img = _rows_bn(self.conv1[1], _rows_linear(img_feats, self.conv1[0].weight, self.conv1[0].bias), relu=True)
+        return img * att
 
 
 class Atten_Fusion_Conv(nn.Module):
@@ -53,9 +80,10 @@ class Atten_Fusion_Conv(nn.Module):
         self.bn1 = nn.BatchNorm1d(outplanes)
 
     def forward(self, point_features, img_features):
+        """[N, P], [N, I] -> [N, outplanes] (fusion_blocks.py:49-68, row-major)."""
         img = self.ai_layer(img_features, point_features)
-        fused = torch.cat([point_features.unsqueeze(0).transpose(1, 2), img], dim=1)
-        return F.relu(self.bn1(self.conv1(fused))).squeeze(0).transpose(0, 1)
+        fused = torch.cat([point_features, img], dim=1)
+        return _rows_bn(self.bn1, _rows_linear(fused, self.conv1.weight, self.conv1.bias), relu=True)
 
 
 class L2CAILayer(nn.Module):
@@ -100,6 +128,23 @@ def _last_camera(mask):
     return (best - 1).clamp(min=0), best > 0
 
 
+class _NchwToRows(torch.autograd.Function):
+    """[B, ncam, C, h, w] -> channel-last rows [B*ncam*h*w, C] and back, with a PLAIN NCHW gradient: the
+    autograd of permute().reshape() would hand the camera branch a channel-last-strided gradient, and
+    every backward kernel downstream (BatchNorm, adds, copies) then runs its slow strided variant."""
+
+    @staticmethod
+    def forward(ctx, fm):
+        ctx.shape = fm.shape
+        B, ncam, C, h, w = fm.shape
+        return fm.permute(0, 1, 3, 4, 2).contiguous().view(B * ncam * h * w, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, ncam, C, h, w = ctx.shape
+        return g.view(B, ncam, h, w, C).permute(0, 1, 4, 2, 3).contiguous()
+
+
 def _c2l_plan(pixel_coordinates, masks, h, w):
     """idx int32 [N, 8] / weights f32 [N, 8]: the 4 bilinear corners (align_corners=True, zero
     padding; slots 4..7 unused) of every point in the feature map of the LAST camera seeing it,
@@ -136,7 +181,7 @@ def c2l_gather(feature_maps, pixel_coordinates, masks):
     from .torchsparse.nn import functional as spf
     B, ncam, C, h, w = feature_maps.shape
     idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w))
-    rows = feature_maps.permute(0, 1, 3, 4, 2).reshape(B * ncam * h * w, C)
+    rows = _NchwToRows.apply(feature_maps)
     if C % 4:                                   # e.g. the 17-class logit map: pad rows to whole 16-byte segments
         rows = F.pad(rows, (0, 4 - C % 4))
     return spf.spdevoxelize(rows, idx8, w8)[:, :C]
