@@ -251,9 +251,12 @@ def _l2c_plan(pixel_coordinates, masks, ch, cw):
     w = 1.0 / num[pix]
     order_d, seg_d = spf._csr_by_destination(key_d, n_dst)
     od = order_d.long()
-    key_s = torch.where(mask, row, torch.full_like(row, -1)).int()
-    order_s, seg_s = spf._csr_by_destination(key_s, n_pts)
-    os_ = order_s.long()
+    # grouping by source point does not depend on the grid: one sort per batch, shared by all scales
+    def by_source():
+        key_s = torch.where(mask, row, torch.full_like(row, -1)).int()
+        order_s, seg_s = spf._csr_by_destination(key_s, n_pts)
+        return order_s.long(), seg_s
+    os_, seg_s = spf._plan(masks[0], 'l2c_by_source', by_source)
     fwd = (row[od].int().contiguous(), w[od].contiguous(), seg_d)
     bwd = (pix[os_].int().contiguous(), w[os_].contiguous(), seg_s)
     return fwd, bwd, n_dst

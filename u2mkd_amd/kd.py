@@ -15,7 +15,7 @@ from torch import nn
 from . import torchsparse
 from .camera import BNReluConv, SwiftNetRes18
 from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c_scatter
-from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d,
+from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
 from .lidar.point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
 from .lidar.sphereformer import SphereFormer
@@ -73,8 +73,8 @@ class StudentMSP2IFM(nn.Module):
         self.l2c_fusion_blocks = nn.ModuleList(
             [L2CFusion(inplanes_I=img_cs[i], inplanes_P=cs[i], outplanes=img_cs[i]) for i in range(1, 5)])
         self.learner = nn.ModuleList([
-            nn.Sequential(nn.Linear(cs[i], img_cs[i]), nn.BatchNorm1d(img_cs[i]), nn.ReLU(True),
-                          nn.Linear(img_cs[i], img_cs[i]), nn.BatchNorm1d(img_cs[i]))
+            FusedSequential(PointLinear(cs[i], img_cs[i]), PointBatchNorm1d(img_cs[i]), nn.ReLU(True),
+                            PointLinear(img_cs[i], img_cs[i]), PointBatchNorm1d(img_cs[i]))
             for i in range(1, 5)])
         self.mse = nn.MSELoss()
 
@@ -88,7 +88,7 @@ class StudentMSP2IFM(nn.Module):
         self.classifier_vox = nn.Sequential(nn.Linear(cs[8], num_classes))
         self.classifier_pix = BNReluConv(self.pix_branch.num_features, num_classes, k=1)
         self.point_transforms = nn.ModuleList([
-            FusedSequential(nn.Linear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
+            FusedSequential(PointLinear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
             for a_, b_ in ((0, 4), (4, 6), (6, 8))])
         for m in self.modules():
             if isinstance(m, nn.BatchNorm1d):
@@ -138,7 +138,7 @@ class StudentMSP2IFM(nn.Module):
             img_feat_tensor = c2l_gather(skip.view(ib, ncam, ifc, ifh, ifw), pixel_coordinates, masks)
             pseudo = self.learner[idx](pts_feat.F)
             img_feat_tensor = torch.where(fov_mask.unsqueeze(1), img_feat_tensor, pseudo)
-            mse_loss.append(self.mse(pseudo[fov_mask], img_feat_tensor[fov_mask].detach()))
+            mse_loss.append(_masked_mse(pseudo, img_feat_tensor.detach(), fov_mask))
             pts_feat.F = self.c2l_fusion_blocks[idx](pts_feat.F, img_feat_tensor)
             vox_feats.append(point_to_voxel(vox_out, pts_feat))
 
@@ -172,6 +172,13 @@ class StudentMSP2IFM(nn.Module):
         return ret
 
 
+def _masked_mse(a, b, mask):
+    """nn.MSELoss()(a[mask], b[mask]) without the boolean-index compaction (a host synchronisation
+    per fusion stage): mean over the selected rows of the squared differences."""
+    m = mask.to(a.dtype).unsqueeze(1)
+    return (((a - b) ** 2) * m).sum() / (m.sum() * a.shape[1]).clamp(min=1.0)
+
+
 class TSDFull(nn.Module):
     """Student + frozen teacher (``SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL``, tsd_full.py:562-596).
     ``spformer`` holds the shared SphereFormer hyper-parameters (see lidar.spformer_kwargs); like
@@ -188,8 +195,8 @@ class TSDFull(nn.Module):
         self.model_t.requires_grad_(False)
         self.num_classes = num_classes
         self.debug_val = debug_val
-        self.model_s.adapt_layer = nn.Sequential(
-            nn.Linear(self.model_s.cs[4], self.model_t.cs[4]), nn.BatchNorm1d(self.model_t.cs[4]), nn.ReLU(True))
+        self.model_s.adapt_layer = FusedSequential(
+            PointLinear(self.model_s.cs[4], self.model_t.cs[4]), PointBatchNorm1d(self.model_t.cs[4]), nn.ReLU(True))
 
     def forward(self, in_mod: dict):
         ret = {'stu': self.model_s(in_mod['student'])}
