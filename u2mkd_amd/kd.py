@@ -18,6 +18,7 @@ from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
 from .lidar.point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .torchsparse.nn import functional as spf
 from .lidar.sphereformer import SphereFormer
 from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
 from .losses import MixLovaszCrossEntropy
@@ -107,6 +108,7 @@ class StudentMSP2IFM(nn.Module):
         z = PointTensor(x.F, x.C.float())
         x0 = initial_voxelize(z, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())
+        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)     # all down-sample syncs up front
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
 
