@@ -3,22 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one training step of the LiDAR hot path on one synthetic batch
-already resident in HBM: forward, Lovasz+CE loss, zero_grad, backward,
-SGD(nesterov) step, LR-scheduler step (the train branch of the reference's
-``_run_step``, core/spformer_trainer.py:58-94).  Workload at every N =
-BASELINE.json configs[1]: SPVCNN cr=1.0, LiDAR-only, one 80 000-voxel synthetic
-scene per GPU (weak scaling; scenes are independent, gradients are all-reduced
-by DDP over RCCL, BatchNorm statistics by SyncBatchNorm as the reference does).
+One "step" = one KD training step (BASELINE.json configs[2], the configuration the metric
+"LiDAR points/sec/node fwd+bwd (teacher+student+KD)" is quoted on) on one synthetic batch
+already resident in HBM: frozen SPVCNN+SphereFormer teacher forward (cr_t 2.0), SwiftNet-18 +
+SPVCNN+SphereFormer student forward (cr 1.0, 6 cameras), the KD / Lovasz+CE losses, zero_grad,
+backward, SGD(nesterov) step, LR-scheduler step -- the train branch of the reference's
+``NuScenesLCTSDFullTrainer._run_step`` (core/nusc_trainers.py:255-366).  One 80 000-point scene
+per GPU at every N (weak scaling: scenes are independent, gradients are all-reduced by DDP over
+RCCL, the student's BatchNorm statistics by SyncBatchNorm, train_lc_nusc_tsd_full.py:80-84).
 
-Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel group
-(SubMConv3d 64->64 k=3 at 80k voxels: forward + dgrad + wgrad), timed live with
-HIP events on the launch stream; ``cpu_baseline`` is the CPU oracle timed on
-the host cores on a bounded sample (rank 0, N=1 only).
+``--gpus N`` without a torchrun environment starts its own N ranks (fresh child processes,
+one per GPU; the parent never touches the GPU and only relays rank 0's JSON line).  Under
+``python -m torch.distributed.run`` (RANK / WORLD_SIZE set) the process is one rank.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel group (SubMConv3d 64->64 k=3
+at 80k voxels: forward + input gradient + weight gradient), timed live with HIP events on the
+launch stream; ``cpu_baseline`` is the CPU oracle timed on the host cores on a bounded sample
+(rank 0, N=1 only); ``secondary`` (N=1 only) holds the 900x1600 KD step and the LiDAR-only
+configs[1] step.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,12 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 N_VOX = 80000
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = 'LiDAR points/sec/node fwd+bwd (teacher+student+KD), 1/2/4/8 MI355X'
 
 
 def parse():
@@ -41,16 +46,43 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--voxels', type=int, default=N_VOX)
     ap.add_argument('--cr', type=float, default=1.0)
-    ap.add_argument('--workload', choices=['spvcnn', 'kd'], default='spvcnn',
-                    help="spvcnn = BASELINE.json configs[1] (default, the judged line); kd = configs[2]: SPVCNN+SphereFormer "
-                         "teacher (cr_t 2.0) + SwiftNet18 student (cr 1.0) + KD losses, 6 cameras")
-    ap.add_argument('--image-hw', type=int, nargs=2, default=[360, 640])
+    ap.add_argument('--cr-t', type=float, default=2.0)
+    ap.add_argument('--workload', choices=['kd', 'spvcnn'], default='kd',
+                    help='kd = BASELINE.json configs[2] (default, the judged line): SPVCNN+SphereFormer teacher (cr_t 2.0) + '
+                         'SwiftNet18/SPVCNN student (cr 1.0) + KD losses, 6 cameras; spvcnn = configs[1], LiDAR-only SPVCNN')
+    ap.add_argument('--image-hw', type=int, nargs=2, default=[360, 640],
+                    help='network input size; 360x640 = int(0.4 * 900) x int(0.4 * 1600) is what the reference model sees '
+                         '(core/datasets/lc_semantic_nusc_tsd_full.py:133-136)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32')
     ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-voxels', type=int, default=80000)
+    ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--cpu-sample-voxels', type=int, default=20000)
     return ap.parse_args()
 
 
+# ----------------------------------------------------------------------------------- launcher
+def launch_ranks(args):
+    """Start one fresh process per GPU (the parent has made no GPU call and imports no torch) and
+    relay rank 0's JSON line."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------- roofline leg
 def subm_algorithmic_bytes(n, p, cin, cout, k=27, s=4):
     """bytes of SubMConv3d fwd + dgrad + wgrad, each gathered row
     read once per pass, outputs written once, 8 B per (in,out) map entry."""
@@ -60,25 +92,30 @@ def subm_algorithmic_bytes(n, p, cin, cout, k=27, s=4):
     return fwd, dgrad, wgrad
 
 
-def time_events(fn, iters, warmup=3):
-    """Average duration (ms) of fn() measured with HIP events on the current
-    stream -- the stream every u2mkd kernel is launched on."""
-    for _ in range(warmup):
-        fn()
+def time_events(fns, iters, warmup=3):
+    """Average duration (ms) of one call, measured with HIP events on the current stream -- the
+    stream every u2mkd kernel is launched on.  ``fns`` is a list of closures called round-robin
+    (one closure = back-to-back launches on one working set; several closures over distinct
+    buffers whose total exceeds the 256 MiB Infinity Cache = cold launches)."""
+    import torch
+    for i in range(warmup * len(fns)):
+        fns[i % len(fns)]()
     torch.cuda.synchronize()
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     start.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        fns[i % len(fns)]()
     stop.record()
     stop.synchronize()
     return start.elapsed_time(stop) / iters
 
 
-def roofline_leg(coords_dev, iters=50):
-    """North-star micro-shape: Conv3d(64, 64, k=3, stride 1) on the scene's
-    stride-1 map; fwd, dgrad and wgrad each timed separately."""
+def roofline_leg(coords_dev, iters=60, cold_sets=8):
+    """North-star micro-shape: Conv3d(64, 64, k=3, stride 1) on the scene's stride-1 map;
+    fwd, dgrad and wgrad each timed separately, warm (one working set, L3-resident) and cold
+    (``cold_sets`` distinct operand sets, > 256 MiB in total, launched round-robin)."""
+    import torch
     from u2mkd_amd import _lib as L
     from u2mkd_amd.torchsparse.nn import functional as F
     cin = cout = 64
@@ -86,117 +123,174 @@ def roofline_leg(coords_dev, iters=50):
     n = km.n_out
     p = int((km.nbr >= 0).sum().item())
     g = torch.Generator(device='cuda').manual_seed(0)
-    x = torch.randn(n, cin, device='cuda', generator=g)
-    w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
-    gy = torch.randn(n, cout, device='cuda', generator=g)
-    wt = F._transpose_weights(w)
     lib = L.load()
-    nbr_s, order = km.sorted_table(False)
-    tile_order = km.schedule(False).tile_order
+    sch = km.schedule(False)
     pairs, _, plan = km.pairs_plan()
     nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
-    dw = torch.empty_like(w)
-    out = torch.empty(n, cout, device='cuda')
-    dx = torch.empty(n, cin, device='cuda')
     st = L.stream()
 
-    def fwd():
-        L.call('u2mkd_conv_forward_sorted', L.ptr(x), n, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order), L.ptr(tile_order), n, 27, 0,
-               0, L.ptr(out), st)
+    def make_set():
+        x = torch.randn(n, cin, device='cuda', generator=g)
+        w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
+        gy = torch.randn(n, cout, device='cuda', generator=g)
+        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty_like(w), 'out': torch.empty(n, cout, device='cuda'),
+             'dx': torch.empty(n, cin, device='cuda'), 'dw': torch.empty_like(w),
+             'ws': torch.empty(nbytes, dtype=torch.uint8, device='cuda'),
+             # private copies of the map structures, so a cold launch also misses on the indices
+             'nbr_s': sch.nbr_s.clone(), 'order': sch.order.clone(), 'pairs': pairs.clone()}
 
-    def dgrad():
-        L.call('u2mkd_conv_forward_sorted', L.ptr(gy), n, cout, L.ptr(w), cin, L.ptr(nbr_s), L.ptr(order), L.ptr(tile_order), n, 27, 1,
-               0, L.ptr(dx), st)
+        # a pass = the weight re-layout into MFMA fragment order (442 KB, its own small launch) + the conv kernel
+        def conv(s, a, transpose, flip, o):
+            L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, transpose, L.ptr(s['wf']), st)
+            L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf']), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
+                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, L.ptr(o), st)
+        s['fwd'] = lambda s=s: conv(s, s['x'], 1, 0, s['out'])
+        s['dgrad'] = lambda s=s: conv(s, s['gy'], 0, 1, s['dx'])
+        s['wgrad'] = lambda s=s: L.call('u2mkd_conv_wgrad_pairs', L.ptr(s['x']), cin, L.ptr(s['gy']), cout, L.ptr(s['pairs']),
+                                        L.ptr(plan), n, 27, 0, L.ptr(s['ws']), nbytes, L.ptr(s['dw']), st)
+        return s
 
-    def wgrad():
-        L.call('u2mkd_conv_wgrad_pairs', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(pairs), L.ptr(plan), n, 27, 0,
-               L.ptr(ws), nbytes, L.ptr(dw), st)
-
-    t_f, t_d, t_w = (time_events(f, iters) for f in (fwd, dgrad, wgrad))
+    sets = [make_set() for _ in range(cold_sets)]
+    set_bytes = sum(t.numel() * t.element_size() for t in sets[0].values() if torch.is_tensor(t))
+    warm = {k: time_events([sets[0][k]], iters) for k in ('fwd', 'dgrad', 'wgrad')}
+    cold = {k: time_events([s[k] for s in sets], iters) for k in ('fwd', 'dgrad', 'wgrad')}
     b_f, b_d, b_w = subm_algorithmic_bytes(n, p, cin, cout)
-    total_b, total_t = b_f + b_d + b_w, t_f + t_d + t_w
+    total_b = b_f + b_d + b_w
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+    t_warm, t_cold = sum(warm.values()), sum(cold.values())
     flops = 6.0 * p * cin * cout
     # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
     # only quoted when it was taken on the same map (same N and P)
     traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
-            tj = json.load(f)
-        if tj['N'] == n and tj['P'] == p:
-            traffic = round(tj['group_fwd_dgrad_wgrad'])
-    except Exception:
-        pass
+    for name in ('r2_traffic.json', 'r1_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                tj = json.load(f)
+            if tj['N'] == n and tj['P'] == p:
+                traffic = round(tj['group_fwd_dgrad_wgrad'])
+                break
+        except Exception:
+            pass
+    r3 = lambda d: {k: round(v, 4) for k, v in d.items()}
     return {
-        'bound': 'hbm', 'achieved': round(gbs(total_b, total_t), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gbs(total_b, total_t) / HBM_PEAK_GBS, 4), 'traffic': traffic,
-        'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_os2_kernel x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
+        'bound': 'hbm', 'achieved': round(gbs(total_b, t_warm), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4), 'traffic': traffic,
+        'kernel': 'SubMConv3d fwd+dgrad+wgrad ((weight_fragments_kernel + conv_tp_kernel) x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
-        'ms': {'fwd': round(t_f, 4), 'dgrad': round(t_d, 4), 'wgrad': round(t_w, 4), 'total': round(total_t, 4)},
-        'GBps': {'fwd': round(gbs(b_f, t_f), 1), 'dgrad': round(gbs(b_d, t_d), 1), 'wgrad': round(gbs(b_w, t_w), 1)},
-        'mfma_f32_tflops': round(flops / (total_t * 1e-3) / 1e12, 2), 'mfma_f32_peak_tflops': 157.3,
+        'ms': dict(r3(warm), total=round(t_warm, 4)),
+        'GBps': {'fwd': round(gbs(b_f, warm['fwd']), 1), 'dgrad': round(gbs(b_d, warm['dgrad']), 1),
+                 'wgrad': round(gbs(b_w, warm['wgrad']), 1)},
+        'cold': {'ms': dict(r3(cold), total=round(t_cold, 4)), 'achieved': round(gbs(total_b, t_cold), 1),
+                 'frac': round(gbs(total_b, t_cold) / HBM_PEAK_GBS, 4),
+                 'note': '%d operand sets of %.0f MB launched round-robin (%.0f MB > 256 MiB Infinity Cache)'
+                         % (cold_sets, set_bytes / 1e6, cold_sets * set_bytes / 1e6)},
+        'mfma_f32_tflops': round(flops / (t_warm * 1e-3) / 1e12, 2), 'mfma_f32_peak_tflops': 157.3,
     }
 
 
+# ------------------------------------------------------------------------------ CPU baseline
 CPU_CHILD = r"""
 import json, os, sys, time
 sys.path.insert(0, %(root)r)
-import torch
-from oracle import spvcnn_ref as O
+import numpy as np, torch
+from oracle import spvcnn_ref as O, spformer_ref as SF, ts_ref as R
 from oracle import torchsparse_cpu as ots
 from u2mkd_amd.synth import synth_batch
-n_vox, cr, threads = %(n_vox)d, %(cr)r, %(threads)d
+from u2mkd_amd.camera import SwiftNetRes18
+n_vox, cr, cr_t, threads, workload = %(n_vox)d, %(cr)r, %(cr_t)r, %(threads)d, %(workload)r
+H, W = %(hw)r
 torch.set_num_threads(threads)
+torch.manual_seed(0)
+
+def med(fn, reps, warm=1):
+    for _ in range(warm): fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
 b = synth_batch(n_vox, 1, seed=1234)
-model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
-opt = torch.optim.SGD(model.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
 feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
-t0 = time.perf_counter()
-out = model({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
-loss = O.mix_lovasz_cross_entropy(out, labels)
-opt.zero_grad(); loss.backward(); opt.step()
-print(json.dumps({'dt': time.perf_counter() - t0}))
+out = {}
+# (i) the SubMConv3d micro-shape on the FULL map of the roofline leg: the algorithm of the
+# reference CPU backend, per offset gather -> mm -> scatter-add (SURVEY.md Appendix A-6), fwd + bwd
+bm = synth_batch(%(micro_vox)d, 1, seed=1234)
+nbmaps, nbsizes, oc, _ = R.build_kmap(bm['coords'], 1, 3, 1)
+n = bm['coords'].shape[0]
+x = torch.randn(n, 64); w = torch.randn(27, 64, 64) / (27 * 64) ** 0.5; gy = torch.randn(n, 64)
+def micro():
+    R.conv_forward(x, w, nbmaps, nbsizes, (n, n)); R.conv_backward(x, w, gy, nbmaps, nbsizes)
+out['micro_s'] = med(micro, 5)
+out['micro_n'] = n
+# (ii) the step on a bounded sample scene
+if workload == 'spvcnn':
+    model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    def step():
+        o = model({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
+        loss = O.mix_lovasz_cross_entropy(o, labels)
+        opt.zero_grad(); loss.backward(); opt.step()
+    out['step_s'] = med(step, 3)
+    out['parts'] = {}
+else:
+    kw_t = SF.default_spformer_kwargs(cr=cr_t); kw_s = SF.default_spformer_kwargs(cr=cr)
+    teacher = SF.SPVCNN_SPFORMER(**kw_t).eval()
+    student = SF.SPVCNN_SPFORMER(**kw_s).train()
+    cam = SwiftNetRes18().train()
+    params = list(student.parameters()) + list(cam.parameters())
+    opt = torch.optim.SGD(params, lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    img = torch.rand(1, 3, H, W) * 255
+    def t_fwd():
+        with torch.no_grad():
+            teacher({'lidar': ots.SparseTensor(feats, coords)})
+    def s_step():
+        o = student({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
+        loss = O.mix_lovasz_cross_entropy(o, labels)
+        opt.zero_grad(); loss.backward()
+    def c_step():
+        y = cam(img)
+        y = y[0] if isinstance(y, (tuple, list)) else y
+        y.float().mean().backward()
+    parts = {'teacher_fwd_s': med(t_fwd, 1, warm=0), 'student_lidar_fwd_bwd_s': med(s_step, 1, warm=0),
+             'swiftnet_one_camera_fwd_bwd_s': med(c_step, 1, warm=0)}
+    t0 = time.perf_counter(); opt.step(); parts['sgd_s'] = time.perf_counter() - t0
+    out['parts'] = parts
+    out['step_s'] = parts['teacher_fwd_s'] + parts['student_lidar_fwd_bwd_s'] + 6 * parts['swiftnet_one_camera_fwd_bwd_s'] + parts['sgd_s']
+print(json.dumps(out))
 """
 
 
-def cpu_baseline_leg(n_vox, cr, timeout_s=240):
-    """The CPU oracle (a port of the torchsparse v1.4.0 CPU algorithm: per kernel
-    offset gather -> mm -> scatter-add) on the host cores: one training step of the
-    same network on a bounded sample scene.  Runs in a child process (bounded by a
-    timeout) with a bounded thread count: the reference's CPU backend only threads
-    its GEMMs, and 256 OpenMP threads on tiny ops crawl."""
-    import subprocess
+def cpu_baseline_leg(args, timeout_s=420):
+    """The CPU oracle (a port of the torchsparse v1.4.0 CPU algorithm: per kernel offset
+    gather -> mm -> scatter-add; SwiftNet-18 is plain torch.nn on both sides) on the host cores, on a
+    bounded sample of the bench workload, plus the CPU time of the roofline leg's micro-shape.  Runs
+    in a child process with a bounded thread count: the reference's CPU backend only threads its
+    GEMMs, and 256 OpenMP threads on tiny ops crawl."""
     threads = min(os.cpu_count() or 1, 16)
-    code = CPU_CHILD % {'root': ROOT, 'n_vox': n_vox, 'cr': cr, 'threads': threads}
+    n_vox = args.cpu_sample_voxels
+    code = CPU_CHILD % {'root': ROOT, 'n_vox': n_vox, 'cr': args.cr, 'cr_t': args.cr_t, 'threads': threads,
+                        'workload': args.workload, 'hw': tuple(args.image_hw), 'micro_vox': args.voxels}
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                OPENBLAS_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    sample = ('1 training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic scene, '
-              'CPU oracle, %d threads' % (cr, n_vox, threads))
+    if args.workload == 'kd':
+        sample = ('KD step on one %d-point synthetic scene, CPU oracle (torchsparse v1.4.0 CPU algorithm) + torch.nn SwiftNet-18, '
+                  '%d threads: teacher SPVCNN+SphereFormer cr %g forward + student SPVCNN+SphereFormer cr %g forward/backward with '
+                  'Lovasz+CE + 6 x (SwiftNet-18 forward/backward on one %dx%d camera) + SGD; fusion MLPs and KD loss terms '
+                  'not included (the CPU figure is an upper bound)' % (n_vox, threads, args.cr_t, args.cr, *args.image_hw))
+    else:
+        sample = ('training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic scene, CPU oracle, '
+                  '%d threads, median of 3 after 1 warm-up' % (args.cr, n_vox, threads))
+    base = {'value': None, 'unit': 'points/s', 'cores': threads, 'kind': 'port'}
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
-        dt = json.loads(r.stdout.strip().splitlines()[-1])['dt']
+        o = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # timeout / crash: report it, never block the bench line
-        return {'value': None, 'unit': 'points/s', 'cores': threads, 'kind': 'port',
-                'sample': sample + ' -- FAILED: %s' % type(e).__name__}
-    return {'value': round(n_vox / dt, 1), 'unit': 'points/s', 'cores': threads, 'kind': 'port',
-            'sample': sample + ', %.1f s' % dt}
-
-
-def cosine_warmup_lambda(num_epochs, batch_size, dataset_size, world):
-    """core/schedulers.py:10-35 (cosine_schedule_with_warmup)."""
-    def fn(k):
-        bs = batch_size * world
-        if world == 1:
-            warmup_iters = 0
-        else:
-            warmup_iters = 1000 // world
-        if k < warmup_iters:
-            return (k + 1) / warmup_iters
-        iter_per_epoch = (dataset_size + bs - 1) // bs
-        ratio = (k - warmup_iters) / (num_epochs * iter_per_epoch)
-        return 0.5 * (1 + np.cos(np.pi * ratio))
-    return fn
+        return dict(base, sample=sample + ' -- FAILED: %s' % type(e).__name__)
+    return dict(base, value=round(n_vox / o['step_s'], 1), sample=sample + ', %.1f s' % o['step_s'],
+                parts_s={k: round(v, 3) for k, v in o['parts'].items()},
+                subm_conv_64x64_fwd_bwd={'ms': round(o['micro_s'] * 1e3, 2), 'N': o['micro_n'],
+                                         'note': 'the roofline leg\'s shape on the CPU oracle (gather -> mm -> index_add per '
+                                                 'offset, fwd + dX + dW), median of 5 after 1 warm-up, %d threads' % threads})
 
 
 def log(msg):
@@ -207,86 +301,115 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def main():
-    args = parse()
+# --------------------------------------------------------------------------------- workloads
+def build_step(args, rank, workload, image_hw):
+    """(step closure, points per step on this rank, description)."""
+    import torch
+    from u2mkd_amd import lidar, train as T
+    from u2mkd_amd.synth import synth_batch, synth_kd_batch
+    torch.manual_seed(0)
+    amp = 'bf16' if args.dtype == 'bf16' else False
+    if workload == 'spvcnn':
+        b = synth_batch(args.voxels, 1, seed=1234 + rank)
+        feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+        model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+        runner = T.LidarStep(model, num_epochs=25, batch_size=1, amp=amp)
+        desc = ('BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE + bwd + SGD), '
+                'one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels))
+        return (lambda: runner(feats, coords, labels)), feats.shape[0], desc
+    from u2mkd_amd import kd as KD
+    sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+    model = KD.TSDFull(cr=args.cr, cr_t=args.cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+    runner = T.KDStep(model, num_epochs=50, batch_size=1, amp=amp)
+    runner.train_mode()
+    nb = synth_kd_batch(args.voxels, 1, seed=1234 + rank, image_hw=tuple(image_hw))
+    n_pts = int(sum(nb['teacher']['num_pts']))
+    dbatch = T.kd_batch_to_device(nb)
+    desc = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t %g, frozen) + SwiftNet18/SPVCNN+SphereFormer student '
+            '(cr %g) + KD losses train step, one %d-point scene + 6 cameras %dx%d per GPU'
+            % (args.cr_t, args.cr, n_pts, image_hw[0], image_hw[1]))
+    return (lambda: runner(dbatch)), n_pts, desc
+
+
+def timed_run(step, warmup, steps, world):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the
+    MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    from u2mkd_amd import distributed as D
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    return D.max_over_ranks(dt), float(loss.detach())
+
+
+def run_rank(args):
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     from u2mkd_amd import distributed as D
     rank, world, local_rank = D.init_from_env('nccl')
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-
-    from u2mkd_amd import lidar, torchsparse as ts
-    from u2mkd_amd.losses import MixLovaszCrossEntropy
-    from u2mkd_amd.synth import synth_batch
-
-    b = synth_batch(args.voxels, 1, seed=1234 + rank)
-    feats = torch.from_numpy(b['feats']).cuda()
-    coords = torch.from_numpy(b['coords']).cuda()
-    labels = torch.from_numpy(b['labels']).cuda()
-
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     result = {}
     if not args.kernel_only:
-        from u2mkd_amd import train as T
-        torch.manual_seed(0)
-        if args.workload == 'spvcnn':
-            model = lidar.SPVCNN(cr=args.cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
-            runner = T.LidarStep(model, num_epochs=25, batch_size=1)
-
-            def step():
-                return runner(feats, coords, labels)
-            workload = ('BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE + bwd + SGD), '
-                        'one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels))
-        else:
-            from u2mkd_amd import kd as KD
-            from u2mkd_amd.synth import synth_kd_batch
-            sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
-            model = KD.TSDFull(cr=args.cr, cr_t=2.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
-            runner = T.KDStep(model, num_epochs=50, batch_size=1)
-            runner.train_mode()
-            dbatch = T.kd_batch_to_device(synth_kd_batch(args.voxels, 1, seed=1234 + rank,
-                                                         image_hw=tuple(args.image_hw)))
-
-            def step():
-                return runner(dbatch)
-            workload = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t 2.0, frozen) + SwiftNet18/SPVCNN '
-                        'student (cr %g) + KD losses train step, %d voxels + 6 cameras %dx%d per GPU'
-                        % (args.cr, args.voxels, args.image_hw[0], args.image_hw[1]))
-
+        step, n_pts, desc = build_step(args, rank, args.workload, args.image_hw)
         log('model built, scene resident; warm-up')
-        for _ in range(args.warmup):
-            step()
-        log('warm-up done')
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        dt, loss = timed_run(step, args.warmup, args.steps, world)
         log('timed region done: %.3f s' % dt)
-        dt = D.max_over_ranks(dt)
-        total_points = world * args.voxels * args.steps
         result.update({
-            'metric': 'LiDAR points/sec/node fwd+bwd (teacher+student+KD), 1/2/4/8 MI355X',
-            'value': round(total_points / dt, 1), 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': workload,
-                       'voxels_per_gpu': args.voxels, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
-                       'final_loss': round(float(loss.detach()), 5)},
+            'metric': METRIC, 'value': round(world * n_pts * args.steps / dt, 1), 'unit': 'points/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': desc, 'points_per_gpu': n_pts, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(loss, 5)},
         })
+        del step
+        if world == 1 and not args.no_secondary:
+            sec = {}
+            torch.cuda.empty_cache()
+            for name, wl, hw, w_, k_ in (('lidar_only_configs1', 'spvcnn', args.image_hw, 3, 10),
+                                         ('kd_6cam_900x1600', 'kd', (900, 1600), 2, 4)):
+                if wl == args.workload and tuple(hw) == tuple(args.image_hw):
+                    continue
+                try:
+                    s2, n2, d2 = build_step(args, rank, wl, hw)
+                    dt2, l2 = timed_run(s2, w_, k_, 1)
+                    sec[name] = {'value': round(n2 * k_ / dt2, 1), 'unit': 'points/s', 'ms_per_step': round(dt2 / k_ * 1e3, 3),
+                                 'steps': k_, 'warmup': w_, 'workload': d2}
+                    del s2
+                    torch.cuda.empty_cache()
+                except Exception as e:     # a secondary line never blocks the judged one
+                    sec[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+                log('secondary %s done' % name)
+            result['secondary'] = sec
 
     if rank == 0:
+        from u2mkd_amd.synth import synth_batch
+        coords = torch.from_numpy(synth_batch(args.voxels, 1, seed=1234)['coords']).cuda()
         result['roofline'] = roofline_leg(coords)
         log('roofline leg done')
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             log('cpu baseline (child process)')
-            result['cpu_baseline'] = cpu_baseline_leg(args.cpu_sample_voxels, args.cr)
+            result['cpu_baseline'] = cpu_baseline_leg(args)
         print(json.dumps(result), flush=True)
     D.shutdown()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == '__main__':

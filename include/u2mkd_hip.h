@@ -108,24 +108,48 @@ int u2mkd_conv_forward(const float *in /*[n_in,cin]*/, int64_t n_in, int32_t cin
                        float *out /*[n_out,cout]*/, u2mkd_stream_t s);
 /* Same contraction on a MASK-SORTED table: row p of nbr_sorted / of the launch grid is
  * original row order[p] (order == NULL: identity).  Sorting rows by their 27-bit
- * neighbour mask makes 16-row MFMA blocks mask-homogeneous, so empty (block, offset)
- * slots are skipped.  variant: 0 = built-in heuristic, else waves*100 + KC (tuning knob:
- * waves in {4,8,16} = 64/128/256-row workgroup tiles, KC in {32,64} channels per stage).
- * tile_order: launch order of the 64-row tiles -- a tile visits the union of its rows' offsets
- * serially, so tiles with the most offsets should start first (NULL: ascending).            */
+ * neighbour mask makes 64-row tiles mask-homogeneous.  A tile visits the union of its rows'
+ * offsets one after the other (conv_os2 / conv_os3); tile_order: launch order of the 64-row
+ * tiles -- heaviest first (NULL: ascending).  kflip in {0,1}.                               */
 int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                               const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
                               const int32_t *tile_order /*[ceil(n_out/64)] or NULL*/, int64_t n_out, int32_t k,
-                              int32_t kflip, int32_t variant, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
-/* The same kernel on sorted rows [row_begin, row_end) of a table whose rows are ld entries
- * long (the other rows of `out` are left untouched).  Together with the two entries below
- * this allows mixed schedules: some sorted rows through the output-stationary tiles, the
- * others (e.g. rows of rare neighbour masks, which make a 64-row tile walk up to 27 offsets
- * serially) through the pair schedule.                                                     */
-int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
-                            const int32_t *nbr_sorted /*[k,ld]*/, int64_t ld, const int32_t *order /*[ld] or NULL*/,
-                            int64_t row_begin, int64_t row_end, int32_t k, int32_t kflip, int32_t variant,
-                            float *out, u2mkd_stream_t s);
+                              int32_t kflip, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* The TILE-LOCAL PAIR schedule (csrc/conv_tp.hip), for layers whose reduction fits the register
+ * file (u2mkd_conv_tiles_supported: cin in {32,64,96,128}, cout in {32,64,96,128}): the (row,
+ * neighbour) pairs of a 64-row tile are compacted per offset in LDS with wave ballots + prefix
+ * popcounts into dense 16-pair MFMA blocks, the waves split the output columns, the output tile is
+ * LDS-resident, gathered rows go through a coalesced LDS image.  Same arguments as
+ * u2mkd_conv_forward_sorted except the weights: wf = FRAGMENT layout of
+ * u2mkd_weight_fragments(w [k,rows,cols], transpose):
+ *   forward:        w = kernel [k,cin,cout], transpose = 1   (B_k[col][ci] = kernel[k][ci][col])
+ *   input gradient: w = kernel [k,cin,cout], transpose = 0   (B_k[ci][co]  = kernel[k][ci][co])
+ * wf has k*rows*cols floats; rows and cols must be multiples of 16.
+ * Work items (optional): a tile is a serial chain of MFMA blocks, so tiles with many blocks are cut
+ * into halves / quarters: items[i] = tile << 4 | sub << 2 | lg  covers the 64 >> lg sorted rows from
+ * 64 tile + (64 >> lg) sub, every row exactly once, listed heaviest first; *n_items (device memory,
+ * never read by the host) of them.  NULL = one item per 64-row tile.                              */
+int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k);
+int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose,
+                           float *wf /*[k*rows*cols]*/, u2mkd_stream_t s);
+int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const float *wf, int32_t cout,
+                             const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
+                             const int32_t *items /*[<= 4 ceil(n_out/64)] or NULL*/,
+                             const int32_t *n_items /*[1] device, or NULL*/, int64_t n_out, int32_t k,
+                             int32_t kflip, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* Tuning / A-B experiments only (tools/ab_*.py), NOT part of the drop-in boundary:
+ * u2mkd_conv_forward_sorted with an explicit kernel choice.  variant 0 = the product heuristic,
+ * waves*100 + kc = conv_os2, 3000 + rb*100 + kc = conv_os3 (see conv.hip).                   */
+int u2mkd_debug_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                                    const int32_t *nbr_sorted, const int32_t *order, const int32_t *tile_order,
+                                    int64_t n_out, int32_t k, int32_t kflip, int32_t variant, float *out,
+                                    u2mkd_stream_t s);
+/* Profiling only: the 64 -> 64 tile-pair kernel with per-workgroup timestamps; stamps [tiles, 8] uint64 =
+ * {realtime start, cycles start, after compaction, after the block walk, end, realtime end, blocks, tile}. */
+int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const float *wf /*fragments of [k,64,64]*/,
+                                       const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                                       const int32_t *n_items, int64_t n_out, int32_t k, float *out, uint64_t *stamps,
+                                       u2mkd_stream_t s);
 /* y[p] = in[pair_idx[p]] * B_{tile_k[p / 64]} over the pair schedule of u2mkd_pairs_build
  * (pair_idx = pair_in for a normal conv, pair_out for a transposed conv / the input gradient):
  * one dense MFMA stage per 64-pair tile, no serial walk over offsets.  meta (device) holds
@@ -148,17 +172,8 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, in
 /* neighbour mask of every output row: bit k set iff nbr[k][j] >= 0 (k <= 32). */
 int u2mkd_kmap_rowmask(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t *mask /*[n_out]*/,
                        u2mkd_stream_t s);
-/* dW[k] = sum_j A_j^T B_j over rows with nbr[k][j] >= 0, where
- *   a_gathered = 1: A_j = a[nbr[k][j]], B_j = b[j]       (normal conv)
- *   a_gathered = 0: A_j = a[j],         B_j = b[nbr[k][j]] (transposed conv)
- * a has ca channels (= cin of the layer), b has cb (= cout).  Deterministic
- * (partial slabs in `workspace`, then an ordered reduction).                */
-size_t u2mkd_conv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k);
-int u2mkd_conv_wgrad(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *nbr /*[k,n_rows]*/,
-                     int64_t n_rows, int32_t k, int32_t a_gathered, int32_t centre_dense,
-                     void *workspace, size_t workspace_bytes, float *dw /*[k,ca,cb]*/, u2mkd_stream_t s);
-
-/* Weight gradient over the compacted pair list (the rulebook of u2mkd_kmap_compact; the
+/* dW[k] = sum over the pairs (i, j) of offset k of A_i^T B_j  (the dW half of torchsparse
+ * convolution_backward_cuda), over the compacted pair list (the rulebook of u2mkd_kmap_compact; the
  * buffer may be over-allocated, only plan[0] = P pairs are read).  u2mkd_wgrad_plan turns
  * nbsizes into the device-side work split (no host sync); plan has u2mkd_wgrad_plan_ints(k)
  * int32 entries.  swap = 0: A rows = pairs[:,0], B rows = pairs[:,1] (normal conv: A = the

@@ -47,7 +47,7 @@ def test_conv_tiny_maps_both_schedules(F, n, cin, cout):
     wt = F._transpose_weights(w.cuda())
     o1 = torch.zeros(n, cout, device='cuda')
     o2 = torch.zeros(n, cout, device='cuda')
-    km.schedule(False).run(x.cuda(), wt, cout, 0, o1)
+    km.schedule(False).run(x.cuda(), w.cuda(), True, cout, 0, o1)
     km.pair_schedule().run(x.cuda(), wt, cout, False, o2)
     if n:
         assert float((o1.cpu() - want).abs().max()) < 1e-4 and float((o2.cpu() - want).abs().max()) < 1e-4

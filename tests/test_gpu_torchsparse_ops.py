@@ -209,7 +209,7 @@ def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
     wt = F._transpose_weights(w.cuda())
     o_t = torch.full((n_out, cout), float('nan'), device='cuda')
     o_p = torch.full((n_out, cout), float('nan'), device='cuda')
-    ts_.run(x.cuda(), wt, cout, 0, o_t)
+    ts_.run(x.cuda(), w.cuda(), True, cout, 0, o_t)
     ps.run(x.cuda(), wt, cout, transposed, o_p)
     assert _rel(o_t, want) < 1e-4 and _rel(o_p, want) < 1e-4
     assert float((o_t - o_p).abs().max()) < 1e-4
@@ -221,21 +221,19 @@ def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
     assert _rel(gi_p, wgi) < 1e-4
     gi_t = torch.empty(n_in, cin, device='cuda')
     if kind == 'subm':
-        ts_.run(g.cuda(), w.cuda().contiguous(), cin, 1, gi_t)          # mirrored offsets on the same table
+        ts_.run(g.cuda(), w.cuda().contiguous(), False, cin, 1, gi_t)   # mirrored offsets on the same table
     else:
-        km.schedule(not transposed).run(g.cuda(), w.cuda().contiguous(), cin, 0, gi_t)
+        km.schedule(not transposed).run(g.cuda(), w.cuda().contiguous(), False, cin, 0, gi_t)
     assert _rel(gi_t, wgi) < 1e-4
-    # row-range entry: two launches over [0, m) and [m, n) write exactly the rows of one launch
+    # the offset-walking tile kernels agree with the product schedule (tile pairs where instantiated)
     nbr_s, order = ts_.tiles()
-    m = n_out // 3
     a = torch.empty(n_out, cout, device='cuda')
-    for lo, hi in ((0, m), (m, n_out)):
-        L.call('u2mkd_conv_forward_rows', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), n_out,
-               L.ptr(order), lo, hi, ks ** 3, 0, 0, L.ptr(a), L.stream())
-    assert torch.equal(a, o_t)
+    L.call('u2mkd_conv_forward_sorted', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order),
+           L.ptr(ts_.tile_order), n_out, ks ** 3, 0, L.ptr(a), L.stream())
+    assert float((a - o_t).abs().max()) < 1e-4
     with pytest.raises(RuntimeError):
-        L.call('u2mkd_conv_forward_rows', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), n_out,
-               L.ptr(order), 0, n_out + 1, ks ** 3, 0, 0, L.ptr(a), L.stream())
+        L.call('u2mkd_conv_forward_sorted', L.ptr(x.cuda()), n_in, cin, L.ptr(wt), cout, L.ptr(nbr_s), L.ptr(order),
+               L.ptr(ts_.tile_order), n_out, ks ** 3, 8, L.ptr(a), L.stream())
 
 
 def test_pair_schedule_is_the_padded_rulebook(F):

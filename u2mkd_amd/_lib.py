@@ -33,16 +33,18 @@ SIGNATURES = {
     'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
-    'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
-    'u2mkd_conv_forward_rows': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_debug_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_tiles_supported': (_i32, [_i32, _i32, _i32]),
+    'u2mkd_weight_fragments': (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_tiles': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_debug_conv_tile_pairs_stamps': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     'u2mkd_conv_forward_pairs': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_linear_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _p, _p]),
     'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_kmap_rowmask': (C.c_int, [_p, _i64, _i32, _p, _p]),
-    'u2mkd_conv_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
-    'u2mkd_conv_wgrad': (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p, _sz, _p, _p]),
     'u2mkd_wgrad_plan_ints': (_i32, [_i32]),
     'u2mkd_wgrad_plan': (C.c_int, [_p, _i32, _i64, _p, _p]),
     'u2mkd_conv_wgrad_pairs_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),

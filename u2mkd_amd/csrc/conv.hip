@@ -17,11 +17,9 @@
 //     reduction dimension; partial slabs + ordered reduce (bitwise reproducible).
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_internal.h"
 
 namespace u2mkd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, int cout, float *__restrict__ wt,
                                          int64_t total) {
@@ -34,13 +32,6 @@ __global__ void transpose_weights_kernel(const float *__restrict__ w, int cin, i
     int64_t k = r / cout;
     wt[t] = w[(k * cin + ci) * cout + co];
 }
-
-// Rows a table-walking forward launch covers: sorted rows [begin, end) of the neighbour table
-// nbr[k * ld + row].
-struct RowRange {
-    int64_t ld, begin, end;
-    const int32_t *tile_order;   // launch order of the 64-row tiles (heaviest first) or nullptr
-};
 
 // ---- output-stationary kernel, LDS-staged weights -----------------------------------
 // Workgroup = WAVES waves = 16*WAVES output rows (mask-sorted order) x 16*NB output columns;
@@ -168,7 +159,7 @@ conv_os2_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 if (km) { kn = __builtin_ctz(km); km &= km - 1; } else have_next = false;
             }
             if (have_next) load_stage(kn, cn, a_nxt, act_nxt);
-            if (act_cur && !(kflip & 8)) {   // (kflip bit 3: timing experiment, skip the MFMAs)
+            if (act_cur) {
                 const float *bb = Bs + (size_t)buf * TN * BS + r * BS + 4 * q;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -293,12 +284,9 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     const int nchunk = (cin + KC - 1) / KC;
     float4 ra[AP], rb[BP];
 
-    // timing-only knobs (tools/ab_conv.py): kflip bit 1 = always read offset 0's weights (B stays
-    // L2-hot), bit 2 = gather A from the tile's own rows (A stays local).  Results are wrong then.
-    const bool dbg_same_b = (kflip & 2) != 0, dbg_local_a = (kflip & 4) != 0;
     const int kf = kflip & 1;
     auto load_stage = [&](int k, int c, unsigned act) {
-        const float *wk = wt + (size_t)(dbg_same_b ? 0 : (kf ? K - 1 - k : k)) * cout * cin;
+        const float *wk = wt + (size_t)(kf ? K - 1 - k : k) * cout * cin;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             int f = tid + 256 * p;
@@ -314,7 +302,6 @@ conv_os3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
             ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((act >> (row >> 4)) & 1u) {
                 int idx = s_idx[k * TM + row];
-                if (dbg_local_a && idx >= 0) idx = (int)min((int64_t)(row0 + row), n_out - 1);
                 if (idx >= 0 && ci < cin) ra[p] = *reinterpret_cast<const float4 *>(in + (size_t)idx * cin + ci);
             }
         }
@@ -412,110 +399,6 @@ static void launch_conv_os3(dim3 grid, int K, hipStream_t st, const float *in, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((conv_os3_kernel<RB, NBW, KC>), grid, dim3(256), lds, st, in, cin, wt, cout, nbr, order, n_out,
                        K, kflip, out);
-}
-
-// ---- weight gradient ---------------------------------------------------------
-// grid = (S splits of the rows, K offsets (or 1), channel tiles).  256 threads:
-// wave w owns the 16 A-channels [ta*64 + 16w, +16) x 16*NB B-channels.
-template <int NB>
-__global__ void __launch_bounds__(256)
-conv_wgrad_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
-                  const int32_t *__restrict__ nbr, int64_t n_rows, int K, int a_gathered, int k_only, int k_skip,
-                  int S, int tiles_b, float *__restrict__ slabs) {
-    __shared__ int s_gi[2][256];
-    __shared__ int s_rj[2][256];
-    __shared__ int s_wcnt[2][4];
-
-    const int k = k_only >= 0 ? k_only : (int)blockIdx.y;
-    if (k == k_skip) return;
-    const int kslot = k_only >= 0 ? 0 : k;
-    const int s = blockIdx.x;
-    const int ta = blockIdx.z / tiles_b, tb = blockIdx.z % tiles_b;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int a_ch = ta * 64 + 16 * wave + r;
-    const bool wave_active = ta * 64 + 16 * wave < ca;
-    const bool a_ok = a_ch < ca;
-    const int b_ch0 = tb * 16 * NB + r;
-
-    const int64_t chunks = (n_rows + 255) / 256;
-    const int64_t per = (chunks + S - 1) / S;
-    const int64_t c_begin = (int64_t)s * per;
-    const int64_t c_end = c_begin + per < chunks ? c_begin + per : chunks;
-
-    f32x4 acc[NB];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int32_t *nk = nbr + (int64_t)k * n_rows;
-    int buf = 0;
-    for (int64_t c = c_begin; c < c_end; ++c, buf ^= 1) {
-        // --- compaction of this chunk's valid pairs (ballot + prefix sum) ---
-        int64_t j = c * 256 + threadIdx.x;
-        int gi = j < n_rows ? nk[j] : -1;
-        bool valid = gi >= 0;
-        unsigned long long m = __ballot(valid);
-        if (lane == 0) s_wcnt[buf][wave] = __popcll(m);
-        int rank = __popcll(m & ((1ULL << lane) - 1ULL));
-        __syncthreads();
-        int base = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            int cw = s_wcnt[buf][w];
-            if (w < wave) base += cw;
-            total += cw;
-        }
-        if (valid) {
-            s_gi[buf][base + rank] = gi;
-            s_rj[buf][base + rank] = (int)j;
-        }
-        __syncthreads();
-        if (!wave_active) continue;
-        // --- MFMA over the pairs: 4 pairs per step (reduction dim) ---
-        for (int p0 = 0; p0 < total; p0 += 4) {
-            int p = p0 + q;
-            bool pv = p < total;
-            int g = pv ? s_gi[buf][p] : 0;
-            int jj = pv ? s_rj[buf][p] : 0;
-            int64_t arow = a_gathered ? g : jj;
-            int64_t brow = a_gathered ? jj : g;
-            float av = (pv && a_ok) ? a[arow * ca + a_ch] : 0.f;
-            float bv[NB];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) bv[n] = (pv && b_ch0 + 16 * n < cb) ? b[brow * cb + b_ch0 + 16 * n] : 0.f;
-#pragma unroll
-            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[n], 0, 0, 0);
-        }
-    }
-    if (!wave_active) return;
-    // D[i = a channel][j = b channel]: row = 4q + reg, col = r
-    float *slab = slabs + ((size_t)kslot * S + s) * (size_t)ca * cb;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        int ach = ta * 64 + 16 * wave + 4 * q + reg;
-        if (ach < ca) {
-#pragma unroll
-            for (int n = 0; n < NB; ++n)
-                if (b_ch0 + 16 * n < cb) slab[(size_t)ach * cb + b_ch0 + 16 * n] = acc[n][reg];
-        }
-    }
-}
-
-// dw[k][e] = sum_s slab(k, s)[e]; two slab regions (all offsets with S0 splits,
-// optional dense centre with S1 splits), fixed summation order.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs0, int S0, const float *__restrict__ slabs1, int S1,
-                                    int k_centre, int64_t tile_elems, int K, float *__restrict__ dw) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (e >= tile_elems) return;
-    float acc = 0.f;
-    if (k == k_centre) {
-        for (int s = 0; s < S1; ++s) acc += slabs1[(size_t)s * tile_elems + e];
-    } else {
-        const float *p = slabs0 + (size_t)k * S0 * tile_elems + e;
-        for (int s = 0; s < S0; ++s) acc += p[(size_t)s * tile_elems];
-    }
-    dw[(size_t)k * tile_elems + e] = acc;
 }
 
 // ---- weight gradient over the compacted pair list (rulebook) ----------------------------
@@ -702,35 +585,6 @@ static int wgrad_g_target(int64_t n_rows, int k) {
     if (g < 32) g = 32;
     if (g > 768) g = 768;
     return (int)g;
-}
-
-struct WgradPlan {
-    int S0, S1, k_centre;
-    size_t bytes;
-};
-
-static WgradPlan wgrad_plan(int64_t n_rows, int ca, int cb, int K, int centre_dense) {
-    WgradPlan p;
-    int64_t chunks = (n_rows + 255) / 256;
-    if (chunks < 1) chunks = 1;
-    if (centre_dense) {
-        p.k_centre = K / 2;
-        int64_t s1 = chunks < 512 ? chunks : 512;
-        int64_t s0 = (chunks + 23) / 24;
-        if (s0 < 1) s0 = 1;
-        if (s0 > 32) s0 = 32;
-        p.S0 = (int)s0;
-        p.S1 = (int)s1;
-    } else {
-        p.k_centre = -1;
-        int64_t s0 = (chunks + 3) / 4;
-        if (s0 < 1) s0 = 1;
-        if (s0 > 64) s0 = 64;
-        p.S0 = (int)s0;
-        p.S1 = 0;
-    }
-    p.bytes = ((size_t)K * p.S0 + p.S1) * (size_t)ca * cb * sizeof(float);
-    return p;
 }
 
 // ---- pair-schedule kernel: one offset per 64-pair tile, pipelined across tiles ------------
@@ -977,6 +831,11 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
     U2_REQUIRE(cin > 0 && cin % 4 == 0, "%s: cin=%d must be a positive multiple of 4", who, cin);
     U2_REQUIRE(cout > 0, "%s: cout=%d must be positive", who, cout);
     U2_REQUIRE(k > 0 && k <= 32 && n_in >= 0, "%s: kernel volume %d not in 1..32", who, k);
+    // variant (u2mkd_debug_conv_forward_sorted only; the product entries pass 0):
+    //   0 / 1 = heuristic;
+    //   waves * 100 + kc = conv_os2 (waves in {4,8,16}, kc in {32,64});  3000 + rb * 100 + kc = conv_os3
+    //   (+10000: 64-column workgroups);  50000 + nb * 1000 + waves * 100 + kc = conv_os2 with nb column blocks.
+    if (variant == 1) variant = 0;
     const int c16 = (cout + 15) / 16;
     int nb = pick_nb(c16);
     if (variant >= 50000) {   // 50000 + nb * 1000 + waves * 100 + kc: conv_os2 with nb 16-column blocks per workgroup
@@ -1041,23 +900,60 @@ static int conv_forward_impl(const char *who, const float *in, int64_t n_in, int
 
 int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                                const int32_t *nbr_sorted, const int32_t *order, const int32_t *tile_order, int64_t n_out,
-                               int32_t k, int32_t kflip, int32_t variant, float *out, u2mkd_stream_t s) {
+                               int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
+    U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_sorted: kflip must be 0 or 1");
     return conv_forward_impl("u2mkd_conv_forward_sorted", in, n_in, cin, wt, cout, nbr_sorted, order,
+                             RowRange{n_out, 0, n_out, tile_order}, k, kflip, 0, out, s);
+}
+
+int u2mkd_debug_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
+                                     const int32_t *nbr_sorted, const int32_t *order, const int32_t *tile_order,
+                                     int64_t n_out, int32_t k, int32_t kflip, int32_t variant, float *out,
+                                     u2mkd_stream_t s) {
+    U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_debug_conv_forward_sorted: kflip must be 0 or 1");
+    return conv_forward_impl("u2mkd_debug_conv_forward_sorted", in, n_in, cin, wt, cout, nbr_sorted, order,
                              RowRange{n_out, 0, n_out, tile_order}, k, kflip, variant, out, s);
+}
+
+int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k) { return conv_tp_supported(cin, cout, k) ? 1 : 0; }
+
+int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, float *wf,
+                           u2mkd_stream_t s) {
+    U2_REQUIRE(w && wf, "u2mkd_weight_fragments: null pointer");
+    U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 16 == 0 && cols % 16 == 0,
+               "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 16", k, rows, cols);
+    return launch_weight_fragments(w, k, rows, cols, transpose ? 1 : 0, wf, as_stream(s));
+}
+
+int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const float *wf, int32_t cout,
+                             const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                             const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, float *out,
+                             u2mkd_stream_t s) {
+    if (n_out <= 0) return 0;
+    U2_REQUIRE(in && wf && nbr_sorted && out, "u2mkd_conv_forward_tiles: null pointer");
+    U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles: kflip must be 0 or 1");
+    U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles: empty input");
+    U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles: items and n_items go together");
+    int rc = launch_conv_tp("u2mkd_conv_forward_tiles", in, cin, wf, cout, nbr_sorted, order,
+                            RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, kflip, out, as_stream(s));
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_tiles: no instantiation for %d -> %d channels, kernel volume %d "
+               "(ask u2mkd_conv_tiles_supported first)", cin, cout, k);
+    return rc;
+}
+
+int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const float *wf, const int32_t *nbr_sorted,
+                                       const int32_t *order, const int32_t *items, const int32_t *n_items, int64_t n_out,
+                                       int32_t k, float *out, uint64_t *stamps, u2mkd_stream_t s) {
+    U2_REQUIRE(in && wf && nbr_sorted && out && stamps && n_out > 0, "u2mkd_debug_conv_tile_pairs_stamps: null pointer");
+    int rc = launch_conv_tp("u2mkd_debug_conv_tile_pairs_stamps", in, 64, wf, 64, nbr_sorted, order,
+                            RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, 0, out, as_stream(s),
+                            reinterpret_cast<unsigned long long *>(stamps));
+    return rc < 0 ? 2 : rc;
 }
 
 int u2mkd_conv_forward(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout, const int32_t *nbr,
                        int64_t n_out, int32_t k, int32_t kflip, float *out, u2mkd_stream_t s) {
-    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, nullptr, n_out, k, kflip, 0, out, s);
-}
-
-int u2mkd_conv_forward_rows(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
-                             const int32_t *nbr_sorted, int64_t ld, const int32_t *order, int64_t row_begin,
-                             int64_t row_end, int32_t k, int32_t kflip, int32_t variant, float *out, u2mkd_stream_t s) {
-    U2_REQUIRE(row_begin >= 0 && row_end <= ld, "u2mkd_conv_forward_rows: rows [%lld, %lld) outside the table of %lld",
-               (long long)row_begin, (long long)row_end, (long long)ld);
-    return conv_forward_impl("u2mkd_conv_forward_rows", in, n_in, cin, wt, cout, nbr_sorted, order,
-                             RowRange{ld, row_begin, row_end, nullptr}, k, kflip, variant, out, s);
+    return u2mkd_conv_forward_sorted(in, n_in, cin, wt, cout, nbr, nullptr, nullptr, n_out, k, kflip, out, s);
 }
 
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
@@ -1187,61 +1083,6 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 64), k), dim3(256), 0, st,
                        slabs, plan, k, tile_elems, dw);
     return check_launch("u2mkd_conv_wgrad_pairs");
-}
-
-size_t u2mkd_conv_wgrad_workspace_bytes(int64_t n_rows, int32_t ca, int32_t cb, int32_t k) {
-    // upper bound over both plans so callers need not know centre_dense
-    size_t a = wgrad_plan(n_rows, ca, cb, k, 0).bytes, b = wgrad_plan(n_rows, ca, cb, k, 1).bytes;
-    return a > b ? a : b;
-}
-
-int u2mkd_conv_wgrad(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *nbr, int64_t n_rows,
-                     int32_t k, int32_t a_gathered, int32_t centre_dense, void *workspace, size_t workspace_bytes,
-                     float *dw, u2mkd_stream_t s) {
-    U2_REQUIRE(dw, "u2mkd_conv_wgrad: null dw");
-    U2_REQUIRE(ca > 0 && cb > 0, "u2mkd_conv_wgrad: ca=%d cb=%d must be positive", ca, cb);
-    hipStream_t st = as_stream(s);
-    if (n_rows == 0) {
-        hipError_t e = hipMemsetAsync(dw, 0, (size_t)k * ca * cb * sizeof(float), st);
-        if (e != hipSuccess) { set_error("u2mkd_conv_wgrad: memset: %s", hipGetErrorString(e)); return 1; }
-        return 0;
-    }
-    U2_REQUIRE(a && b && nbr && workspace, "u2mkd_conv_wgrad: null pointer");
-    if (centre_dense) U2_REQUIRE(k % 2 == 1, "u2mkd_conv_wgrad: centre_dense needs an odd kernel volume");
-    WgradPlan p = wgrad_plan(n_rows, ca, cb, k, centre_dense);
-    U2_REQUIRE(workspace_bytes >= p.bytes, "u2mkd_conv_wgrad: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
-    const int c16 = (cb + 15) / 16;
-    const int nb = pick_nb(c16);
-    const int tiles_b = (int)ceil_div(c16, nb), tiles_a = (ca + 63) / 64;
-    float *slabs0 = reinterpret_cast<float *>(workspace);
-    float *slabs1 = slabs0 + (size_t)k * p.S0 * ca * cb;
-#define U2_WG(N, GRID, KONLY, KSKIP, SS, SLAB)                                                                    \
-    case N:                                                                                                       \
-        hipLaunchKernelGGL((conv_wgrad_kernel<N>), GRID, dim3(256), 0, st, a, ca, b, cb, nbr, n_rows, k,          \
-                           a_gathered, KONLY, KSKIP, SS, tiles_b, SLAB);                                          \
-        break;
-#define U2_WG_SWITCH(GRID, KONLY, KSKIP, SS, SLAB)                                                                \
-    switch (nb) {                                                                                                 \
-        U2_WG(1, GRID, KONLY, KSKIP, SS, SLAB) U2_WG(2, GRID, KONLY, KSKIP, SS, SLAB)                             \
-        U2_WG(3, GRID, KONLY, KSKIP, SS, SLAB) U2_WG(4, GRID, KONLY, KSKIP, SS, SLAB)                             \
-        U2_WG(5, GRID, KONLY, KSKIP, SS, SLAB) U2_WG(6, GRID, KONLY, KSKIP, SS, SLAB)                             \
-        U2_WG(7, GRID, KONLY, KSKIP, SS, SLAB) U2_WG(8, GRID, KONLY, KSKIP, SS, SLAB)                             \
-        default: set_error("wgrad: unsupported column block count %d", nb); return 2;                             \
-    }
-    {
-        dim3 grid(p.S0, k, tiles_a * tiles_b);
-        U2_WG_SWITCH(grid, -1, p.k_centre, p.S0, slabs0)
-    }
-    if (p.k_centre >= 0) {
-        dim3 grid(p.S1, 1, tiles_a * tiles_b);
-        U2_WG_SWITCH(grid, p.k_centre, -1, p.S1, slabs1)
-    }
-#undef U2_WG_SWITCH
-#undef U2_WG
-    int64_t tile_elems = (int64_t)ca * cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 256), k), dim3(256), 0, st, slabs0,
-                       p.S0, slabs1, p.S1, p.k_centre, tile_elems, k, dw);
-    return check_launch("u2mkd_conv_wgrad");
 }
 
 }  // extern "C"

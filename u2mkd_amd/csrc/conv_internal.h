@@ -1,0 +1,24 @@
+// Internal declarations shared by the sparse-conv translation units (conv.hip, conv_tp.hip).
+#pragma once
+#include "common.h"
+
+namespace u2mkd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Rows a table-walking forward launch covers: sorted rows [begin, end) of the neighbour table
+// nbr[k * ld + row].
+struct RowRange {
+    int64_t ld, begin, end;
+    const int32_t *tile_order;   // launch order of the 64-row tiles (heaviest first) or nullptr (offset-walking kernels)
+};
+
+// Tile-local pair schedule (conv_tp.hip); wf = weight fragments of launch_weight_fragments.  Returns -1 when
+// the shape has no instantiation, else the launch status.
+int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *nbr,
+                   const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int k, int kflip,
+                   float *out, hipStream_t st, unsigned long long *stamps = nullptr);
+bool conv_tp_supported(int cin, int cout, int k);
+int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, float *wf, hipStream_t st);
+
+}  // namespace u2mkd

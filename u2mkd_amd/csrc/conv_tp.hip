@@ -1,0 +1,396 @@
+// Sparse conv forward / input gradient: the TILE-LOCAL PAIR schedule (gfx950, fp32 MFMA).
+//
+// Replaces torchsparse v1.4.0 convolution_forward_cuda / the dX half of convolution_backward_cuda
+// (gather -> cuBLAS mm -> scatter-add per kernel offset) behind the
+// spnn.Conv3d calls of core/models/build_blocks.py:25-80, for layers whose whole reduction
+// (cin) fits the register file.
+//
+// Why: the offset-walking tile kernel (conv_os2_kernel) visits the union of its 64 rows' offsets
+// one after the other, every stage behind a barrier, with a wave idle whenever its own 16 rows lack
+// the offset -- on LiDAR maps (k-bar ~3.6 of 27) the kernel time is the critical path of the tiles
+// made of rare neighbour masks (27 stages x ~4k cycles).  Here a workgroup owns a work item of <= 64
+// (mask-sorted) output rows and
+//   1. COMPACTS, per kernel offset, the rows that have a neighbour into dense lists in LDS
+//      (wave ballot + prefix popcount; one wave per offset, 64 rows per ballot), and flattens them
+//      into a list of 16-pair MFMA blocks (wave prefix sum);
+//   2. walks the blocks in a software pipeline (details at the loop).  The waves split the output
+//      COLUMNS (16*NBW each): every wave does the same work on every block and owns its columns of the
+//      LDS-resident output tile exclusively.  The gathered rows of a block are read ONCE by the
+//      workgroup, coalesced (16 lanes per row), through a 3-slot LDS image; the MFMA computes
+//      D^T = B_k x rows^T (weights as the A operand), which leaves each lane with 4 CONSECUTIVE output
+//      columns of ONE pair: the accumulate into the output tile is one ds_read_b128 + ds_write_b128;
+//   3. weights come in MFMA-fragment order (u2mkd_weight_fragments), so a wave's fragment load is
+//      1 KiB contiguous per instruction.
+// Every output row is written once, no atomics, fixed summation order (bitwise reproducible).
+// MFMA padding: sum over (tile, offset) of ceil(pairs / 16) blocks = 1.12 x dense on the 80k-voxel
+// scene (the 16-row-block walk of conv_os2: 1.29 x).
+//
+// What was measured on the way (MI355X, 64 -> 64 at 80k voxels, in-kernel s_memtime stamps):
+//   * gathering straight into MFMA operand registers (lane (r, q) loads 16 B of row r): the 4 column-split
+//     waves repeat the gather and every wave instruction is 64 uncoalesced 16-byte accesses: the texture
+//     addresser, not the MFMA pipe, bounds the kernel (83 -> 106 us when the fragments were also re-read
+//     per block);
+//   * a conditional load inside the pipelined loop makes hipcc's s_waitcnt counters inexact (vmcnt(0)
+//     before every use = no prefetch): all loads in the loop are unconditional;
+//   * __syncthreads() waits for vmcnt(0): the loop uses an LDS-only barrier;
+//   * a tile is a serial chain of blocks (up to 62 at 64 rows, mean 16): tiles above 30 / 60 blocks run as
+//     2 / 4 work items (TileSchedule in torchsparse/nn/functional.py), heaviest item first.
+#include <type_traits>
+
+#include "conv_internal.h"
+
+namespace u2mkd {
+
+// Weight fragments: B_k = the [ncol x nred] matrix whose row `col` holds the reduction channels of output
+// column `col` (forward: B_k[col][ci] = kernel[k][ci][col], transpose = 1; input gradient: B_k[ci][co] =
+// kernel[k][ci][co], transpose = 0).  Fragment layout: wf[k][cb][j][lane][4] = B_k[16 cb + r][16 j + 4 q .. +3],
+// lane = r + 16 q -- exactly the registers of one MFMA operand fragment, so a wave's load instruction reads
+// 1 KiB contiguously.
+__global__ void weight_fragments_kernel(const float *__restrict__ w, int rows, int cols, int transpose,
+                                        float *__restrict__ wf, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
+    const int c = (int)(t & 3);
+    const int lane = (int)((t >> 2) & 63);
+    int64_t u = t >> 8;
+    const int nj = nred / 16, ncb = ncol / 16;
+    const int j = (int)(u % nj);
+    u /= nj;
+    const int cb = (int)(u % ncb);
+    const int64_t k = u / ncb;
+    const int col = 16 * cb + (lane & 15), red = 16 * j + 4 * (lane >> 4) + c;
+    wf[t] = transpose ? w[((size_t)k * rows + red) * cols + col] : w[((size_t)k * rows + col) * cols + red];
+}
+
+template <int NW, int NBW, int CIN, bool STAMP>
+__global__ void __launch_bounds__(64 * NW)
+conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int cout, const int32_t *__restrict__ nbr,
+               const int32_t *__restrict__ order, RowRange rr_, const int32_t *__restrict__ items,
+               const int32_t *__restrict__ n_items_dev, int K, int kflip, float *__restrict__ out,
+               unsigned long long *__restrict__ stamps) {
+    // STAMP (tools/stamps_tp.py only): per workgroup {realtime start, cycles start, after compaction, after the block
+    // walk, end, realtime end, blocks, tile}; the product instantiation has none of it
+    unsigned long long t_rt0 = 0, t_c0 = 0, t_c1 = 0, t_c2 = 0;
+    int n_blocks = 0;
+    if (STAMP) { t_rt0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_amdgcn_s_memtime(); }
+    constexpr int T = 64, NT = 64 * NW, TN = 16 * NW * NBW, NJ = CIN / 16;
+    constexpr int OS = TN + 4;                    // output tile row stride (floats)
+    constexpr int AS = CIN + 4;                   // gathered-row image row stride (floats)
+    constexpr int CPR = CIN / 4;                  // 16-byte chunks per gathered row
+    constexpr int LPT = (16 * CPR + NT - 1) / NT; // chunks a thread moves per block
+    constexpr int KPW = (32 + NW - 1) / NW;       // offsets a wave compacts (K <= 32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_out = reinterpret_cast<float *>(smem);                           // [T][OS]
+    float *s_a = s_out + T * OS;                                              // [3][16][AS] gathered rows of blocks t .. t+2
+    int *s_idx = reinterpret_cast<int *>(s_a + 3 * 16 * AS);                  // [K+1][T] compacted input rows (+ sentinel row)
+    int *s_cnt = s_idx + (K + 1) * T;                                         // [32] pairs per offset
+    int *s_rid = s_cnt + 32;                                                  // [T] original output row
+    int *s_blk = s_rid + T;                                                   // [4K + 8] block descriptors
+    unsigned char *s_row = reinterpret_cast<unsigned char *>(s_blk + 4 * K + 8);   // [K+1][T] tile row of each entry
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int col0 = blockIdx.y * TN;
+    const int64_t n_out = rr_.end, ld = rr_.ld;
+    // Work items: a 64-row tile or, for tiles with many blocks, a half / a quarter of one (a tile is a serial
+    // chain of blocks: the heaviest tiles would set the kernel time).  item = tile << 4 | sub << 2 | lg with
+    // 64 >> lg rows starting at row 64 tile + (64 >> lg) sub, listed heaviest first, one workgroup per item; the
+    // grid is sized by the host-known upper bound, surplus workgroups leave at once.
+    if (items && (int)blockIdx.x >= *n_items_dev) return;
+    const int code = items ? items[blockIdx.x] : ((int)blockIdx.x << 4);
+    const int R = T >> (code & 3);                        // rows of this item
+    const int64_t row0 = rr_.begin + (int64_t)(code >> 4) * T + ((code >> 2) & 3) * R;
+
+    // ---- 1. neighbour indices of the tile (one burst of independent loads), compaction per offset
+    int v[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        int kk = wave + i * NW;
+        int64_t row = row0 + lane;
+        v[i] = (kk < K && lane < R && row < n_out) ? nbr[(int64_t)kk * ld + row] : -1;
+    }
+    for (int e = tid; e < T * OS / 4; e += NT) reinterpret_cast<float4 *>(s_out)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < T; e += NT) {
+        int64_t row = row0 + e;
+        s_rid[e] = (e < R && row < n_out) ? (order ? order[row] : (int)row) : -1;
+    }
+    if (tid >= K && tid < 32) s_cnt[tid] = 0;            // (entries < K are written by the compaction below)
+    if (tid < T) { s_idx[K * T + tid] = -1; s_row[K * T + tid] = 0; }
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        int kk = wave + i * NW;
+        if (kk < K) {
+            const bool valid = v[i] >= 0;
+            const unsigned long long bal = __ballot(valid);
+            const int cnt = __popcll(bal);
+            const int rank = __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (valid) {
+                s_idx[kk * T + rank] = v[i];
+                s_row[kk * T + rank] = (unsigned char)lane;
+            }
+            if (lane >= cnt && lane < ((cnt + 15) & ~15)) {   // pad the last block
+                s_idx[kk * T + lane] = -1;
+                s_row[kk * T + lane] = 0;
+            }
+            if (lane == 0) s_cnt[kk] = cnt;
+        }
+    }
+    __syncthreads();
+
+    if (STAMP) t_c1 = __builtin_amdgcn_s_memtime();
+    // ---- 2. the tile's (offset, 16-pair block) sequence as a flat list: descriptor = offset << 8 | block.
+    // Every wave writes the same values (a wave reads back its own writes, no barrier needed); the list is
+    // followed by sentinel blocks (offset K: an all -1 index row) so the pipeline can run ahead of the end
+    // without conditionals.
+    const int myc = lane < 32 ? s_cnt[lane] : 0;
+    int total;
+    {
+        const int nbk = (myc + 15) >> 4;
+        int incl = nbk;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        total = __builtin_amdgcn_readlane(incl, 31);
+        const int start = incl - nbk;
+        if (lane < 32)
+            for (int b = 0; b < nbk; ++b) s_blk[start + b] = (lane << 8) | b;
+        if (lane < 8) s_blk[total + lane] = K << 8;          // desc(t + 6) is read at the last step
+    }
+
+    // ---- 3. software pipeline over the blocks.  Block b's data moves through five steps, all waves in
+    // lockstep (one barrier per step; every wave does the same work in every step):
+    //   step b-4  gather issue: 16 rows x CIN floats, one 16-byte chunk per thread, 16 consecutive lanes read
+    //             one row's contiguous bytes (a gather straight into MFMA operand registers is 64 uncoalesced
+    //             16-byte accesses per wave instruction -- measured texture-addresser-bound -- and repeats the
+    //             gather in every column-split wave);
+    //   step b-2  the rows are stored into one third of the LDS row image (3 slots: the slot stored at step t
+    //             was last read at step t-1, one barrier earlier);
+    //   step b-1  this wave's weight fragment of block b's offset is issued (1 KiB contiguous per instruction; re-loading an unchanged
+    //             offset is an L1 hit -- loads stay UNCONDITIONAL so that the compiler's s_waitcnt counters
+    //             stay exact: with conditional loads in the loop they degrade to vmcnt(0) before every use);
+    //   step b-1  the pair's (input row, output row) are read from LDS;
+    //   step b    the MFMA operand fragments are read from LDS, multiplied, accumulated into the output tile.
+    // Every LDS / global read a step needs was issued at least one step earlier, so a step is its 16*NBW*NJ/4
+    // MFMAs + one barrier (in-kernel stamps of the straightforward order: 2.0k cycles per step, 0.5k of them MFMA).
+    // The MFMA computes D^T = B_k (A operand) x rows^T (B operand): a lane ends up with 4 consecutive output
+    // columns of ONE pair.  Lanes of a padded last block (idx < 0) multiply row 0 and drop the result.
+    float4 bw[2][NJ][NBW], a[NJ];
+    f32x4 g[3][LPT];      // (native vector type: the HIP float4 struct kept this ring in scratch memory)
+    int gix[LPT];                                  // gather row of this thread's chunk(s), block t+4
+    int pidx[2], prow[2];                          // (input row, output tile row) of pair r, blocks t / t+1
+    const int kf = kflip & 1;
+    const int ncb = cout / 16;
+    const int cb0 = col0 / 16 + NBW * wave;
+
+    auto desc = [&](int t) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(s_blk[t]); };
+    auto dbase = [&](int d) __attribute__((always_inline)) { return (d >> 8) * T + 16 * (d & 255); };
+    auto issue_B = [&](int d, float4 (&bb)[NJ][NBW]) __attribute__((always_inline)) {
+        int k = d >> 8;
+        if (k >= K) k = K - 1;                        // sentinel block: any valid fragment
+        if (kf) k = K - 1 - k;
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+            int cb = cb0 + n;
+            if (cb >= ncb) cb = ncb - 1;              // column blocks past cout: computed, never stored
+            const float *pb = wf + ((((size_t)k * ncb + cb) * NJ) * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bb[j][n] = *reinterpret_cast<const float4 *>(pb + (size_t)j * 256);
+        }
+    };
+    auto read_gix = [&](int d) __attribute__((always_inline)) {
+        const int base = dbase(d);
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int e = tid + i * NT;
+            gix[i] = e < 16 * CPR ? s_idx[base + e / CPR] : 0;
+        }
+    };
+    auto issue_G = [&](f32x4 (&gg)[LPT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int e = tid + i * NT;
+            const int ch = e % CPR;
+            const int ix = gix[i] >= 0 ? gix[i] : 0;
+            gg[i] = *reinterpret_cast<const f32x4 *>(in + (size_t)ix * CIN + 4 * ch);
+        }
+    };
+    auto store_G = [&](const f32x4 (&gg)[LPT], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int e = tid + i * NT;
+            const int pr = e / CPR, ch = e - pr * CPR;
+            if (e < 16 * CPR) *reinterpret_cast<f32x4 *>(s_a + (slot * 16 + pr) * AS + 4 * ch) = gg[i];
+        }
+    };
+    auto read_frag = [&](int slot, float4 (&aa)[NJ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            aa[j] = *reinterpret_cast<const float4 *>(s_a + (slot * 16 + r) * AS + 16 * j + 4 * q);
+    };
+
+    if (total > 0) {
+        int d1 = desc(1), d2 = desc(2), d5 = desc(5);
+        {
+            const int d0 = desc(0);
+            read_gix(d0); issue_G(g[0]);
+            read_gix(d1); issue_G(g[1]);
+            read_gix(d2); issue_G(g[2]);
+            issue_B(d0, bw[0]);
+            store_G(g[0], 0);
+            read_gix(desc(3)); issue_G(g[0]);
+            store_G(g[1], 1);
+            read_gix(desc(4));
+            pidx[0] = s_idx[dbase(d0) + r];
+            prow[0] = s_row[dbase(d0) + r];
+            __syncthreads();
+        }
+        // one step, `u` = t mod 6 as a compile-time constant (ring positions are static register names)
+        auto step = [&](auto U, int t) __attribute__((always_inline)) {
+            constexpr int u = decltype(U)::value;
+                // -- issue everything later steps need
+            read_frag(u % 3, a);                                     // block t (stored at step t-2, barrier since)
+            issue_G(g[(u + 4) % 3]);                                 // block t+4
+            issue_B(d1, bw[(u + 1) & 1]);                            // block t+1
+            read_gix(d5);                                            // block t+5
+            pidx[(u + 1) & 1] = s_idx[dbase(d1) + r];                // block t+1
+            prow[(u + 1) & 1] = s_row[dbase(d1) + r];
+            const int d6 = desc(t + 6);
+            // -- block t: the old output values first (in flight under the MFMAs), then the products
+            const bool live = pidx[u & 1] >= 0;
+            float4 *po[NBW];
+            float4 o[NBW];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                po[n] = reinterpret_cast<float4 *>(s_out + prow[u & 1] * OS + 16 * (NBW * wave + n) + 4 * q);
+                o[n] = *po[n];
+            }
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)
+                f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].x, a[j].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].y, a[j].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].z, a[j].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].w, a[j].w, acc1, 0, 0, 0);
+                }
+                // D^T: lane (r, q) holds columns 4q .. 4q+3 of pair r
+                if (live) {
+                    o[n].x += acc0[0] + acc1[0];
+                    o[n].y += acc0[1] + acc1[1];
+                    o[n].z += acc0[2] + acc1[2];
+                    o[n].w += acc0[3] + acc1[3];
+                    *po[n] = o[n];
+                }
+            }
+            store_G(g[(u + 2) % 3], (u + 2) % 3);                    // block t+2 (gathered at step t-2)
+            d1 = d2;
+            d2 = desc(t + 3);
+            d5 = d6;
+            if (STAMP) ++n_blocks;
+            // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. it would drain the gathers and
+            // weight fragments in flight for the next steps at every step
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        for (int t0 = 0; t0 < total; t0 += 6) {
+            step(std::integral_constant<int, 0>{}, t0);
+            if (t0 + 1 >= total) break;
+            step(std::integral_constant<int, 1>{}, t0 + 1);
+            if (t0 + 2 >= total) break;
+            step(std::integral_constant<int, 2>{}, t0 + 2);
+            if (t0 + 3 >= total) break;
+            step(std::integral_constant<int, 3>{}, t0 + 3);
+            if (t0 + 4 >= total) break;
+            step(std::integral_constant<int, 4>{}, t0 + 4);
+            if (t0 + 5 >= total) break;
+            step(std::integral_constant<int, 5>{}, t0 + 5);
+        }
+    }
+    if (STAMP) t_c2 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+
+    // ---- 4. epilogue: whole rows of the tile, 16-byte coalesced, to their original positions
+    constexpr int F4 = TN / 4;
+    for (int e = tid; e < T * F4; e += NT) {
+        const int row = e / F4, c4 = e - row * F4;
+        const int rid = s_rid[row];
+        const int col = col0 + 4 * c4;
+        if (rid >= 0 && col < cout)
+            *reinterpret_cast<float4 *>(out + (size_t)rid * cout + col) =
+                *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
+    }
+    if (STAMP && tid == 0) {
+        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
+        o[0] = t_rt0; o[1] = t_c0; o[2] = t_c1; o[3] = t_c2; o[4] = __builtin_amdgcn_s_memtime();
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = (unsigned long long)n_blocks; o[7] = (unsigned long long)code;
+    }
+}
+
+template <int NW, int NBW, int CIN, bool STAMP = false>
+static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const float *wt, int cout, const int32_t *nbr,
+                      const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
+                      float *out, unsigned long long *stamps = nullptr) {
+    constexpr int TN = 16 * NW * NBW;
+    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)3 * 16 * (CIN + 4) * 4 + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
+                       (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
+    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
+                       items, n_items, K, kflip, out, stamps);
+}
+
+// column split: cout -> (waves, 16-column blocks per wave, columns per workgroup)
+static bool tp_split(int cout, int &nw, int &nbw) {
+    if (cout % 16 != 0) return false;
+    switch (cout) {
+        case 32: nw = 2; nbw = 1; return true;
+        case 64: nw = 4; nbw = 1; return true;
+        case 96: nw = 3; nbw = 2; return true;
+        case 128: nw = 4; nbw = 2; return true;
+        default: return false;
+    }
+}
+
+bool conv_tp_supported(int cin, int cout, int k) {
+    int nw, nbw;
+    if (k < 1 || k > 32 || !tp_split(cout, nw, nbw)) return false;
+    if (!(cin == 32 || cin == 64 || cin == 96 || cin == 128)) return false;
+    return cin * nbw <= 128;      // weight fragment (double-buffered) + gathered rows stay in registers
+}
+
+int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *nbr,
+                   const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int k, int kflip,
+                   float *out, hipStream_t st, unsigned long long *stamps) {
+    if (!conv_tp_supported(cin, cout, k)) return -1;
+    int nw = 0, nbw = 0;
+    tp_split(cout, nw, nbw);
+    const int64_t n_rows = rr.end - rr.begin;
+    dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile
+#define U2_TP(NW_, NBW_, CIN_) launch_tp<NW_, NBW_, CIN_>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out)
+    if (nw == 2) {
+        if (cin == 32) U2_TP(2, 1, 32); else if (cin == 64) U2_TP(2, 1, 64);
+        else if (cin == 96) U2_TP(2, 1, 96); else U2_TP(2, 1, 128);
+    } else if (nw == 4 && nbw == 1) {
+        if (stamps && cin == 64) launch_tp<4, 1, 64, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        else if (cin == 32) U2_TP(4, 1, 32); else if (cin == 64) U2_TP(4, 1, 64);
+        else if (cin == 96) U2_TP(4, 1, 96); else U2_TP(4, 1, 128);
+    } else if (nw == 3) {
+        if (cin == 32) U2_TP(3, 2, 32); else U2_TP(3, 2, 64);
+    } else {
+        if (cin == 32) U2_TP(4, 2, 32); else U2_TP(4, 2, 64);
+    }
+#undef U2_TP
+    return check_launch(who);
+}
+
+int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, float *wf, hipStream_t st) {
+    const int64_t total = (int64_t)k * rows * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, rows, cols,
+                       transpose, wf, total);
+    return check_launch("u2mkd_weight_fragments");
+}
+
+}  // namespace u2mkd

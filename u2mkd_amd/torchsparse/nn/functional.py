@@ -267,6 +267,10 @@ def _scratch(nbytes, device):
     return buf
 
 
+_TILE_SPLIT = tuple(int(v) for v in os.environ.get('U2MKD_TILE_SPLIT', '30,60').split(','))   # blocks above which a 64-row tile
+# is processed as 2 / 4 work items (measured: tools/ab_tp.py)
+
+
 class TileSchedule:
     """Output-stationary walk of a neighbour table [K, N]: 64-row tiles of the table in SORTED
     row order, each tile visits the union of its rows' offsets serially.  Rows are sorted by
@@ -290,18 +294,48 @@ class TileSchedule:
         t = (n + 63) // 64
         ms = torch.zeros(t * 64, dtype=torch.int32, device=dev)
         ms[:n] = mask[order]
-        bits = (ms.view(t, 64, 1) >> torch.arange(k, dtype=torch.int32, device=dev)) & 1
-        stages = bits.amax(1).sum(1)
-        self.tile_order = torch.argsort(stages, descending=True, stable=True).int()
+        bits = (ms.view(t, 4, 16, 1) >> torch.arange(k, dtype=torch.int32, device=dev)) & 1
+        c16 = bits.sum(2)                                           # pairs per (tile, 16-row quarter, offset)
+        # work of a set of rows = its 16-pair MFMA blocks, sum over offsets of ceil(pairs / 16)
+        b4 = ((c16 + 15) >> 4).sum(2)                               # [t, 4]  quarters
+        b2 = ((c16.view(t, 2, 2, k).sum(2) + 15) >> 4).sum(2)       # [t, 2]  halves
+        b1 = ((c16.sum(1) + 15) >> 4).sum(1)                        # [t]     whole tiles
+        self.tile_order = torch.argsort(b1, descending=True, stable=True).int()   # offset-walking kernels
+        # Work items of the tile-pair kernel (u2mkd_conv_forward_tiles): a tile is a SERIAL chain of blocks, so
+        # the heaviest tiles (rows with rare neighbour masks: up to 62 blocks against a mean of 16) are cut into
+        # halves / quarters; items are listed heaviest first.  item = tile << 4 | sub << 2 | lg.  Built without a
+        # host sync: 7 candidates per tile, the ones not chosen (or without rows) sort to the end.
+        lg = (b1 > _TILE_SPLIT[0]).int() + (b1 > _TILE_SPLIT[1]).int()          # [t] 0 / 1 / 2
+        tid = torch.arange(t, dtype=torch.int32, device=dev)
+        rows_left = n - tid * 64                                                # rows of the tile that exist
+        cand_w, cand_code = [], []
+        for l, bl in ((0, b1.view(t, 1)), (1, b2), (2, b4)):
+            nsub = 1 << l
+            sub = torch.arange(nsub, dtype=torch.int32, device=dev).view(1, nsub)
+            live = (lg.view(t, 1) == l) & (sub * (64 >> l) < rows_left.view(t, 1))
+            cand_w.append(torch.where(live, bl.int(), -1).reshape(-1))
+            cand_code.append(((tid.view(t, 1) << 4) | (sub << 2) | l).reshape(-1))
+        w = torch.cat(cand_w)
+        srt = torch.argsort(w, descending=True, stable=True)
+        self.items = torch.cat(cand_code)[srt].int().contiguous()
+        self.n_items = (w >= 0).sum().int().view(1)
 
     def tiles(self):
         return self.nbr_s, self.order
 
-    def run(self, feats, wt, cout, kflip, out, variant=0):
-        """out[j] = sum_k feats[tbl[k][j]] @ B_k,  B_k = wt[kflip ? K-1-k : k] as [cout][cin]."""
+    def run(self, feats, weight, transpose, cout, kflip, out):
+        """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k[col][ci] = weight[kk][ci][col] (transpose, the forward) or
+        weight[kk][col][ci] (the input gradient), kk = K-1-k if kflip else k; weight = `kernel` [K, cin, cout]."""
         n_in, cin = feats.shape
-        L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(self.nbr_s),
-               L.ptr(self.order), L.ptr(self.tile_order), self.n, self.k, int(kflip), variant, L.ptr(out), L.stream())
+        if L.load().u2mkd_conv_tiles_supported(cin, cout, self.k):
+            wf = _weight_layout(weight, transpose, True)
+            L.call('u2mkd_conv_forward_tiles', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), L.ptr(out),
+                   L.stream())
+        else:
+            wt = _weight_layout(weight, transpose, False)
+            L.call('u2mkd_conv_forward_sorted', L.ptr(feats), n_in, cin, L.ptr(wt), cout, L.ptr(self.nbr_s),
+                   L.ptr(self.order), L.ptr(self.tile_order), self.n, self.k, int(kflip), L.ptr(out), L.stream())
         return out
 
 
@@ -491,37 +525,52 @@ def prefetch_kmaps(x: SparseTensor, specs) -> None:
 
 
 # --------------------------------------------------------------------- conv
-def _conv_os(feats, wt, cout, kmap, inverse, n_rows, kflip):
-    """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k = wt[kflip ? K-1-k : k] as [cout][cin];
-    tbl = the kernel map's (inverse) neighbour table.  kflip = 1 is the input gradient of a
-    symmetric (submanifold) map computed on the forward table with mirrored offsets -- in the
+def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
+    """out[j] = sum_k feats[tbl[k][j]] @ B_k, tbl = the kernel map's (inverse) neighbour table, B_k taken from
+    `weight` = kernel [K, cin, cout]: B_k[col][ci] = weight[kk][ci][col] (transpose = True: the forward) or
+    weight[kk][col][ci] (False: the input gradient), kk = K-1-k if kflip else k.  kflip = 1 is the input
+    gradient of a symmetric (submanifold) map computed on the forward table with mirrored offsets -- in the
     pair schedule that is simply the swapped-role walk."""
     out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
     if _pairs_mode(feats.shape[1], cout):
+        wt = _weight_layout(weight, transpose, False)
         return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
     if inverse and kmap.nbr_inv is None:      # symmetric map: the inverse table is the mirrored forward table
         inverse, kflip = False, 1 - int(kflip)
     sch = kmap.schedule(inverse)
     assert sch.n == n_rows
-    return sch.run(feats, wt, cout, kflip, out)
+    return sch.run(feats, weight, transpose, cout, kflip, out)
+
+
+def _weight_layout(weight, transpose, fragments):
+    """The layout of `kernel` [K, R, C] a conv kernel reads: rows of B_k = output columns, reduction contiguous.
+    transpose: B_k[col][red] = weight[k][red][col] (else weight[k][col][red], the tensor as it is).
+    fragments: MFMA operand-fragment order (u2mkd_weight_fragments) instead of row-major [K, ncol, nred].
+    For FROZEN weights (requires_grad False: the KD teacher, inference) the result is cached on the tensor
+    together with its in-place version; trained weights are re-laid out per call."""
+    if not transpose and not fragments:
+        return weight
+    k, r, c = weight.shape
+    frozen = not weight.requires_grad
+    key = '_u2mkd_w%d%d' % (int(transpose), int(fragments))
+    if frozen:
+        hit = weight.__dict__.get(key)
+        if hit is not None and hit[0] == weight._version and hit[1].numel() == weight.numel():
+            return hit[1]
+    if fragments:
+        out = torch.empty(k * r * c, dtype=torch.float32, device=weight.device)
+        L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, int(transpose), L.ptr(out), L.stream())
+    else:
+        out = torch.empty(k, c, r, dtype=torch.float32, device=weight.device)
+        L.call('u2mkd_transpose_weights', L.ptr(weight), k, r, c, L.ptr(out), L.stream())
+    if frozen:
+        weight.__dict__[key] = (weight._version, out)
+    return out
 
 
 def _transpose_weights(weight):
-    """kernel [K, cin, cout] -> [K, cout, cin] (reduction dim contiguous for the MFMA B operand).
-    For FROZEN weights (requires_grad False: the KD teacher, inference) the result is cached on
-    the tensor object together with its in-place version; trained weights are transposed per call
-    (an optimizer that writes through ``.data`` would not bump the version)."""
-    k, cin, cout = weight.shape
-    frozen = not weight.requires_grad
-    if frozen:
-        hit = weight.__dict__.get('_u2mkd_wt')
-        if hit is not None and hit[0] == weight._version and hit[1].shape == (k, cout, cin):
-            return hit[1]
-    wt = torch.empty(k, cout, cin, dtype=torch.float32, device=weight.device)
-    L.call('u2mkd_transpose_weights', L.ptr(weight), k, cin, cout, L.ptr(wt), L.stream())
-    if frozen:
-        weight.__dict__['_u2mkd_wt'] = (weight._version, wt)
-    return wt
+    """kernel [K, cin, cout] -> [K, cout, cin] (reduction dim contiguous for the MFMA B operand)."""
+    return _weight_layout(weight, True, False)
 
 
 _IDENTITY_PAIRS = {}
@@ -637,8 +686,7 @@ class ConvolutionFunction(Function):
             expect = kmap.n_out
         if input.shape[0] != expect:
             raise RuntimeError(f'conv3d: {input.shape[0]} input rows, kernel map expects {expect}')
-        wt = _transpose_weights(weight)
-        out = _conv_os(input, wt, cout, kmap, inverse, n_rows, 0)
+        out = _conv_os(input, weight, True, cout, kmap, inverse, n_rows, 0)
         ctx.save_for_backward(input, weight)
         ctx.kmap = kmap
         ctx.transposed = transposed
@@ -681,7 +729,7 @@ class ConvolutionFunction(Function):
                 inverse, kflip = False, 0
             if cout % 4 != 0:
                 raise RuntimeError(f'conv3d backward: out_channels={cout} must be a multiple of 4')
-            grad_input = _conv_os(g, weight, cin, kmap, inverse, input.shape[0], kflip)
+            grad_input = _conv_os(g, weight, False, cin, kmap, inverse, input.shape[0], kflip)
         if side is not None:
             torch.cuda.current_stream(g.device).wait_stream(side)
         return grad_input, grad_weight, None, None

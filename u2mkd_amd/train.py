@@ -29,6 +29,33 @@ def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4):
     return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
 
 
+class _Amp:
+    """``amp.autocast(enabled)`` + ``amp.GradScaler(enabled)`` of the reference trainers
+    (core/nusc_trainers.py:157-158,285,362-364; core/spformer_trainer.py likewise).  amp = False / None: fp32
+    (the parity path); 'fp16': the reference's mode (autocast to half + loss scaling); 'bf16': autocast to
+    bfloat16, no loss scaling needed (fp32 exponent range) -- BASELINE.json configs[4].  The sparse operators
+    of this package take fp32 rows (like torchsparse's fp32-only CPU backend, they up-cast their inputs), so
+    under autocast the dense torch.nn layers -- the SwiftNet-18 camera branch above all -- run reduced."""
+
+    def __init__(self, amp):
+        if amp is True:
+            amp = 'fp16'
+        if amp not in (None, False, 'fp16', 'bf16'):
+            raise ValueError(f'amp must be False, "fp16" or "bf16", got {amp!r}')
+        self.dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(amp)
+        self.enabled = self.dtype is not None
+        self.scaler = torch.amp.GradScaler('cuda', enabled=(amp == 'fp16'))
+
+    def autocast(self):
+        return torch.autocast('cuda', dtype=self.dtype or torch.float16, enabled=self.enabled)
+
+    def backward_and_step(self, loss, opt):
+        opt.zero_grad()
+        self.scaler.scale(loss).backward()
+        self.scaler.step(opt)
+        self.scaler.update()
+
+
 def _scheduler(opt, num_epochs, batch_size, dataset_size=28130):
     w = D.world()
     return torch.optim.lr_scheduler.LambdaLR(
@@ -38,21 +65,21 @@ def _scheduler(opt, num_epochs, batch_size, dataset_size=28130):
 class LidarStep:
     """Teacher / LiDAR-only training step."""
 
-    def __init__(self, model, num_epochs=25, batch_size=1, ignore_index=0):
+    def __init__(self, model, num_epochs=25, batch_size=1, ignore_index=0, amp=False):
         self.model = model
+        self.amp = _Amp(amp)
         self.net = D.wrap_model(model, sync_bn=True)
         self.criterion = MixLovaszCrossEntropy(ignore_index=ignore_index)
         self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
         self.sched = _scheduler(self.opt, num_epochs, batch_size)
 
     def __call__(self, feats, coords, targets, keyframe_mask=None):
-        out = self.net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
-        if keyframe_mask is not None:
-            out, targets = out[keyframe_mask], targets[keyframe_mask]
-        loss = self.criterion(out, targets)
-        self.opt.zero_grad()
-        loss.backward()
-        self.opt.step()
+        with self.amp.autocast():
+            out = self.net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+            if keyframe_mask is not None:
+                out, targets = out[keyframe_mask], targets[keyframe_mask]
+            loss = self.criterion(out, targets)
+        self.amp.backward_and_step(loss, self.opt)
         self.sched.step()
         return loss.detach()
 
@@ -78,8 +105,9 @@ class KDStep:
     """Uni-to-multi-modal KD training step: frozen teacher forward (no grad, eval-mode BN),
     student forward/backward, the five loss terms."""
 
-    def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0):
+    def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0, amp=False):
         self.model = model
+        self.amp = _Amp(amp)
         if D.world() > 1:
             from .lidar.point_voxel import SparseSyncBatchNorm
             model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
@@ -96,11 +124,10 @@ class KDStep:
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
                'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
         tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
-        out = self.net({'student': stu, 'teacher': tea})
-        ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
-                          self.crit, d['keyframe_mask_full'])
-        self.opt.zero_grad()
-        ld['total'].backward()
-        self.opt.step()
+        with self.amp.autocast():
+            out = self.net({'student': stu, 'teacher': tea})
+            ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
+                              self.crit, d['keyframe_mask_full'])
+        self.amp.backward_and_step(ld['total'], self.opt)
         self.sched.step()
         return ld['total'].detach()
