@@ -150,6 +150,9 @@ int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const floa
                                        const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
                                        const int32_t *n_items, int64_t n_out, int32_t k, float *out, uint64_t *stamps,
                                        u2mkd_stream_t s);
+/* Profiling only: the 64 x 64 weight-gradient kernel with s_memtime stamps of workgroup 0 (stamps [256]). */
+int u2mkd_debug_wgrad_stamps(const float *a, const float *b, const int32_t *pairs, const int32_t *plan, int64_t n_rows,
+                             int32_t k, void *workspace, uint64_t *stamps, u2mkd_stream_t s);
 /* y[p] = in[pair_idx[p]] * B_{tile_k[p / 64]} over the pair schedule of u2mkd_pairs_build
  * (pair_idx = pair_in for a normal conv, pair_out for a transposed conv / the input gradient):
  * one dense MFMA stage per 64-pair tile, no serial walk over offsets.  meta (device) holds
@@ -184,6 +187,33 @@ size_t u2mkd_conv_wgrad_pairs_workspace_bytes(int64_t n_rows, int32_t ca, int32_
 int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs /*[>=P,2]*/,
                            const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
                            size_t workspace_bytes, float *dw /*[k,ca,cb]*/, u2mkd_stream_t s);
+
+/* ---- torchsparse v1.4.0 backend format ---------------------------------------
+ * replace torchsparse.backend.convolution_forward_cuda(in_feat, out_feat, kernel, neighbor_map,
+ * neighbor_offset, transpose) and convolution_backward_cuda(in_feat, grad_in_feat, grad_out_feat, kernel,
+ * grad_kernel, neighbor_map, neighbor_offset, transpose) argument for argument (ConvolutionFunction of
+ * torchsparse/nn/functional/conv.py, behind every spnn.Conv3d of core/models/build_blocks.py:25-80), for a
+ * caller that already holds a v1.4.0 kernel map: neighbor_map = nbmaps int32 [P,2] rows (in, out) grouped
+ * by kernel offset (DEVICE), neighbor_offset = nbsizes int32 [k] pairs per offset ON THE HOST (v1.4.0 keeps
+ * it on the CPU).  transpose = 0: out[out_idx] += in[in_idx] W_k;  transpose = 1: out[in_idx] += in[out_idx] W_k
+ * (roles of the two map columns swapped, as the transposed conv of build_blocks.py:39-52 calls it).
+ * kernel / grad_kernel: [k, cin, cout].  Outputs are fully written (the reference pre-zeroes and accumulates:
+ * same result).  Everything else lives in `workspace` (u2mkd_convolution_workspace_bytes); cin and cout must be
+ * multiples of 4.  The rulebook is re-laid into the pair schedule on the fly (one scatter kernel), then runs
+ * on u2mkd_conv_forward_pairs + u2mkd_pairs_gather_sum / u2mkd_conv_wgrad_pairs (deterministic).  grad_in_feat
+ * or grad_kernel may be NULL (skipped).                                                                   */
+size_t u2mkd_convolution_workspace_bytes(int64_t n_in_rows, int64_t n_out_rows, int32_t cin, int32_t cout,
+                                         const int32_t *nbsizes_host /*[k] HOST*/, int32_t k);
+int u2mkd_convolution_forward(const float *in_feat /*[n_in_rows,cin]*/, int64_t n_in_rows, int32_t cin,
+                              float *out_feat /*[n_out_rows,cout]*/, int64_t n_out_rows, int32_t cout,
+                              const float *kernel /*[k,cin,cout]*/, const int32_t *nbmaps /*[P,2] device*/,
+                              const int32_t *nbsizes_host /*[k] HOST*/, int32_t k, int32_t transpose, void *workspace,
+                              size_t workspace_bytes, u2mkd_stream_t s);
+int u2mkd_convolution_backward(const float *in_feat /*[n_in_rows,cin]*/, int64_t n_in_rows, int32_t cin,
+                               float *grad_in_feat /*[n_in_rows,cin] or NULL*/, const float *grad_out_feat /*[n_out_rows,cout]*/,
+                               int64_t n_out_rows, int32_t cout, const float *kernel /*[k,cin,cout]*/,
+                               float *grad_kernel /*[k,cin,cout] or NULL*/, const int32_t *nbmaps, const int32_t *nbsizes_host,
+                               int32_t k, int32_t transpose, void *workspace, size_t workspace_bytes, u2mkd_stream_t s);
 
 /* ---- point <-> voxel ---------------------------------------------------
  * replace torchsparse.backend.count_cuda, voxelize_forward/backward_cuda,

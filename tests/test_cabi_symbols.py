@@ -30,7 +30,7 @@ def test_host_only_entry_points():
     assert lib.u2mkd_version() >= 100
     assert lib.u2mkd_hash_table_bytes(1000) == 2048 * 12
     assert lib.u2mkd_hash_table_bytes(80000) == 262144 * 12
-    assert lib.u2mkd_conv_wgrad_pairs_workspace_bytes(80000, 64, 64, 27) == (768 + 27) * 64 * 64 * 4
+    assert lib.u2mkd_conv_wgrad_pairs_workspace_bytes(80000, 64, 64, 27) == (1024 + 27) * 64 * 64 * 4
     assert lib.u2mkd_wgrad_plan_ints(27) == 58
 
 

@@ -362,3 +362,55 @@ def test_batch_norm_matches_torch_cpu(F, n, c, relu):
         assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked)
         ref.zero_grad()
         ours.zero_grad()
+
+
+@pytest.mark.parametrize('kind', ['subm', 'down', 'up'])
+@pytest.mark.parametrize('cin,cout', [(32, 64), (96, 48)])
+def test_v140_backend_format_entries(F, kind, cin, cout):
+    """u2mkd_convolution_forward / _backward take the v1.4.0 rulebook as torchsparse.backend's
+    convolution_forward_cuda / convolution_backward_cuda do: (neighbor_map [P,2] on the device,
+    neighbor_offset [K] on the HOST, transpose).  The rulebook fed here is the oracle's own (nonzero order),
+    not one derived from this library's tables."""
+    import ctypes
+    from u2mkd_amd import _lib as L
+    coords, _ = _scene(2200, 2, seed=5)
+    torch.manual_seed(3)
+    ks, st_ = (3, 1) if kind == 'subm' else (2, 2)
+    nbmaps, nbsizes, oc, _ = R.build_kmap(coords, 1, ks, st_)
+    k = ks ** 3
+    sizes = (len(coords), len(oc))
+    transposed = kind == 'up'
+    n_in, n_out = (sizes[1], sizes[0]) if transposed else sizes
+    x = torch.randn(n_in, cin)
+    w = torch.randn(k, cin, cout) / (k * cin) ** 0.5
+    g = torch.randn(n_out, cout)
+    want = R.conv_forward(x, w, nbmaps, nbsizes, sizes, transposed=transposed)
+    want_gi, want_gw = R.conv_backward(x, w, g, nbmaps, nbsizes, transposed=transposed)
+    nb_dev = _dev(np.asarray(nbmaps, dtype=np.int32))
+    sizes_host = (ctypes.c_int32 * k)(*[int(v) for v in nbsizes])
+    lib = L.load()
+    nbytes = lib.u2mkd_convolution_workspace_bytes(n_in, n_out, cin, cout, sizes_host, k)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    xd, wd, gd = x.cuda(), w.cuda(), g.cuda()
+    out = torch.full((n_out, cout), float('nan'), device='cuda')
+    L.call('u2mkd_convolution_forward', L.ptr(xd), n_in, cin, L.ptr(out), n_out, cout, L.ptr(wd), L.ptr(nb_dev),
+           ctypes.addressof(sizes_host), k, int(transposed), L.ptr(ws), nbytes, L.stream())
+    assert _rel(out, want) < 1e-4
+    gi = torch.full((n_in, cin), float('nan'), device='cuda')
+    gw = torch.full((k, cin, cout), float('nan'), device='cuda')
+    L.call('u2mkd_convolution_backward', L.ptr(xd), n_in, cin, L.ptr(gi), L.ptr(gd), n_out, cout, L.ptr(wd), L.ptr(gw),
+           L.ptr(nb_dev), ctypes.addressof(sizes_host), k, int(transposed), L.ptr(ws), nbytes, L.stream())
+    assert _rel(gi, want_gi) < 1e-4 and _rel(gw, want_gw) < 1e-4
+    # same numbers as the native (neighbour-table) path, bit for bit: one summation order
+    km = F.build_kmap(_dev(coords), (1,) * 3, (ks,) * 3, (st_,) * 3)
+    o2 = torch.empty(n_out, cout, device='cuda')
+    km.pair_schedule().run(xd, F._transpose_weights(wd), cout, transposed, o2)
+    assert torch.equal(out, o2)
+    # errors: workspace too small, channel count not a multiple of 4
+    with pytest.raises(RuntimeError, match='workspace'):
+        L.call('u2mkd_convolution_forward', L.ptr(xd), n_in, cin, L.ptr(out), n_out, cout, L.ptr(wd), L.ptr(nb_dev),
+               ctypes.addressof(sizes_host), k, int(transposed), L.ptr(ws), 1024, L.stream())
+    with pytest.raises(RuntimeError, match='multiples of 4'):
+        L.call('u2mkd_convolution_forward', L.ptr(xd), n_in, 6, L.ptr(out), n_out, cout, L.ptr(wd), L.ptr(nb_dev),
+               ctypes.addressof(sizes_host), k, int(transposed), L.ptr(ws), nbytes, L.stream())
