@@ -157,17 +157,17 @@ int u2mkd_debug_wgrad_stamps(const float *a, const float *b, const int32_t *pair
  * (pair_idx = pair_in for a normal conv, pair_out for a transposed conv / the input gradient):
  * one dense MFMA stage per 64-pair tile, no serial walk over offsets.  meta (device) holds
  * the tile count; a fixed grid splits the tiles into contiguous runs, so nothing is read back
- * by the host.  variant: 0 = heuristic, 32 / 64 = channels per pipeline stage.
+ * by the host.  kc = reduction channels per pipeline stage: 32 or 64, 0 = chosen from the shape.
  * y must hold `capacity` rows (only the first meta[0] are written; padding entries give 0).  */
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                              const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
-                             int32_t k, int32_t variant, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
+                             int32_t k, int32_t kc, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
 /* y = x * w^T (+ bias): nn.Linear on the rows of a feature matrix (the point-branch MLPs of
  * core/models/semantickitti/spvcnn.py:58-74 and the 1x1x1 convs of ResidualBlock.downsample,
  * build_blocks.py:69-72), on the pair kernel's pipeline with the identity schedule.  w is
  * nn.Linear's [cout, cin]; y must hold ceil(n / 64) * 64 rows (rows >= n receive the bias). */
 int u2mkd_linear_forward(const float *x /*[n,cin]*/, int64_t n, int32_t cin, const float *w /*[cout,cin]*/, int32_t cout,
-                         const float *bias /*[cout] or NULL*/, int32_t variant, float *y, u2mkd_stream_t s);
+                         const float *bias /*[cout] or NULL*/, int32_t kc, float *y, u2mkd_stream_t s);
 /* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
  * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,
@@ -308,7 +308,7 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
  * vectors on the MFMA unit, one slab per wave in `workspace`, summed in a fixed order
  * (deterministic, no atomics; dtq/dtk/dtv are fully written, no pre-zeroing).  qc_span = host-known
  * bound on the quantised in-window coordinates of the affine axes (ceil(window / quant_size));
- * spans above 24 (never on the U2MKD configs) take the generic kernel with LDS atomics.       */
+ * spans above 24 (never on the U2MKD configs: window / quant size = 24) are an error.          */
 size_t u2mkd_sptr_backward_workspace_bytes(int64_t n, int32_t h, int32_t L);
 int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
                                   const float *lse, const int32_t *sort_idx, const int32_t *wstart,

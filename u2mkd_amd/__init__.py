@@ -18,3 +18,35 @@ def install_as_torchsparse():
     for sub in ('tensor', 'point_tensor', 'operators', 'nn', 'nn.functional', 'nn.utils', 'nn.modules',
                 'utils', 'utils.quantize', 'utils.collate'):
         sys.modules['torchsparse.' + sub] = importlib.import_module(base + '.' + sub)
+
+
+def install_as_sptr():
+    """Make ``from third_party.SparseTransformer.sptr import to_3d_numpy, SparseTrTensor,
+    sparse_self_attention, get_indices_params`` (core/models/sphereformer/spherical_transformer.py:7)
+    resolve to :mod:`u2mkd_amd.sptr` -- what a maintainer of the reference does instead of building
+    the ``sptr_cuda`` extension (third_party/SparseTransformer/setup.py) and installing torch_scatter /
+    torch_geometric / torch_cluster.  Parent packages that are not importable are registered as empty
+    namespace modules; an existing ``third_party`` package is left in place and only its
+    ``SparseTransformer.sptr`` entry is overridden."""
+    import importlib
+    import sys
+    import types
+    drop_in = importlib.import_module('u2mkd_amd.sptr')
+    parent = None
+    for name in ('third_party', 'third_party.SparseTransformer'):
+        mod = sys.modules.get(name)
+        if mod is None:
+            try:
+                mod = importlib.import_module(name)
+            except Exception:
+                mod = types.ModuleType(name)
+                mod.__path__ = []
+                sys.modules[name] = mod
+        if parent is not None:
+            setattr(parent, name.rsplit('.', 1)[1], mod)
+        parent = mod
+    sys.modules['third_party.SparseTransformer.sptr'] = drop_in
+    parent.sptr = drop_in
+    for sub in ('functional',):
+        sys.modules['third_party.SparseTransformer.sptr.' + sub] = importlib.import_module('u2mkd_amd.sptr.' + sub)
+    return drop_in

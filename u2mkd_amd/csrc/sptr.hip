@@ -107,7 +107,6 @@ __device__ __forceinline__ int exp_split(float d, float a) {
 struct RelCtx {
     int qgl;        // quant_grid_length
     float a;        // > 0: spherical branch (exponential radial split + clamp)
-    int dbg;        // timing experiments only (U2MKD_SPTR_DEBUG): 1 = skip the table-gradient atomics
 };
 
 __device__ __forceinline__ void rel_rows(const RelCtx &c, const int qi[3], float ri, const int qj[3], float rj,
@@ -234,119 +233,6 @@ __global__ void sptr_delta_kernel(const float *__restrict__ dout, const float *_
     delta[e] = s;
 }
 
-__device__ __forceinline__ void lds_add_rows(float *tab, const int r[3], float scale, const float vec[kHd]) {
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        float *row = tab + (r[ax] * 3 + ax) * kTabRow;
-#pragma unroll
-        for (int d = 0; d < kHd; ++d) atomicAdd(row + d, scale * vec[d]);
-    }
-}
-// ---- backward: every (sorted position, head) thread acts as query (dq, table grads) and as key (dk, dv)
-__global__ void __launch_bounds__(kSptrThreads)
-sptr_attn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-                     const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
-                     const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
-                     const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
-                     const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
-                     const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
-                     float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) float s_tab[];
-    const int hh = blockIdx.y;
-    const int tabf = L * 3 * kTabRow;
-    float *g_tab = s_tab + 3 * tabf;                 // gradient accumulators, same layout
-    load_tables(s_tab, tq, tk, tv, L, h, hh);
-    for (int e = threadIdx.x; e < 3 * tabf; e += blockDim.x) g_tab[e] = 0.f;
-    __syncthreads();
-    const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
-    float *Gq = g_tab, *Gk = g_tab + tabf, *Gv = g_tab + 2 * tabf;
-    // a fixed grid walks the token blocks; the table gradients of all its blocks stay in LDS
-    const int64_t nblk = (n + blockDim.x - 1) / blockDim.x;
-    const size_t hc = (size_t)h * kHd;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t p = blk * blockDim.x + threadIdx.x;
-    if (p < n) {
-        const int64_t t = sort_idx[p];
-        int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
-        float ri = radial ? radial[p] : 0.f;
-        const int ws = wstart[p], wl = wlen[p];
-        float qi[kHd], ki[kHd], vi[kHd], doi[kHd];
-        load16(q + t * hc + hh * kHd, qi);
-        load16(k + t * hc + hh * kHd, ki);
-        load16(v + t * hc + hh * kHd, vi);
-        load16(dout + t * hc + hh * kHd, doi);
-        const float lse_i = lse[p * h + hh], del_i = delta[p * h + hh];
-        float dqi[kHd], dki[kHd], dvi[kHd];
-#pragma unroll
-        for (int d = 0; d < kHd; ++d) { dqi[d] = 0.f; dki[d] = 0.f; dvi[d] = 0.f; }
-        for (int jj = 0; jj < wl; ++jj) {
-            const int pj = ws + jj;
-            const int64_t tj = sort_idx[pj];
-            int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
-            float rj = radial ? radial[pj] : 0.f;
-            float xj[kHd], ts[kHd], tks[kHd];
-            int r[3];
-            // ---- this thread as QUERY i = p against key j = pj
-            rel_rows(rc, qci, ri, qcj, rj, r);
-            load16(k + tj * hc + hh * kHd, xj);                  // k_j
-            tab_sum(Tq, r, ts);
-            tab_sum(Tk, r, tks);
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) s += qi[d] * (xj[d] + ts[d]) + xj[d] * tks[d];
-            float pr = __expf(s - lse_i);
-            float vj[kHd], tvs[kHd];
-            load16(v + tj * hc + hh * kHd, vj);
-            tab_sum(Tv, r, tvs);
-            float dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) dp += doi[d] * (vj[d] + tvs[d]);
-            float ds = pr * (dp - del_i);
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) dqi[d] += ds * (xj[d] + ts[d]);
-            if (!(rc.dbg & 1)) {
-                lds_add_rows(Gq, r, ds, qi);
-                lds_add_rows(Gk, r, ds, xj);
-                lds_add_rows(Gv, r, pr, doi);
-            }
-            // ---- this thread as KEY j = p against query i = pj
-            rel_rows(rc, qcj, rj, qci, ri, r);
-            float qj[kHd], doj[kHd];
-            load16(q + tj * hc + hh * kHd, qj);
-            load16(dout + tj * hc + hh * kHd, doj);
-            tab_sum(Tq, r, ts);
-            tab_sum(Tk, r, tks);
-            float s2 = 0.f;
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) s2 += qj[d] * (ki[d] + ts[d]) + ki[d] * tks[d];
-            float pr2 = __expf(s2 - lse[pj * h + hh]);
-            tab_sum(Tv, r, tvs);
-            float dp2 = 0.f;
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) dp2 += doj[d] * (vi[d] + tvs[d]);
-            float ds2 = pr2 * (dp2 - delta[pj * h + hh]);
-#pragma unroll
-            for (int d = 0; d < kHd; ++d) {
-                dki[d] += ds2 * (qj[d] + tks[d]);
-                dvi[d] += pr2 * doj[d];
-            }
-        }
-        float *o1 = dq + t * hc + hh * kHd, *o2 = dk + t * hc + hh * kHd, *o3 = dv + t * hc + hh * kHd;
-#pragma unroll
-        for (int d = 0; d < kHd; ++d) { o1[d] = dqi[d]; o2[d] = dki[d]; o3[d] = dvi[d]; }
-    }
-    }
-    __syncthreads();
-    // this workgroup's table gradients -> its slab [3][L*3][16] (plain stores; summed in a fixed
-    // order by sptr_table_reduce_kernel: float atomics from every workgroup to the same few
-    // thousand addresses ran at ~1.5 G atomics/s and were 90 % of the backward time)
-    const int rows = L * 3;
-    float *slab = slabs + ((size_t)blockIdx.x * h + hh) * 3 * rows * kHd;
-    for (int e = threadIdx.x; e < 3 * rows * kHd; e += blockDim.x) {
-        int row = e / kHd, d = e - row * kHd;     // row over [3 tables][rows]
-        slab[e] = g_tab[row * kTabRow + d];
-    }
-}
 
 
 // ---- backward, histogram form (the default) ----------------------------------------------------
@@ -522,7 +408,7 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
         for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-        if (!(rc.dbg & 64)) hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
         __builtin_amdgcn_wave_barrier();
     }
     const int table_of[NT] = {0, 2};
@@ -623,7 +509,7 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
         for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        if (!(rc.dbg & 64)) hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
         __builtin_amdgcn_wave_barrier();
     }
     const int table_of[NT] = {1};
@@ -702,7 +588,7 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
                "u2mkd_sptr_attention_forward: null pointer");
     if (int rc = sptr_check("u2mkd_sptr_attention_forward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(split_a <= 0.f || radial, "u2mkd_sptr_attention_forward: spherical branch needs the radial coordinate");
-    RelCtx rc{qgl, split_a, 0};
+    RelCtx rc{qgl, split_a};
     size_t lds = (size_t)3 * L * 3 * kTabRow * sizeof(float);
     hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
                        as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk, tv,
@@ -733,8 +619,7 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
     if (int rc = sptr_check("u2mkd_sptr_attention_backward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(workspace_bytes >= u2mkd_sptr_backward_workspace_bytes(n, h, L),
                "u2mkd_sptr_attention_backward: workspace too small");
-    const char *dbg_env = getenv("U2MKD_SPTR_DEBUG");
-    RelCtx rc{qgl, split_a, dbg_env ? atoi(dbg_env) : 0};
+    RelCtx rc{qgl, split_a};
     hipStream_t st = as_stream(s);
     hipLaunchKernelGGL(sptr_delta_kernel, dim3((unsigned)ceil_div(n * h, 256)), dim3(256), 0, st, dout, out, sort_idx,
                        n, h, delta);
@@ -743,35 +628,24 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
     const float *rad = split_a > 0.f ? radial : nullptr;
     const int per = 3 * L * 3 * kHd;
     // histogram form: every token reaches at most kNB rows per affine axis (quantised coordinates in
-    // [0, qc_span), qc_span <= kNB) and 2*kNB rows on the radial axis; otherwise the generic kernel
-    const bool hist_ok = qc_span > 0 && qc_span <= kNB && qgl < kNB && L <= 48 && !(rc.dbg & 8);
-    if (hist_ok) {
-        const int tabf = L * 3 * kTabRow;
-        size_t lds_q = ((size_t)3 * tabf + (size_t)kSptrThreads * (2 * kHistTab + 1) + 2 * kSptrThreads * kVecRow +
-                        kSptrThreads * 3) * sizeof(float);
-        size_t lds_k = ((size_t)3 * tabf + (size_t)kSptrThreads * (kHistTab + 1) + kSptrThreads * kVecRow +
-                        kSptrThreads * 3) * sizeof(float);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_query_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-        if (!(rc.dbg & 32))   // (bits 16 / 32: timing experiments, skip one of the two kernels)
-            hipLaunchKernelGGL(sptr_bwd_query_kernel, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse,
-                               delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs);
-        if (!(rc.dbg & 16))
-            hipLaunchKernelGGL(sptr_bwd_key_kernel, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse,
-                               delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs);
-        hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs,
-                           2 * G, L, h, dtq, dtk, dtv);
-        return check_launch("u2mkd_sptr_attention_backward");
-    }
-    size_t lds = (size_t)6 * L * 3 * kTabRow * sizeof(float);
-    if (lds > 65536)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_attn_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(sptr_attn_bwd_kernel, dim3(G, h), dim3(kSptrThreads), lds, st, q, k, v, dout, lse, delta,
-                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, dk, dv, slabs);
-    hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, G, L, h,
+    // [0, qc_span), qc_span <= kNB) and 2*kNB rows on the radial axis
+    U2_REQUIRE(qc_span > 0 && qc_span <= kNB && qgl < kNB && L <= 48,
+               "u2mkd_sptr_attention_backward: qc_span=%d (window / quant size) must be in 1..%d, qgl=%d below %d, L=%d <= 48 "
+               "(every U2MKD configuration has span = qgl = 24)", qc_span, kNB, qgl, kNB, L);
+    const int tabf = L * 3 * kTabRow;
+    size_t lds_q = ((size_t)3 * tabf + (size_t)kSptrThreads * (2 * kHistTab + 1) + 2 * kSptrThreads * kVecRow +
+                    kSptrThreads * 3) * sizeof(float);
+    size_t lds_k = ((size_t)3 * tabf + (size_t)kSptrThreads * (kHistTab + 1) + kSptrThreads * kVecRow +
+                    kSptrThreads * 3) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_query_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+    hipLaunchKernelGGL(sptr_bwd_query_kernel, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse, delta,
+                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs);
+    hipLaunchKernelGGL(sptr_bwd_key_kernel, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse, delta,
+                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs);
+    hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, 2 * G, L, h,
                        dtq, dtk, dtv);
     return check_launch("u2mkd_sptr_attention_backward");
 }
