@@ -232,7 +232,8 @@ int u2mkd_devoxelize_backward(const float *grad_out /*[n,c]*/, const int32_t *id
                               u2mkd_stream_t s);
 /* Deterministic form of the two scatters (voxelize forward, devoxelize backward): entries
  * sorted by destination row (CSR: seg_offsets [nv+1]); out[v] = sum_e w[e] * src[row[e]]
- * (entry_w NULL = 1; mean != 0 divides by the segment length).  No atomics.             */
+ * (entry_w NULL = 1); mean != 0: out[v] = sum_e src[row[e]] / len(v), each term divided before it is
+ * added, in entry order -- torchsparse's voxelize arithmetic, bit for bit.  No atomics.            */
 int u2mkd_segment_sum(const float *src /*[*,c]*/, int32_t c, const int32_t *entry_row /*[E]*/,
                       const float *entry_w /*[E] or NULL*/, const int32_t *seg_offsets /*[nv+1]*/, int64_t nv,
                       int32_t mean, float *out /*[nv,c]*/, u2mkd_stream_t s);

@@ -146,14 +146,16 @@ def kd_inputs(b):
     return stu, tea
 
 
-def make_kd_golden(crit):
+def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True):
     """The reference's own SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL (student + teacher) and the KD loss
-    arithmetic of NuScenesLCTSDFullTrainer._run_step, on CPU over the oracle operators."""
+    arithmetic of NuScenesLCTSDFullTrainer._run_step, on CPU over the oracle operators.  (cr, cr_t) =
+    (1.0, 1.0): the first fixture; (1.0, 2.0) = configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:32-43
+    (the shipped student / teacher); (2.0, 2.0) = spformer_tsd_full_ours_star_B.yaml:34-36."""
     import torch.nn.functional as F
     from u2mkd_amd.synth import synth_kd_batch
     from oracle.spformer_ref import default_spformer_kwargs
     cfg = sys.modules['torchpack.utils.config'].configs
-    cfg['model'].update({'cr': 1.0, 'cr_t': 1.0, 'in_channel': 4, 'in_channel_t': 4, 'imagenet_pretrain': None})
+    cfg['model'].update({'cr': cr, 'cr_t': cr_t, 'in_channel': 4, 'in_channel_t': 4, 'imagenet_pretrain': None})
     cfg['eval'] = {'run_pix_decoder': True, 'run_align_loss': True}
     cfg['debug'] = {'debug_val': False}
     torch.Tensor.cuda = lambda self, *a, **k: self          # Feature_Fetch hard-codes .cuda() (fusion_blocks.py:271-273)
@@ -164,7 +166,7 @@ def make_kd_golden(crit):
     model = O.fill_state_by_name(SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL(**kw)).train()
     model.model_t.eval()
     model.model_s.dropout.p = 0.0
-    b = synth_kd_batch(1500, 2, seed=77, image_hw=(64, 112))
+    b = synth_kd_batch(n_vox, 2, seed=77, image_hw=(64, 112))
     stu, tea = kd_inputs(b)
     out = model({'student': stu, 'teacher': tea})
     s, t = b['student'], b['teacher']
@@ -190,7 +192,7 @@ def make_kd_golden(crit):
     total.backward()
     g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     np.savez_compressed(
-        os.path.join(HERE, 'kd_cr10_3000.npz'),
+        os.path.join(HERE, tag + '.npz'),
         x_vox=x_vox.detach().numpy(), x_pix=x_pix.detach().numpy(), x_vox_t=out['t']['x_vox'].numpy(),
         mse=np.array([float(m) for m in out['stu']['mse_loss']], dtype=np.float32),
         pts_feats_s=out['stu']['pts_feats'][0].detach().numpy()[::16],
@@ -200,10 +202,24 @@ def make_kd_golden(crit):
         grad_c2l=g['model_s.c2l_fusion_blocks.2.conv1.weight'].numpy(),
         grad_layer2=g['model_s.pix_branch.layer2.0.conv1.weight'].numpy()[:8],
         grad_stem=g['model_s.stem.3.kernel'].numpy())
-    with open(os.path.join(HERE, 'kd_cr10_keys.json'), 'w') as f:
-        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0)
-    print('kd golden losses', [float(x) for x in (ce_vox, ce_pix, kl, feat, total)])
+    if write_keys:
+        with open(os.path.join(HERE, 'kd_cr10_keys.json'), 'w') as f:
+            json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0)
+    print(tag, 'kd golden losses', [float(x) for x in (ce_vox, ce_pix, kl, feat, total)])
+
+
+def main_kd_widths():
+    """Only the KD fixtures at the shipped widths (`python tests/golden/make_golden.py kd`)."""
+    _, MixLovaszCrossEntropy = import_reference()
+    import_reference_spformer(1.0)
+    crit = MixLovaszCrossEntropy(ignore_index=0)
+    make_kd_golden(crit, cr=1.0, cr_t=2.0, tag='kd_cr10_t20_2000', n_vox=1000, write_keys=False)
+    make_kd_golden(crit, cr=2.0, cr_t=2.0, tag='kd_cr20_t20_2000', n_vox=1000, write_keys=False)
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'kd':
+        main_kd_widths()
+    else:
+        main()
+        main_kd_widths()

@@ -31,10 +31,16 @@ def _rel(a, b):
     (False, [1.2, 1.2, 1.2], [0.05, 0.05, 0.05], 1),
     (True, [16.0, 16.0, 120.0], [16 / 24, 16 / 24, 5.0], 3),
     (True, [4.0, 4.0, 120.0], [16 / 12, 16 / 12, 5.0], 2),     # aliased quant size
+    # heads per branch of the shipped configurations (spvcnn_spformer.py:70-83: C = cs[1..4], h = C / 16 split
+    # half / half): cr 1.0 -> up to 8 per branch, cr 2.0 (the teacher, the `_B` student) -> 16 per branch at C = 512
+    (False, [2.4, 2.4, 2.4], [0.1, 0.1, 0.1], 8),
+    (False, [2.4, 2.4, 2.4], [0.1, 0.1, 0.1], 16),
+    (True, [16.0, 16.0, 120.0], [16 / 12, 16 / 12, 5.0], 8),
+    (True, [16.0, 16.0, 120.0], [16 / 12, 16 / 12, 5.0], 16),
 ])
 def test_window_attention_fwd_bwd(hip, sphere, window, quant, h):
     from u2mkd_amd import sptr
-    n, d, qgl = 3000, 16, 24
+    n, d, qgl = (3000 if h <= 3 else 1500), 16, 24
     L = 2 * qgl if sphere else 2 * qgl - 1
     a = 0.0125 if sphere else None
     xyz, b = _tokens(n, 5, sphere=sphere)
@@ -93,3 +99,43 @@ def test_reference_api_signature(hip):
     assert _rel(out, ref) < 1e-5
     t = sptr.SparseTrTensor(q, torch.cat([b[:, None].float(), xyz], 1), None, None)
     assert t.find_indice_params('x') is None
+
+
+@pytest.mark.parametrize('window,quant', [([0.3, 0.3, 0.3], [0.0125, 0.0125, 0.0125]),
+                                          ([2.4, 2.4, 2.4], [0.1, 0.1, 0.1]),
+                                          ([2.0, 2.0, 120.0], [16 / 12, 16 / 12, 5.0])])
+def test_quantiser_decisions_equal_on_equal_inputs(hip, window, quant):
+    """The hard quantisers of the attention (window id = floor((p - min) / window), in-window coordinate =
+    floor(((p - min) mod window) / quant)) are INTEGER decisions on fp32 inputs: fed identical fp32 coordinates, the
+    HIP kernels must take exactly the decisions of the CPU restatement -- also for tokens ON a bin edge and one
+    ulp either side of it (the adversarial half of this cloud).  What moves a token across an edge between the
+    two paths is therefore never the quantiser, only a last-place difference in its INPUT (the atan2-derived
+    angles of the spherical branch): the bounded allowance of tests/test_kd_path.py's first fixture."""
+    from u2mkd_amd import sptr
+    n = 4096
+    g = torch.Generator().manual_seed(3)
+    w = torch.tensor(window)
+    qz = torch.tensor(quant)
+    xyz = torch.rand(n, 3, generator=g) * w * 7.3
+    lo = xyz.min(0)[0]
+    # second half: tokens on window / quantisation edges and 1 ulp around them
+    k = torch.randint(1, 7, (n // 2, 3), generator=g).float()
+    j = torch.randint(0, 20, (n // 2, 3), generator=g).float()
+    edge = lo + torch.where(torch.rand(n // 2, 3, generator=g) < 0.5, k * w, k * w + j * qz)
+    ulp = torch.randint(-1, 2, (n // 2, 3), generator=g)
+    edge = torch.where(ulp > 0, torch.nextafter(edge, edge + 1), torch.where(ulp < 0, torch.nextafter(edge, edge - 1), edge))
+    xyz[n // 2:] = edge
+    xyz[0] = lo                                                     # keep the minimum where it was
+    b = torch.sort(torch.randint(0, 2, (n,), generator=g))[0]
+    plan = sptr.WindowPlan(xyz.cuda(), b.cuda(), np.array(window))
+    # window partition
+    c_ref = S.grid_cluster(xyz, b, np.array(window))
+    order = plan.sort_idx.cpu().long()
+    ws = plan.wstart.cpu().long()
+    assert torch.equal(c_ref[order], c_ref[order][ws])
+    assert int((ws == torch.arange(n)).sum()) == len(torch.unique(c_ref))
+    # in-window quantised coordinates (sptr/modules.py:40-41), sorted order
+    qc, _, span = plan.quant_coords(xyz.cuda(), np.array(quant), False)
+    want = torch.div((xyz - xyz.min(0)[0] + 0.0) % w, qz, rounding_mode='floor').int()
+    assert torch.equal(qc.cpu(), want[order])
+    assert int(want.max()) < span

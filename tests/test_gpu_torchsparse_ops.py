@@ -188,7 +188,9 @@ def test_strided_and_transposed_conv(F, cin, cout):
     assert _rel(xd.grad, wgi) < 1e-4 and _rel(wd.grad, wgw) < 1e-4
 
 
-@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (96, 128), (20, 12)])
+# the last four: layer shapes of the cr = 2.0 models (teacher / `_B` student): cs = [64,64,128,256,512,512,256,192,192],
+# e.g. 512 -> 512 residual convs, 768 -> 512 and 384 -> 256 after the skip concatenations, 256 -> 512 at stride 16
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (96, 128), (20, 12), (512, 512), (768, 512), (256, 512), (384, 256)])
 @pytest.mark.parametrize('kind', ['subm', 'down', 'up'])
 def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
     """The tile schedule and the pair schedule (+ gather-sum) compute the same contraction; both are

@@ -117,10 +117,10 @@ def test_teacher_to_student_equals_reference_loop():
                        FR.t2s_loop(x_t, inv, inds2, t['num_pts'], t['num_vox'], kfm))
 
 
-def _build(dev):
+def _build(dev, cr=1.0, cr_t=1.0):
     from u2mkd_amd import kd, lidar
     sp = {k: v for k, v in lidar.spformer_kwargs(drop_path_rate=0.0).items() if k not in ('cr', 'in_channel', 'num_classes')}
-    return kd.TSDFull(cr=1.0, cr_t=1.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp)
+    return kd.TSDFull(cr=cr, cr_t=cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp)
 
 
 def test_kd_state_dict_keys_match_reference():
@@ -131,15 +131,22 @@ def test_kd_state_dict_keys_match_reference():
     assert {k: list(v.shape) for k, v in sd.items()} == keys
 
 
+# (student cr, teacher cr_t, fixture, voxels per sample): the first fixture, the shipped student / teacher widths
+# (configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:32-43: 512-channel teacher convs, 16 heads per attention
+# branch) and the `_B` student (spformer_tsd_full_ours_star_B.yaml:34-36)
+KD_GOLDENS = [(1.0, 1.0, 'kd_cr10_3000', 1500), (1.0, 2.0, 'kd_cr10_t20_2000', 1000), (2.0, 2.0, 'kd_cr20_t20_2000', 1000)]
+
+
 @pytest.mark.gpu
-def test_hip_kd_step_matches_reference_golden(hip):
+@pytest.mark.parametrize('cr,cr_t,fixture,n_vox', KD_GOLDENS)
+def test_hip_kd_step_matches_reference_golden(hip, cr, cr_t, fixture, n_vox):
     from oracle.spvcnn_ref import fill_state_by_name
     from u2mkd_amd import kd, torchsparse as ts
-    gold = np.load(os.path.join(G, 'kd_cr10_3000.npz'))
-    model = fill_state_by_name(_build('cuda')).cuda().train()
+    gold = np.load(os.path.join(G, fixture + '.npz'))
+    model = fill_state_by_name(_build('cuda', cr, cr_t)).cuda().train()
     model.model_t.eval()
     model.model_s.dropout.p = 0.0
-    b = synth_kd_batch(1500, 2, seed=77, image_hw=(64, 112))
+    b = synth_kd_batch(n_vox, 2, seed=77, image_hw=(64, 112))
     s, t = b['student'], b['teacher']
     pc, ms = _kd_tensors(b, 'cuda')
     stu = {'lidar': ts.SparseTensor(torch.from_numpy(s['feats']).cuda(), torch.from_numpy(s['coords']).cuda()),
@@ -161,18 +168,25 @@ def test_hip_kd_step_matches_reference_golden(hip):
         return float((e.max(1)[0] > 1e-3).float().mean()), float(e.median()), float(e.max())
     assert err(out['t']['x_vox'], 'x_vox_t') < 1e-3
     assert err(out['stu']['x_pix'], 'x_pix') < 1e-3
-    # The student contains hard quantisers on fp32 inputs that differ in the last bit between
-    # devices (pixel = floor(u) of the L2C scatter, window / relative-position bins of SphereFormer):
-    # a point within rounding of a bin edge lands in the other bin and its logits move by ~1e-2.
-    # tools/dbg_kd.py: median |err| 3e-6, 7 of 2985 rows above 1e-3.  Gate: 1e-3 on >= 99% of the
-    # points, tight median, bounded max.
+    # North-star gate: every row within 1e-3 -- held WITHOUT exception on the fixtures at the shipped widths.
+    # The first fixture (seed 77, 1500 voxels) contains tokens within fp32 rounding of an edge of SphereFormer's
+    # hard quantisers (spherical window / relative-position bin of atan2-derived angles: the CPU and GPU libm
+    # differ in the last place): such a token lands in the neighbouring bin and the rows around it move by ~1e-2
+    # (0.2 % of the rows; median error 3e-6).  That fixture keeps a bounded allowance and documents the effect;
+    # tests/test_gpu_sptr.py::test_quantiser_decisions_equal_on_equal_inputs shows the quantisers themselves
+    # are bit-exact on identical inputs.
+    strict = fixture != 'kd_cr10_3000'
     for a, key in ((out['stu']['x_vox'], 'x_vox'), (out['stu']['pts_feats'][0][::16], 'pts_feats_s')):
         frac, med, mx = rows_off(a, key)
-        assert frac <= 0.01 and med < 1e-5 and mx < 0.1, (key, frac, med, mx)
+        print('KD-PARITY', fixture, key, 'rows above 1e-3: %.5f' % frac, 'median %.2e' % med, 'max %.2e' % mx)
+        if strict:
+            assert mx < 1e-3, (key, frac, med, mx)
+        else:
+            assert frac <= 0.01 and med < 1e-5 and mx < 0.1, (key, frac, med, mx)
     mse = torch.stack([m.detach() for m in out['stu']['mse_loss']]).cpu().numpy()
     assert np.abs(mse - gold['mse']).max() < 1e-3
     got = np.array([float(ld[k].detach()) for k in ('ce_vox', 'ce_pix', 'kl', 'feat', 'total')])
-    assert np.abs(got - gold['losses']).max() < 2e-3, (got, gold['losses'])
+    assert np.abs(got - gold['losses']).max() < (1e-3 if strict else 2e-3), (got, gold['losses'])
     g = dict(model.named_parameters())
     for name, key, sl in (('model_s.l2c_fusion_blocks.1.conv1.weight', 'grad_l2c', slice(None)),
                           ('model_s.c2l_fusion_blocks.2.conv1.weight', 'grad_c2l', slice(None)),

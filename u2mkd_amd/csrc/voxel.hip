@@ -151,6 +151,11 @@ __global__ void segment_sum_kernel(const float *__restrict__ src, int c4, const 
     const int e0 = seg[v], e1 = seg[v + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = e0;
+    // mean: every term is divided by the segment length BEFORE it is added, in entry order -- the arithmetic
+    // of torchsparse's voxelize (out[idx[i]] += feats[i] / counts[idx[i]]), so voxel means
+    // (and with them the metric coordinates SphereFormer quantises into windows and relative-position bins)
+    // are bit-identical to the CPU path instead of differing in the last place
+    const float cnt = (float)(e1 - e0);
     // four entries in flight (segments reach ~100 entries at stride 16: a one-at-a-time walk is a
     // chain of dependent L2 round trips); the accumulation order stays e0, e0+1, ...
     for (; e + 4 <= e1; e += 4) {
@@ -161,19 +166,26 @@ __global__ void segment_sum_kernel(const float *__restrict__ src, int c4, const 
         for (int u = 0; u < 4; ++u) { r[u] = erow[e + u]; w[u] = ew ? ew[e + u] : 1.f; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) f[u] = reinterpret_cast<const float4 *>(src)[(int64_t)r[u] * c4 + j];
+        if (mean) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc.x += w[u] * f[u].x; acc.y += w[u] * f[u].y; acc.z += w[u] * f[u].z; acc.w += w[u] * f[u].w;
+            for (int u = 0; u < 4; ++u) {
+                acc.x += f[u].x / cnt; acc.y += f[u].y / cnt; acc.z += f[u].z / cnt; acc.w += f[u].w / cnt;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x += w[u] * f[u].x; acc.y += w[u] * f[u].y; acc.z += w[u] * f[u].z; acc.w += w[u] * f[u].w;
+            }
         }
     }
     for (; e < e1; ++e) {
         float w = ew ? ew[e] : 1.f;
         float4 f = reinterpret_cast<const float4 *>(src)[(int64_t)erow[e] * c4 + j];
-        acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
-    }
-    if (mean && e1 > e0) {
-        float inv = (float)(e1 - e0);
-        acc.x /= inv; acc.y /= inv; acc.z /= inv; acc.w /= inv;
+        if (mean) {
+            acc.x += f.x / cnt; acc.y += f.y / cnt; acc.z += f.z / cnt; acc.w += f.w / cnt;
+        } else {
+            acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w;
+        }
     }
     reinterpret_cast<float4 *>(out)[t] = acc;
 }
