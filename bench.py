@@ -354,6 +354,18 @@ def timed_run(step, warmup, steps, world):
 
 def run_rank(args):
     import torch
+    if os.environ.get('U2MKD_BENCH_DRYRUN') == '1':
+        # launcher / rendezvous check without a GPU (tests/test_ddp_gloo.py): ranks meet over gloo, agree on the
+        # world size, reduce a value; no step is timed and no metric is printed
+        from u2mkd_amd import distributed as D
+        rank, world, _ = D.init_from_env('gloo')
+        assert world == args.gpus, (world, args.gpus)
+        D.barrier()
+        top = D.max_over_ranks(float(rank))
+        if rank == 0:
+            print(json.dumps({'dryrun': True, 'n_gpus': world, 'max_rank': top}), flush=True)
+        D.shutdown()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     from u2mkd_amd import distributed as D

@@ -63,3 +63,23 @@ def test_two_rank_gradients_are_the_mean(tmp_path):
         assert torch.equal(g0[name], g1[name]), name          # all-reduced: identical on both ranks
         want = (s0[name] + s1[name]) / 2
         assert torch.allclose(g0[name], want, rtol=1e-4, atol=1e-6), name
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun environment) starts two fresh rank processes that
+    rendezvous on 127.0.0.1 and relays rank 0's JSON line; here without a GPU (U2MKD_BENCH_DRYRUN: gloo, no step)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['U2MKD_BENCH_DRYRUN'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {'dryrun': True, 'n_gpus': 2, 'max_rank': 1.0}
+    # under a torchrun-style environment the process is ONE rank and must not spawn
+    env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], capture_output=True, text=True,
+                       timeout=280, env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])['n_gpus'] == 1, r.stderr[-2000:]

@@ -129,3 +129,69 @@ def _check_hip_sync_bn_pieces(lidar):
         assert float((ref.running_mean - syn.running_mean).abs().max()) < 1e-6
         assert float((ref.running_var - syn.running_var).abs().max()) < 1e-5
         assert int(syn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('n0,n1,c,relu', [(3000, 1700, 32, True), (777, 5, 96, False), (64, 4000, 256, True)])
+def test_sync_bn_pieces_emulate_two_ranks_on_one_gpu(hip, n0, n1, c, relu):
+    """SyncBatchNorm at world_size 2, emulated on ONE GPU: a batch is cut into two UNEQUAL per-rank parts, every
+    part goes through the per-rank pieces (u2mkd_bn_local_stats -> [all_gather = stacking the two [2C+1] rows] ->
+    u2mkd_bn_merge_stats(world = 2) -> u2mkd_bn_apply;  u2mkd_bn_backward_local -> [all_reduce = the sum of the two
+    [2C] rows] -> u2mkd_bn_backward_apply) and the result must equal torch's BatchNorm1d over the whole batch in
+    fp64: y, dx, the per-rank dgamma / dbeta (DDP averages them afterwards: their SUM is the full-batch gradient),
+    the running statistics with the GLOBAL count (torch.nn.SyncBatchNorm semantics, core/models/utils.py:138-220)."""
+    from u2mkd_amd import _lib as L
+    torch.manual_seed(n0 + c)
+    eps, mom = 1e-5, 0.1
+    x = torch.randn(n0 + n1, c, device='cuda') * 1.7 + 0.6
+    dy = torch.randn(n0 + n1, c, device='cuda')
+    gamma = torch.rand(c, device='cuda') + 0.5
+    beta = torch.rand(c, device='cuda') - 0.5
+    # reference: fp64 BatchNorm1d over the concatenated batch
+    ref = torch.nn.BatchNorm1d(c, eps=eps, momentum=mom).double().cuda().train()
+    with torch.no_grad():
+        ref.weight.copy_(gamma.double()); ref.bias.copy_(beta.double())
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+    # the two "ranks"
+    parts = [(x[:n0].contiguous(), dy[:n0].contiguous()), (x[n0:].contiguous(), dy[n0:].contiguous())]
+    lib, st = L.load(), L.stream()
+    stats = torch.empty(2, 2 * c + 1, device='cuda')
+    for r, (xp, _) in enumerate(parts):
+        n = xp.shape[0]
+        partial = torch.empty(max(lib.u2mkd_bn_num_slabs(n), 1) * 2 * c, device='cuda')
+        L.call('u2mkd_bn_local_stats', L.ptr(xp), n, c, L.ptr(partial), L.ptr(stats[r]), st)
+    assert stats[:, 2 * c].tolist() == [float(n0), float(n1)]
+    run_mean, run_var = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    mean, invstd, total = torch.empty(c, device='cuda'), torch.empty(c, device='cuda'), torch.empty(1, device='cuda')
+    L.call('u2mkd_bn_merge_stats', L.ptr(stats), 2, c, eps, mom, L.ptr(run_mean), L.ptr(run_var), L.ptr(mean), L.ptr(invstd),
+           L.ptr(total), st)
+    assert float(total) == n0 + n1
+    assert float((run_mean.double() - ref.running_mean).abs().max()) < 1e-6
+    assert float((run_var.double() - ref.running_var).abs().max()) < 1e-5
+    ys, sums = [], torch.empty(2, 2 * c, device='cuda')
+    for r, (xp, dyp) in enumerate(parts):
+        n = xp.shape[0]
+        y = torch.empty_like(xp)
+        L.call('u2mkd_bn_apply', L.ptr(xp), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu), L.ptr(y), st)
+        ys.append(y)
+        partial = torch.empty(max(lib.u2mkd_bn_num_slabs(n), 1) * 2 * c, device='cuda')
+        L.call('u2mkd_bn_backward_local', L.ptr(dyp), L.ptr(xp), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
+               int(relu), L.ptr(partial), L.ptr(sums[r]), st)
+    assert float((torch.cat(ys).double() - yr).abs().max()) < 1e-5
+    reduced = sums.sum(0).contiguous()                      # the all_reduce
+    dxs = []
+    for xp, dyp in parts:
+        n = xp.shape[0]
+        dx = torch.empty_like(xp)
+        L.call('u2mkd_bn_backward_apply', L.ptr(dyp), L.ptr(xp), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+               L.ptr(beta), int(relu), L.ptr(reduced), L.ptr(dx), st)
+        dxs.append(dx)
+    scale = max(1.0, float(xr.grad.abs().max()))
+    assert float((torch.cat(dxs).double() - xr.grad).abs().max()) < 1e-4 * scale
+    # sums rows = [dbeta, dgamma] per rank; the full-batch parameter gradients are their sums
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    assert float((reduced[:c].double() - ref.bias.grad).abs().max()) < 1e-4 * gs
+    assert float((reduced[c:].double() - ref.weight.grad).abs().max()) < 1e-4 * gs

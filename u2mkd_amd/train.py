@@ -10,7 +10,8 @@ from . import kd as KD
 from . import torchsparse as ts
 from .losses import MixLovaszCrossEntropy
 
-__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device']
+__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device', 'state_dict',
+           'load_state_dict', 'load_weights']
 
 
 def cosine_schedule_with_warmup(k, num_epochs, batch_size, dataset_size, world):
@@ -131,3 +132,55 @@ class KDStep:
         self.amp.backward_and_step(ld['total'], self.opt)
         self.sched.step()
         return ld['total'].detach()
+
+
+# ------------------------------------------------------------------------------------- checkpoints
+def _strip(sd):
+    """DDP prefixes its keys with `module.`; the reference strips them on load (core/nusc_trainers.py:180,198)."""
+    return {k.replace('module.', ''): v for k, v in sd.items()}
+
+
+def state_dict(runner):
+    """The trainer checkpoint of the reference, same four entries with the same meaning
+    (``_state_dict``, core/nusc_trainers.py:423-429): model (keys as the reference's modules produce them: conv
+    weights are ``...kernel`` [K, Cin, Cout]), scaler, optimizer, scheduler.  ``runner`` = LidarStep / KDStep."""
+    return {'model': runner.net.state_dict(), 'scaler': runner.amp.scaler.state_dict(),
+            'optimizer': runner.opt.state_dict(), 'scheduler': runner.sched.state_dict()}
+
+
+def load_state_dict(runner, ckpt):
+    """``_load_state_dict`` (core/nusc_trainers.py:431-435): resume model, loss scaler, optimizer and LR schedule."""
+    own_ddp = any(k.startswith('module.') for k in runner.net.state_dict())
+    model_sd = ckpt['model']
+    if not own_ddp:
+        model_sd = _strip(model_sd)
+    runner.net.load_state_dict(model_sd)
+    if 'scaler' in ckpt and ckpt['scaler']:
+        runner.amp.scaler.load_state_dict(ckpt['scaler'])
+    runner.opt.load_state_dict(ckpt['optimizer'])
+    runner.sched.load_state_dict(ckpt['scheduler'])
+
+
+def load_weights(model, weight_path=None, pretrain_weight=None, teacher_pretrain_weight=None, map_location='cpu'):
+    """The three weight sources of ``_before_train`` (core/nusc_trainers.py:173-201), in the reference's order of
+    precedence; ``model`` is the bare module (kd.TSDFull for the KD trainer).  Returns which one was used.
+
+    * ``weight_path``: a trainer checkpoint -> its ``model`` entry, `module.` stripped, strict;
+    * ``pretrain_weight``: ``model`` entry without the classifier heads, non-strict (fine-tuning);
+    * ``teacher_pretrain_weight``: the stage-1 teacher (train_spformer.py) into ``model.model_t``, strict --
+      the authors' teacher checkpoints load because module names and the ``kernel`` [K, Cin, Cout] layout are the
+      reference's (tests/golden/*_keys.json)."""
+    import os
+    if weight_path is not None and os.path.exists(weight_path):
+        sd = torch.load(weight_path, map_location=map_location, weights_only=False)
+        model.load_state_dict(_strip(sd['model']))
+        return 'weight_path'
+    if pretrain_weight is not None and os.path.exists(pretrain_weight):
+        sd = torch.load(pretrain_weight, map_location=map_location, weights_only=False)['model']
+        model.load_state_dict({k: v for k, v in sd.items() if 'classifier' not in k}, strict=False)
+        return 'pretrain_weight'
+    if teacher_pretrain_weight is not None and os.path.exists(teacher_pretrain_weight):
+        sd = torch.load(teacher_pretrain_weight, map_location=map_location, weights_only=False)['model']
+        model.model_t.load_state_dict(_strip(sd), strict=True)
+        return 'teacher_pretrain_weight'
+    return None
