@@ -133,7 +133,7 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
         x = torch.randn(n, cin, device='cuda', generator=g)
         w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
         gy = torch.randn(n, cout, device='cuda', generator=g)
-        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty_like(w), 'out': torch.empty(n, cout, device='cuda'),
+        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty(lib.u2mkd_weight_fragments_bytes(27, cin, cout, 0), dtype=torch.uint8, device='cuda'), 'out': torch.empty(n, cout, device='cuda'),
              'dx': torch.empty(n, cin, device='cuda'), 'dw': torch.empty_like(w),
              'ws': torch.empty(nbytes, dtype=torch.uint8, device='cuda'),
              # private copies of the map structures, so a cold launch also misses on the indices
@@ -141,9 +141,9 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
 
         # a pass = the weight re-layout into MFMA fragment order (442 KB, its own small launch) + the conv kernel
         def conv(s, a, transpose, flip, o):
-            L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, transpose, L.ptr(s['wf']), st)
+            L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, transpose, 0, L.ptr(s['wf']), st)
             L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf']), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
-                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, L.ptr(o), st)
+                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, 0, L.ptr(o), st)
         s['fwd'] = lambda s=s: conv(s, s['x'], 1, 0, s['out'])
         s['dgrad'] = lambda s=s: conv(s, s['gy'], 0, 1, s['dx'])
         s['wgrad'] = lambda s=s: L.call('u2mkd_conv_wgrad_pairs', L.ptr(s['x']), cin, L.ptr(s['gy']), cout, L.ptr(s['pairs']),

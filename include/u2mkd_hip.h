@@ -124,19 +124,26 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
  * u2mkd_weight_fragments(w [k,rows,cols], transpose):
  *   forward:        w = kernel [k,cin,cout], transpose = 1   (B_k[col][ci] = kernel[k][ci][col])
  *   input gradient: w = kernel [k,cin,cout], transpose = 0   (B_k[ci][co]  = kernel[k][ci][co])
- * wf has k*rows*cols floats; rows and cols must be multiples of 16.
+ * wf has u2mkd_weight_fragments_bytes(k, rows, cols, arith) bytes; rows and cols must be multiples of 32.
+ * arith selects the arithmetic of the MFMA tiles (the same value for the fragments and the convolution):
+ *   1 = f32 MFMA (v_mfma_f32_16x16x4_f32: the exact fp32 fma chain);
+ *   2 = bf16x3: every fp32 operand is split exactly into three bf16 (8 + 8 + 8 significand bits), the six partial
+ *       products above 2^-24 relative are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32 GEMM accuracy
+ *       (not the bitwise fma chain) at 2.7x fewer matrix-pipe cycles; inputs and outputs stay fp32;
+ *   0 = the library default (bf16x3; environment U2MKD_CONV_ARITH=f32 selects 1).
  * Work items (optional): a tile is a serial chain of MFMA blocks, so tiles with many blocks are cut
  * into halves / quarters: items[i] = tile << 4 | sub << 2 | lg  covers the 64 >> lg sorted rows from
  * 64 tile + (64 >> lg) sub, every row exactly once, listed heaviest first; *n_items (device memory,
  * never read by the host) of them.  NULL = one item per 64-row tile.                              */
 int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k);
-int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose,
-                           float *wf /*[k*rows*cols]*/, u2mkd_stream_t s);
-int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const float *wf, int32_t cout,
+size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32_t arith);
+int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
+                           void *wf, u2mkd_stream_t s);
+int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
                              const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
                              const int32_t *items /*[<= 4 ceil(n_out/64)] or NULL*/,
                              const int32_t *n_items /*[1] device, or NULL*/, int64_t n_out, int32_t k,
-                             int32_t kflip, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+                             int32_t kflip, int32_t arith, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
 /* Tuning / A-B experiments only (tools/ab_*.py), NOT part of the drop-in boundary:
  * u2mkd_conv_forward_sorted with an explicit kernel choice.  variant 0 = the product heuristic,
  * waves*100 + kc = conv_os2, 3000 + rb*100 + kc = conv_os3 (see conv.hip).                   */
@@ -146,10 +153,10 @@ int u2mkd_debug_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, 
                                     u2mkd_stream_t s);
 /* Profiling only: the 64 -> 64 tile-pair kernel with per-workgroup timestamps; stamps [tiles, 8] uint64 =
  * {realtime start, cycles start, after compaction, after the block walk, end, realtime end, blocks, tile}. */
-int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const float *wf /*fragments of [k,64,64]*/,
+int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const void *wf /*fragments of [k,64,64]*/,
                                        const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
-                                       const int32_t *n_items, int64_t n_out, int32_t k, float *out, uint64_t *stamps,
-                                       u2mkd_stream_t s);
+                                       const int32_t *n_items, int64_t n_out, int32_t k, int32_t arith, float *out,
+                                       uint64_t *stamps, u2mkd_stream_t s);
 /* Profiling only: the 64 x 64 weight-gradient kernel with s_memtime stamps of workgroup 0 (stamps [256]). */
 int u2mkd_debug_wgrad_stamps(const float *a, const float *b, const int32_t *pairs, const int32_t *plan, int64_t n_rows,
                              int32_t k, void *workspace, uint64_t *stamps, u2mkd_stream_t s);

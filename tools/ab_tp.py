@@ -30,22 +30,24 @@ def main(shapes=None):
         sch = km.schedule(False)
         outs = {}
         res = [f'ts={ts} N={n} P={p} {cin}->{cout}:']
-        wf = torch.empty_like(w); wfd = torch.empty_like(w)
-        L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, 1, L.ptr(wf), st)
-        L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, 0, L.ptr(wfd), st)
+        lib = L.load()
+        frag = {}
+        for ar in (1, 2):
+            for tr in (0, 1):
+                buf = torch.empty(lib.u2mkd_weight_fragments_bytes(27, cin, cout, ar), dtype=torch.uint8, device='cuda')
+                L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, tr, ar, L.ptr(buf), st)
+                frag[(ar, tr)] = buf
         def run(nm, a, ca, wts, cb, flip, o):
-            if nm == 'tp':
-                L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, ca, L.ptr(wts[0]), cb, L.ptr(sch.nbr_s), L.ptr(sch.order),
-                       L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, L.ptr(o), st)
-            elif nm == 'tp1':
-                L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, ca, L.ptr(wts[0]), cb, L.ptr(sch.nbr_s), L.ptr(sch.order),
-                       None, None, n, 27, flip, L.ptr(o), st)
+            if nm in ('tp', 'tpf32'):
+                ar = 2 if nm == 'tp' else 1
+                L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, ca, L.ptr(frag[(ar, 1 - flip)]), cb, L.ptr(sch.nbr_s), L.ptr(sch.order),
+                       L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, ar, L.ptr(o), st)
             else:
                 L.call('u2mkd_conv_forward_sorted', L.ptr(a), n, ca, L.ptr(wts[1]), cb, L.ptr(sch.nbr_s), L.ptr(sch.order),
                        L.ptr(sch.tile_order), n, 27, flip, L.ptr(o), st)
-        for nm in ('tp', 'tp1', 'walk'):
+        for nm in ('tp', 'tpf32', 'walk'):
             o = torch.empty(n, cout, device='cuda')
-            t = ev(lambda: run(nm, x, cin, (wf, wt), cout, 0, o))
+            t = ev(lambda: run(nm, x, cin, (None, wt), cout, 0, o))
             outs[nm] = o
             res.append(f'{nm} {t*1e3:.1f}us ({2.0*p*cin*cout/(t*1e-3)/1e12:.1f}TF)')
         ps = km.pair_schedule()
@@ -53,19 +55,19 @@ def main(shapes=None):
         t = ev(lambda: ps.run(x, wt, cout, False, o))
         outs['pairs'] = o
         res.append(f'pairs {t*1e3:.1f}us')
-        res.append('err tp-walk %.1e tp-pairs %.1e' % (float((outs['tp'] - outs['walk']).abs().max()),
+        res.append('err tp-walk %.1e tpf32-walk %.1e tp-pairs %.1e' % (float((outs['tp'] - outs['walk']).abs().max()), float((outs['tpf32'] - outs['walk']).abs().max()),
                                                         float((outs['tp'] - outs['pairs']).abs().max())))
         # input gradient (kflip = 1 on the same table, B = kernel as [cin][cout])
         g = torch.randn(n, cout, device='cuda')
         d = {}
         for nm in ('tp', 'walk'):
             o = torch.empty(n, cin, device='cuda')
-            t = ev(lambda: run(nm, g, cout, (wfd, w), cin, 1, o))
+            t = ev(lambda: run(nm, g, cout, (None, w), cin, 1, o))
             d[nm] = o
             res.append(f'dgrad-{nm} {t*1e3:.1f}us')
         res.append('err %.1e' % float((d['tp'] - d['walk']).abs().max()))
         a = outs['tp'].clone()
-        run('tp', x, cin, (wf, wt), cout, 0, outs['tp'])
+        run('tp', x, cin, (None, wt), cout, 0, outs['tp'])
         res.append('bitwise-repro %s' % bool(torch.equal(a, outs['tp'])))
         print(' | '.join(res), flush=True)
 

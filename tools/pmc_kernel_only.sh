@@ -11,6 +11,7 @@ run() {  # name, counters...
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -o pmc -- python3 "$REPO/bench.py" --kernel-only > "$out/stdout.txt" 2> "$out/stderr.txt" || echo "rc=$? for $name"
 }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVES
+run sq2 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 ls $REPO/gpurun_out/pmc_${TAG}_*

@@ -11,13 +11,14 @@ km = F.build_kmap(c, (1,) * 3, (3,) * 3, (1,) * 3)
 n = km.n_out
 sch = km.schedule(False)
 x = torch.randn(n, 64, device='cuda'); w = torch.randn(27, 64, 64, device='cuda') / 40
-wt = torch.empty_like(w); L.call('u2mkd_weight_fragments', L.ptr(w), 27, 64, 64, 1, L.ptr(wt), L.stream()); o = torch.empty(n, 64, device='cuda')
+ARITH = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+wt = torch.empty(L.load().u2mkd_weight_fragments_bytes(27, 64, 64, ARITH), dtype=torch.uint8, device='cuda'); L.call('u2mkd_weight_fragments', L.ptr(w), 27, 64, 64, 1, ARITH, L.ptr(wt), L.stream()); o = torch.empty(n, 64, device='cuda')
 tiles = (n + 63) // 64
 st = torch.zeros(4 * tiles + 64, 8, dtype=torch.int64, device='cuda')
 n_items = int(sch.n_items.item()); assert n_items <= 4 * tiles
 for _ in range(3):
     L.call('u2mkd_debug_conv_tile_pairs_stamps', L.ptr(x), n, L.ptr(wt), L.ptr(sch.nbr_s), L.ptr(sch.order), L.ptr(sch.items), L.ptr(sch.n_items),
-           n, 27, L.ptr(o), L.ptr(st), L.stream())
+           n, 27, ARITH, L.ptr(o), L.ptr(st), L.stream())
 torch.cuda.synchronize()
 sall = st.cpu().numpy(); s = sall[:n_items]; ph = sall[4 * tiles:]
 rt0 = s[:, 0].min()

@@ -984,36 +984,42 @@ int u2mkd_debug_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, 
 
 int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k) { return conv_tp_supported(cin, cout, k) ? 1 : 0; }
 
-int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, float *wf,
-                           u2mkd_stream_t s) {
-    U2_REQUIRE(w && wf, "u2mkd_weight_fragments: null pointer");
-    U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 16 == 0 && cols % 16 == 0,
-               "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 16", k, rows, cols);
-    return launch_weight_fragments(w, k, rows, cols, transpose ? 1 : 0, wf, as_stream(s));
+size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32_t arith) {
+    return weight_fragments_bytes(k, rows, cols, arith);
 }
 
-int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const float *wf, int32_t cout,
+int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
+                           void *wf, u2mkd_stream_t s) {
+    U2_REQUIRE(w && wf, "u2mkd_weight_fragments: null pointer");
+    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
+    U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 32 == 0 && cols % 32 == 0,
+               "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 32", k, rows, cols);
+    return launch_weight_fragments(w, k, rows, cols, transpose ? 1 : 0, arith, reinterpret_cast<float *>(wf), as_stream(s));
+}
+
+int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
                              const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
-                             const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, float *out,
+                             const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, int32_t arith, float *out,
                              u2mkd_stream_t s) {
     if (n_out <= 0) return 0;
     U2_REQUIRE(in && wf && nbr_sorted && out, "u2mkd_conv_forward_tiles: null pointer");
     U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles: kflip must be 0 or 1");
+    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_conv_forward_tiles: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
     U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles: empty input");
     U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles: items and n_items go together");
-    int rc = launch_conv_tp("u2mkd_conv_forward_tiles", in, cin, wf, cout, nbr_sorted, order,
-                            RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, kflip, out, as_stream(s));
+    int rc = launch_conv_tp("u2mkd_conv_forward_tiles", in, cin, reinterpret_cast<const float *>(wf), cout, nbr_sorted, order,
+                            RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, kflip, arith, out, as_stream(s));
     U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_tiles: no instantiation for %d -> %d channels, kernel volume %d "
                "(ask u2mkd_conv_tiles_supported first)", cin, cout, k);
     return rc;
 }
 
-int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const float *wf, const int32_t *nbr_sorted,
+int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const void *wf, const int32_t *nbr_sorted,
                                        const int32_t *order, const int32_t *items, const int32_t *n_items, int64_t n_out,
-                                       int32_t k, float *out, uint64_t *stamps, u2mkd_stream_t s) {
+                                       int32_t k, int32_t arith, float *out, uint64_t *stamps, u2mkd_stream_t s) {
     U2_REQUIRE(in && wf && nbr_sorted && out && stamps && n_out > 0, "u2mkd_debug_conv_tile_pairs_stamps: null pointer");
-    int rc = launch_conv_tp("u2mkd_debug_conv_tile_pairs_stamps", in, 64, wf, 64, nbr_sorted, order,
-                            RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, 0, out, as_stream(s),
+    int rc = launch_conv_tp("u2mkd_debug_conv_tile_pairs_stamps", in, 64, reinterpret_cast<const float *>(wf), 64, nbr_sorted,
+                            order, RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, 0, arith, out, as_stream(s),
                             reinterpret_cast<unsigned long long *>(stamps));
     return rc < 0 ? 2 : rc;
 }

@@ -13,12 +13,14 @@ struct RowRange {
     const int32_t *tile_order;   // launch order of the 64-row tiles (heaviest first) or nullptr (offset-walking kernels)
 };
 
-// Tile-local pair schedule (conv_tp.hip); wf = weight fragments of launch_weight_fragments.  Returns -1 when
-// the shape has no instantiation, else the launch status.
+// Tile-local pair schedule (conv_tp.hip); wf = weight fragments of launch_weight_fragments (same `arith`).
+// Returns -1 when the shape has no instantiation, else the launch status.
 int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *nbr,
                    const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int k, int kflip,
-                   float *out, hipStream_t st, unsigned long long *stamps = nullptr);
+                   int arith, float *out, hipStream_t st, unsigned long long *stamps = nullptr);
 bool conv_tp_supported(int cin, int cout, int k);
-int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, float *wf, hipStream_t st);
+int conv_tp_arith(int arith);
+size_t weight_fragments_bytes(int k, int rows, int cols, int arith);
+int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st);
 
 }  // namespace u2mkd

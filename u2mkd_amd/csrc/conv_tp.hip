@@ -35,6 +35,8 @@
 //   * __syncthreads() waits for vmcnt(0): the loop uses an LDS-only barrier;
 //   * a tile is a serial chain of blocks (up to 62 at 64 rows, mean 16): tiles above 30 / 60 blocks run as
 //     2 / 4 work items (TileSchedule in torchsparse/nn/functional.py), heaviest item first.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_internal.h"
@@ -63,7 +65,70 @@ __global__ void weight_fragments_kernel(const float *__restrict__ w, int rows, i
     wf[t] = transpose ? w[((size_t)k * rows + red) * cols + col] : w[((size_t)k * rows + col) * cols + red];
 }
 
-template <int NW, int NBW, int CIN, bool STAMP>
+// ---- fp32 through three bf16 MFMA operands ("bf16x3") -------------------------------------------
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): the three 8-bit significands tile the
+// 24-bit one, both subtractions are exact.  a*b = sum of the nine partial products, each of them exact in fp32;
+// the six with (order_a + order_b) <= 2 are kept -- the dropped ones are below 2^-24 |a b|, half an fp32 ulp of the
+// product -- and accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (8192 MACs per 16-cycle issue against 1024 per
+// 32 cycles of v_mfma_f32_16x16x4_f32: 16x the rate, 6 products -> 2.7x fewer matrix-pipe cycles at fp32
+// accuracy).  Result = fp32 GEMM accuracy, not the bitwise fma chain of the f32 MFMA; tests hold it to the same
+// gates (tests/test_gpu_torchsparse_ops.py: <= 1e-4 relative on operators, measured ~1e-6; bitwise reproducible).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    float r1 = x - (float)h;
+    m = (__bf16)r1;
+    float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+// Fragment layout, bf16x3: wf3[k][cb][f = 3 s + p][lane][8 bf16] = plane p (0 = h, 1 = m, 2 = l) of
+// B_k[16 cb + r][32 s + 8 q .. +7], lane = r + 16 q: the operand fragment of v_mfma_f32_16x16x32_bf16
+// (lane l holds A[row l & 15][k = 8 (l >> 4) + j]).  One thread reads 8 reduction channels of one column
+// and writes the three 16-byte fragments.
+__global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows, int cols, int transpose,
+                                           bf16x8 *__restrict__ wf, int64_t total) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
+    const int lane = (int)(t & 63);
+    int64_t u = t >> 6;
+    const int ns = nred / 32, ncb = ncol / 16;
+    const int sstep = (int)(u % ns);
+    u /= ns;
+    const int cb = (int)(u % ncb);
+    const int64_t k = u / ncb;
+    const int col = 16 * cb + (lane & 15), red0 = 32 * sstep + 8 * (lane >> 4);
+    float x[8];
+    if (transpose) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = w[((size_t)k * rows + red0 + i) * cols + col];
+    } else {
+        const float4 *p = reinterpret_cast<const float4 *>(w + ((size_t)k * rows + col) * cols + red0);
+        const float4 a = p[0], b = p[1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+    bf16x8 vh, vm, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h, m, l;
+        split3(x[i], h, m, l);
+        vh[i] = h; vm[i] = m; vl[i] = l;
+    }
+    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * 3 * 64 + lane;
+    o[0] = vh;
+    o[64] = vm;
+    o[128] = vl;
+}
+
+__device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
+    f32x4 v = (f32x4){x.x, x.y, x.z, x.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NW, int NBW, int CIN, bool STAMP, bool X3>
 __global__ void __launch_bounds__(64 * NW)
 conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int cout, const int32_t *__restrict__ nbr,
                const int32_t *__restrict__ order, RowRange rr_, const int32_t *__restrict__ items,
@@ -76,7 +141,9 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     if (STAMP) { t_rt0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_amdgcn_s_memtime(); }
     constexpr int T = 64, NT = 64 * NW, TN = 16 * NW * NBW, NJ = CIN / 16;
     constexpr int OS = TN + 4;                    // output tile row stride (floats)
-    constexpr int AS = CIN + 4;                   // gathered-row image row stride (floats)
+    // gathered-row image: fp32 rows, or (X3) three bf16 planes h | m | l of CIN elements per row; + 16 B pad
+    constexpr int AS = X3 ? (6 * CIN + 16) / 4 : CIN + 4;        // row stride (floats)
+    constexpr int NF = X3 ? CIN / 32 * 3 : CIN / 16;             // 16-byte operand fragments per lane per block
     constexpr int CPR = CIN / 4;                  // 16-byte chunks per gathered row
     constexpr int LPT = (16 * CPR + NT - 1) / NT; // chunks a thread moves per block
     constexpr int KPW = (32 + NW - 1) / NW;       // offsets a wave compacts (K <= 32)
@@ -177,7 +244,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // MFMAs + one barrier (in-kernel stamps of the straightforward order: 2.0k cycles per step, 0.5k of them MFMA).
     // The MFMA computes D^T = B_k (A operand) x rows^T (B operand): a lane ends up with 4 consecutive output
     // columns of ONE pair.  Lanes of a padded last block (idx < 0) multiply row 0 and drop the result.
-    float4 bw[2][NJ][NBW], a[NJ];
+    float4 bw[2][NF][NBW], a[NF];
     f32x4 g[3][LPT];      // (native vector type: the HIP float4 struct kept this ring in scratch memory)
     int gix[LPT];                                  // gather row of this thread's chunk(s), block t+4
     int pidx[2], prow[2];                          // (input row, output tile row) of pair r, blocks t / t+1
@@ -187,7 +254,11 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
 
     auto desc = [&](int t) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(s_blk[t]); };
     auto dbase = [&](int d) __attribute__((always_inline)) { return (d >> 8) * T + 16 * (d & 255); };
-    auto issue_B = [&](int d, float4 (&bb)[NJ][NBW]) __attribute__((always_inline)) {
+    // (Tried, MI355X: switching the fragment load of block t+1 off when its offset equals block t's -- all lanes
+    // reading one address, registers kept by a select -- to spare the texture addresser: no gain at 64 -> 64
+    // (45.0 vs 42.9 us), a loss at 64 -> 128.  Buffer loads with an out-of-range offset cannot be used: hipcc 7.2
+    // narrows element reads of __builtin_amdgcn_raw_buffer_load_b128 into dword loads at the wrong offset.)
+    auto issue_B = [&](int d, float4 (&bb)[NF][NBW]) __attribute__((always_inline)) {
         int k = d >> 8;
         if (k >= K) k = K - 1;                        // sentinel block: any valid fragment
         if (kf) k = K - 1 - k;
@@ -195,9 +266,9 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         for (int n = 0; n < NBW; ++n) {
             int cb = cb0 + n;
             if (cb >= ncb) cb = ncb - 1;              // column blocks past cout: computed, never stored
-            const float *pb = wf + ((((size_t)k * ncb + cb) * NJ) * 64 + lane) * 4;
+            const float *pb = wf + ((((size_t)k * ncb + cb) * NF) * 64 + lane) * 4;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bb[j][n] = *reinterpret_cast<const float4 *>(pb + (size_t)j * 256);
+            for (int j = 0; j < NF; ++j) bb[j][n] = *reinterpret_cast<const float4 *>(pb + (size_t)j * 256);
         }
     };
     auto read_gix = [&](int d) __attribute__((always_inline)) {
@@ -222,13 +293,34 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         for (int i = 0; i < LPT; ++i) {
             const int e = tid + i * NT;
             const int pr = e / CPR, ch = e - pr * CPR;
-            if (e < 16 * CPR) *reinterpret_cast<f32x4 *>(s_a + (slot * 16 + pr) * AS + 4 * ch) = gg[i];
+            if (e < 16 * CPR) {
+                if (X3) {      // split the 4 channels into the three bf16 planes of the row image
+                    bf16x4 h, m, l;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        __bf16 hh, mm, ll;
+                        split3(gg[i][c], hh, mm, ll);
+                        h[c] = hh; m[c] = mm; l[c] = ll;
+                    }
+                    char *row = reinterpret_cast<char *>(s_a + (slot * 16 + pr) * AS) + 8 * ch;
+                    *reinterpret_cast<bf16x4 *>(row) = h;
+                    *reinterpret_cast<bf16x4 *>(row + 2 * CIN) = m;
+                    *reinterpret_cast<bf16x4 *>(row + 4 * CIN) = l;
+                } else {
+                    *reinterpret_cast<f32x4 *>(s_a + (slot * 16 + pr) * AS + 4 * ch) = gg[i];
+                }
+            }
         }
     };
-    auto read_frag = [&](int slot, float4 (&aa)[NJ]) __attribute__((always_inline)) {
+    auto read_frag = [&](int slot, float4 (&aa)[NF]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            aa[j] = *reinterpret_cast<const float4 *>(s_a + (slot * 16 + r) * AS + 16 * j + 4 * q);
+        for (int j = 0; j < NF; ++j) {
+            if (X3)    // fragment j = 3 s + p: 8 consecutive channels 32 s + 8 q .. of plane p
+                aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) +
+                                                          (j % 3) * 2 * CIN + 64 * (j / 3) + 16 * q);
+            else
+                aa[j] = *reinterpret_cast<const float4 *>(s_a + (slot * 16 + r) * AS + 16 * j + 4 * q);
+        }
     };
 
     if (total > 0) {
@@ -252,8 +344,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             constexpr int u = decltype(U)::value;
                 // -- issue everything later steps need
             read_frag(u % 3, a);                                     // block t (stored at step t-2, barrier since)
-            issue_G(g[(u + 4) % 3]);                                 // block t+4
             issue_B(d1, bw[(u + 1) & 1]);                            // block t+1
+            issue_G(g[(u + 4) % 3]);                                 // block t+4
             read_gix(d5);                                            // block t+5
             pidx[(u + 1) & 1] = s_idx[dbase(d1) + r];                // block t+1
             prow[(u + 1) & 1] = s_row[dbase(d1) + r];
@@ -269,14 +361,30 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             }
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)
                 f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (X3) {
+                    // the six partial products per 32-channel step, low order first; weights = A operand
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].x, a[j].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].y, a[j].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].z, a[j].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].w, a[j].w, acc1, 0, 0, 0);
+                    for (int sk = 0; sk < CIN / 32; ++sk) {
+                        const bf16x8 wh = as_bf8(bw[u & 1][3 * sk][n]), wm = as_bf8(bw[u & 1][3 * sk + 1][n]),
+                                     wl = as_bf8(bw[u & 1][3 * sk + 2][n]);
+                        const bf16x8 xh = as_bf8(a[3 * sk]), xm = as_bf8(a[3 * sk + 1]), xl = as_bf8(a[3 * sk + 2]);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc1, 0, 0, 0);
+                    }
+                } else {
+                    // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].x, a[j].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].y, a[j].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].z, a[j].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].w, a[j].w, acc1, 0, 0, 0);
+                    }
                 }
                 // D^T: lane (r, q) holds columns 4q .. 4q+3 of pair r
                 if (live) {
@@ -330,14 +438,14 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     }
 }
 
-template <int NW, int NBW, int CIN, bool STAMP = false>
+template <int NW, int NBW, int CIN, bool STAMP = false, bool X3 = false>
 static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const float *wt, int cout, const int32_t *nbr,
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
-    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)3 * 16 * (CIN + 4) * 4 + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
+    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)3 * 16 * (X3 ? 6 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
                        (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
-    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
+    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, X3>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
                        items, n_items, K, kflip, out, stamps);
 }
 
@@ -360,20 +468,37 @@ bool conv_tp_supported(int cin, int cout, int k) {
     return cin * nbw <= 128;      // weight fragment (double-buffered) + gathered rows stay in registers
 }
 
+// arithmetic of the tile-pair kernel: 1 = f32 MFMA (bitwise fma chain), 2 = bf16x3 (fp32 accuracy, 2.7x fewer
+// matrix-pipe cycles); 0 = the library default (U2MKD_CONV_ARITH=f32|bf16x3, default bf16x3)
+int conv_tp_arith(int arith) {
+    if (arith == 1 || arith == 2) return arith;
+    static const int dflt = [] {
+        const char *e = getenv("U2MKD_CONV_ARITH");
+        return (e && e[0] == 'f') ? 1 : 2;
+    }();
+    return dflt;
+}
+
 int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *nbr,
                    const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int k, int kflip,
-                   float *out, hipStream_t st, unsigned long long *stamps) {
+                   int arith, float *out, hipStream_t st, unsigned long long *stamps) {
     if (!conv_tp_supported(cin, cout, k)) return -1;
     int nw = 0, nbw = 0;
     tp_split(cout, nw, nbw);
+    const bool x3 = conv_tp_arith(arith) == 2;
     const int64_t n_rows = rr.end - rr.begin;
     dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile
-#define U2_TP(NW_, NBW_, CIN_) launch_tp<NW_, NBW_, CIN_>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out)
+#define U2_TP(NW_, NBW_, CIN_)                                                                                          \
+    do {                                                                                                                \
+        if (x3) launch_tp<NW_, NBW_, CIN_, false, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
+        else launch_tp<NW_, NBW_, CIN_, false, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);    \
+    } while (0)
     if (nw == 2) {
         if (cin == 32) U2_TP(2, 1, 32); else if (cin == 64) U2_TP(2, 1, 64);
         else if (cin == 96) U2_TP(2, 1, 96); else U2_TP(2, 1, 128);
     } else if (nw == 4 && nbw == 1) {
-        if (stamps && cin == 64) launch_tp<4, 1, 64, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        if (stamps && cin == 64 && x3) launch_tp<4, 1, 64, true, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        else if (stamps && cin == 64) launch_tp<4, 1, 64, true, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
         else if (cin == 32) U2_TP(4, 1, 32); else if (cin == 64) U2_TP(4, 1, 64);
         else if (cin == 96) U2_TP(4, 1, 96); else U2_TP(4, 1, 128);
     } else if (nw == 3) {
@@ -385,11 +510,21 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     return check_launch(who);
 }
 
-int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, float *wf, hipStream_t st) {
-    const int64_t total = (int64_t)k * rows * cols;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, rows, cols,
-                       transpose, wf, total);
+size_t weight_fragments_bytes(int k, int rows, int cols, int arith) {
+    return (size_t)k * rows * cols * (conv_tp_arith(arith) == 2 ? 6 : 4);
+}
+
+int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st) {
+    const int64_t elems = (int64_t)k * rows * cols;
+    if (elems == 0) return 0;
+    if (conv_tp_arith(arith) == 2) {
+        const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
+        hipLaunchKernelGGL(weight_fragments_x3_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, rows, cols,
+                           transpose, reinterpret_cast<bf16x8 *>(wf), total);
+    } else {
+        hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, w, rows, cols,
+                           transpose, wf, elems);
+    }
     return check_launch("u2mkd_weight_fragments");
 }
 

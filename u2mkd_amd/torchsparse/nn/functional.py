@@ -330,7 +330,7 @@ class TileSchedule:
         if L.load().u2mkd_conv_tiles_supported(cin, cout, self.k):
             wf = _weight_layout(weight, transpose, True)
             L.call('u2mkd_conv_forward_tiles', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
-                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), L.ptr(out),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), 0, L.ptr(out),
                    L.stream())
         else:
             wt = _weight_layout(weight, transpose, False)
@@ -555,11 +555,11 @@ def _weight_layout(weight, transpose, fragments):
     key = '_u2mkd_w%d%d' % (int(transpose), int(fragments))
     if frozen:
         hit = weight.__dict__.get(key)
-        if hit is not None and hit[0] == weight._version and hit[1].numel() == weight.numel():
+        if hit is not None and hit[0] == weight._version:
             return hit[1]
     if fragments:
-        out = torch.empty(k * r * c, dtype=torch.float32, device=weight.device)
-        L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, int(transpose), L.ptr(out), L.stream())
+        out = torch.empty(L.load().u2mkd_weight_fragments_bytes(k, r, c, 0), dtype=torch.uint8, device=weight.device)
+        L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, int(transpose), 0, L.ptr(out), L.stream())
     else:
         out = torch.empty(k, c, r, dtype=torch.float32, device=weight.device)
         L.call('u2mkd_transpose_weights', L.ptr(weight), k, r, c, L.ptr(out), L.stream())
