@@ -613,6 +613,13 @@ conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__rest
         }
 }
 
+// (Tried and rejected, MI355X: this kernel in bf16x3 arithmetic -- both gathered operands split into three bf16
+// planes at the LDS store, fragments read with ds_read_b64_tr_b16, 6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block.
+// Bit-for-bit gate passed, but 50.6 us against 44.3 us at 64 x 64 and 610 against 438 us at 256 x 256: every element
+// of BOTH operands needs the ~10-instruction split at run time and feeds only 64 MACs, which costs the vector ALU
+// what the matrix pipe saves, and the fragments + planes push the kernel to 2 waves per SIMD.  The forward kernel
+// is different: its weights are split once, off line, and a gathered row is split once for 4 column-split waves.)
+
 // dw[k][e] = sum of the offset's slabs, fixed order: 16 slab lanes x 16 float4 lanes per
 // block (64 elements); lane g sums slabs wg[k]+g, +16, ... and the 16 partials are added
 // in lane order through LDS (deterministic, ~P/CH/16 dependent loads per thread).
