@@ -195,3 +195,40 @@ def test_sync_bn_pieces_emulate_two_ranks_on_one_gpu(hip, n0, n1, c, relu):
     gs = max(1.0, float(ref.weight.grad.abs().max()))
     assert float((reduced[:c].double() - ref.bias.grad).abs().max()) < 1e-4 * gs
     assert float((reduced[c:].double() - ref.weight.grad).abs().max()) < 1e-4 * gs
+
+
+def test_teacher_only_step_masks_the_loss_to_key_frame_voxels(hip):
+    """Row f4 -- the stage-1 trainer (core/spformer_trainer.py:58-94) on a multi-sweep scene: the network sees the
+    voxels of all sweeps, the loss only the key-frame ones (`outputs['x_vox'][keyframe_mask]`).  The product step
+    must give the loss and the gradients of the manual computation on the same weights, and voxels of the other
+    sweeps must not contribute to the classifier's bias gradient."""
+    from u2mkd_amd import lidar, torchsparse as ts, train as T
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    b = synth_batch(6000, 1, seed=9, sweeps=3)
+    kf = torch.from_numpy(b['keyframe']).cuda()
+    assert 0 < int(kf.sum()) < kf.numel()                   # genuinely multi-sweep
+    feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+    torch.manual_seed(0)
+    kw = dict(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05)
+    model = lidar.SPVCNN(**kw).cuda().train()
+    model.dropout.p = 0.0
+    twin = lidar.SPVCNN(**kw).cuda().train()
+    twin.dropout.p = 0.0
+    twin.load_state_dict(model.state_dict())
+    # manual: forward, mask, loss, backward
+    out = twin({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+    want = MixLovaszCrossEntropy(ignore_index=0)(out[kf], labels[kf])
+    want.backward()
+    runner = T.LidarStep(model, num_epochs=1, batch_size=1)
+    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    got = runner(feats, coords, labels, keyframe_mask=kf)
+    assert abs(float(got) - float(want)) < 1e-5
+    # the step was plain SGD-nesterov from zero momentum: p1 = p0 - lr * (1 + momentum) * (g + wd * p0)
+    lr, mom, wd = 0.24, 0.9, 1.0e-4
+    for n, p in model.named_parameters():
+        g = dict(twin.named_parameters())[n].grad
+        step = (w0[n] - p.detach()) / (lr * (1 + mom)) - wd * w0[n]
+        assert float((step - g).abs().max()) <= 2e-4 * max(1.0, float(g.abs().max())), n
+    # and the loss without the mask is a different number (the mask is not a no-op on this scene)
+    full = MixLovaszCrossEntropy(ignore_index=0)(out.detach(), labels)
+    assert abs(float(full) - float(want)) > 1e-4

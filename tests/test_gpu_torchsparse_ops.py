@@ -416,3 +416,25 @@ def test_v140_backend_format_entries(F, kind, cin, cout):
     with pytest.raises(RuntimeError, match='multiples of 4'):
         L.call('u2mkd_convolution_forward', L.ptr(xd), n_in, 6, L.ptr(out), n_out, cout, L.ptr(wd), L.ptr(nb_dev),
                ctypes.addressof(sizes_host), k, int(transposed), L.ptr(ws), nbytes, L.stream())
+
+
+@pytest.mark.parametrize('cin,cout', [(5, 32), (3, 17), (32, 17)])
+def test_conv3d_accepts_any_channel_count(hip, cin, cout):
+    """torchsparse v1.4.0 has no channel-multiple restriction (in_channel = 5 with a time channel, 3, an odd class
+    count): the drop-in zero-pads to 16-byte rows inside F.conv3d; forward and both gradients equal the oracle."""
+    import u2mkd_amd.torchsparse as ts
+    from u2mkd_amd.torchsparse.nn import functional as F
+    coords, _ = _scene(1500, 2, seed=2)
+    torch.manual_seed(cin + cout)
+    x = torch.randn(len(coords), cin)
+    w = torch.randn(27, cin, cout) / (27 * cin) ** 0.5
+    g = torch.randn(len(coords), cout)
+    nbmaps, nbsizes, _, _ = R.build_kmap(coords, 1, 3, 1)
+    want = R.conv_forward(x, w, nbmaps, nbsizes, (len(coords), len(coords)))
+    wgi, wgw = R.conv_backward(x, w, g, nbmaps, nbsizes)
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    out = F.conv3d(ts.SparseTensor(xd, _dev(coords)), wd, kernel_size=3).F
+    assert out.shape == (len(coords), cout) and _rel(out, want) < 1e-4
+    out.backward(g.cuda())
+    assert xd.grad.shape == x.shape and _rel(xd.grad, wgi) < 1e-4
+    assert wd.grad.shape == w.shape and _rel(wd.grad, wgw) < 1e-4

@@ -97,13 +97,18 @@ def _csr_by_destination(keys: torch.Tensor, nv: int):
     return order, seg
 
 
-def _plan(t: torch.Tensor, name: str, build):
+def _plan(t: torch.Tensor, name: str, build, *deps):
     """Cache a derived index structure on the index tensor it was derived from (the point<->voxel
-    index tensors are themselves cached by the model in z.idx_query / z.additional_features)."""
+    index tensors are themselves cached by the model in z.idx_query / z.additional_features).  The entry is
+    rebuilt when the index tensor, or any tensor in ``deps`` that is baked into the plan, has been written in
+    place or replaced since (torch version counters + data pointers): torchsparse's functions carry no hidden
+    state, so a caller may edit ``idx`` / ``weights`` between two calls."""
     cache = t.__dict__.setdefault('_u2mkd_plans', {})
-    if name not in cache:
-        cache[name] = build()
-    return cache[name]
+    stamp = (t._version,) + tuple((d.data_ptr(), d._version) for d in deps)
+    hit = cache.get(name)
+    if hit is None or hit[0] != stamp:
+        hit = cache[name] = (stamp, build())
+    return hit[1]
 
 
 def _segment_sum(src, erow, ew, seg, nv, mean):
@@ -184,7 +189,7 @@ class DevoxelizeFunction(Function):
                 keys = torch.where(weights != 0, coords, -1).view(-1)          # [n*8], zero-weight corners dropped
                 order, seg = _csr_by_destination(keys, nv)
                 return (order >> 3).contiguous(), weights.view(-1)[order.long()].contiguous(), seg
-            erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build)
+            erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build, weights)
             gi = _segment_sum(g, erow, ew, seg, nv, False)
         else:
             gi = torch.zeros(nv, c, dtype=torch.float32, device=g.device)
@@ -735,6 +740,22 @@ class ConvolutionFunction(Function):
         return grad_input, grad_weight, None, None
 
 
+def _conv_any_channels(feats, weight, kmap, transposed):
+    """ConvolutionFunction for any channel count, as torchsparse v1.4.0 accepts (e.g. in_channel = 5 with a time
+    channel, or 3): the kernels move 16-byte row segments, so channel counts that are not multiples of 4 are
+    zero-padded to the next multiple (rows of `kernel` for cin, columns for cout; differentiable, the padded
+    entries receive zero gradient and the extra output columns are dropped)."""
+    cin, cout = weight.shape[1], weight.shape[2]
+    pin, pout = (-cin) % 4, (-cout) % 4
+    if feats.shape[1] != cin:
+        raise RuntimeError(f'conv3d: input has {feats.shape[1]} channels, kernel expects {cin}')
+    if pin == 0 and pout == 0:
+        return ConvolutionFunction.apply(feats, weight, kmap, transposed)
+    feats = torch.nn.functional.pad(feats, (0, pin))
+    weight = torch.nn.functional.pad(weight, (0, pout, 0, pin))
+    return ConvolutionFunction.apply(feats, weight, kmap, transposed)[:, :cout]
+
+
 def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, stride=1, dilation=1,
            transposed: bool = False) -> SparseTensor:
     feats, coords = input.feats, input.coords
@@ -758,7 +779,7 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, st
             # v1.4.0 builds the offsets from the tensor stride only (dilation is not applied)
             kmap = build_kmap(coords, input.stride, kernel_size, stride)
             input.kmaps[key] = kmap
-        feats = ConvolutionFunction.apply(feats, weight, kmap, transposed)
+        feats = _conv_any_channels(feats, weight, kmap, transposed)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(coords=kmap.out_coords, feats=feats,
@@ -766,7 +787,7 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, st
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
-        feats = ConvolutionFunction.apply(feats, weight, kmap, transposed)
+        feats = _conv_any_channels(feats, weight, kmap, transposed)
         if bias is not None:
             feats = feats + bias
         output = SparseTensor(coords=input.cmaps[tensor_stride], feats=feats, stride=tensor_stride)
