@@ -133,19 +133,21 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
         x = torch.randn(n, cin, device='cuda', generator=g)
         w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
         gy = torch.randn(n, cout, device='cuda', generator=g)
-        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty(lib.u2mkd_weight_fragments_bytes(27, cin, cout, 0), dtype=torch.uint8, device='cuda'), 'out': torch.empty(n, cout, device='cuda'),
+        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty(2, lib.u2mkd_weight_fragments_bytes(27, cin, cout, 0), dtype=torch.uint8, device='cuda'), 'out': torch.empty(n, cout, device='cuda'),
              'dx': torch.empty(n, cin, device='cuda'), 'dw': torch.empty_like(w),
              'ws': torch.empty(nbytes, dtype=torch.uint8, device='cuda'),
              # private copies of the map structures, so a cold launch also misses on the indices
              'nbr_s': sch.nbr_s.clone(), 'order': sch.order.clone(), 'pairs': pairs.clone()}
 
-        # a pass = the weight re-layout into MFMA fragment order (442 KB, its own small launch) + the conv kernel
-        def conv(s, a, transpose, flip, o):
-            L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, transpose, 0, L.ptr(s['wf']), st)
-            L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf']), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
+        # forward = the weight re-layout into MFMA fragment order (442 KB -> both orientations, ONE small launch per
+        # weight per training step: the input gradient of the same step reads the second half) + the conv kernel
+        def conv(s, a, frag, flip, o):
+            if not flip:
+                L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, 2, 0, L.ptr(s['wf']), st)
+            L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf'][frag]), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
                    L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, 0, L.ptr(o), st)
-        s['fwd'] = lambda s=s: conv(s, s['x'], 1, 0, s['out'])
-        s['dgrad'] = lambda s=s: conv(s, s['gy'], 0, 1, s['dx'])
+        s['fwd'] = lambda s=s: conv(s, s['x'], 0, 0, s['out'])
+        s['dgrad'] = lambda s=s: conv(s, s['gy'], 1, 1, s['dx'])
         s['wgrad'] = lambda s=s: L.call('u2mkd_conv_wgrad_pairs', L.ptr(s['x']), cin, L.ptr(s['gy']), cout, L.ptr(s['pairs']),
                                         L.ptr(plan), n, 27, 0, L.ptr(s['ws']), nbytes, L.ptr(s['dw']), st)
         return s
@@ -175,7 +177,7 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
     return {
         'bound': 'hbm', 'achieved': round(gbs(total_b, t_warm), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4), 'traffic': traffic,
-        'kernel': 'SubMConv3d fwd+dgrad+wgrad ((weight_fragments_kernel + conv_tp_kernel) x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
+        'kernel': 'SubMConv3d fwd+dgrad+wgrad (weight_fragments_kernel for both orientations + conv_tp_kernel x2 + conv_wgrad_pairs_kernel + reduce), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
         'ms': dict(r3(warm), total=round(t_warm, 4)),
         'GBps': {'fwd': round(gbs(b_f, warm['fwd']), 1), 'dgrad': round(gbs(b_d, warm['dgrad']), 1),

@@ -125,6 +125,8 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
  *   forward:        w = kernel [k,cin,cout], transpose = 1   (B_k[col][ci] = kernel[k][ci][col])
  *   input gradient: w = kernel [k,cin,cout], transpose = 0   (B_k[ci][co]  = kernel[k][ci][co])
  * wf has u2mkd_weight_fragments_bytes(k, rows, cols, arith) bytes; rows and cols must be multiples of 32.
+ * transpose = 2 writes BOTH layouts in one launch (a training step needs both, the launch is latency-bound):
+ * wf = [transpose = 1 layout | transpose = 0 layout], 2 x u2mkd_weight_fragments_bytes bytes.
  * arith selects the arithmetic of the MFMA tiles (the same value for the fragments and the convolution):
  *   1 = f32 MFMA (v_mfma_f32_16x16x4_f32: the exact fp32 fma chain);
  *   2 = bf16x3: every fp32 operand is split exactly into three bf16 (8 + 8 + 8 significand bits), the six partial

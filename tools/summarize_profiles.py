@@ -38,7 +38,7 @@ t = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `be
      'weight_fragments': traffic('weight_fragments'),
      'conv_wgrad_pairs': traffic('conv_wgrad_pairs_kernel'),
      'wgrad_reduce': traffic('wgrad_pairs_reduce_kernel')}
-t['group_fwd_dgrad_wgrad'] = 2 * (t['conv_tp_fwd_or_dgrad'] + t['weight_fragments']) + t['conv_wgrad_pairs'] + t['wgrad_reduce']
+t['group_fwd_dgrad_wgrad'] = 2 * t['conv_tp_fwd_or_dgrad'] + t['weight_fragments'] + t['conv_wgrad_pairs'] + t['wgrad_reduce']
 json.dump(t, open(os.path.join(P, f'{rnd}_traffic.json'), 'w'), indent=1)
 print(json.dumps(t, indent=1))
 for k in ('conv_tp_kernel', 'conv_wgrad_pairs_kernel'):

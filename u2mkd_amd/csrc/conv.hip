@@ -1001,7 +1001,8 @@ int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols
     U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
     U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 32 == 0 && cols % 32 == 0,
                "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 32", k, rows, cols);
-    return launch_weight_fragments(w, k, rows, cols, transpose ? 1 : 0, arith, reinterpret_cast<float *>(wf), as_stream(s));
+    U2_REQUIRE(transpose >= 0 && transpose <= 2, "u2mkd_weight_fragments: transpose must be 0, 1 or 2 (both)");
+    return launch_weight_fragments(w, k, rows, cols, transpose, arith, reinterpret_cast<float *>(wf), as_stream(s));
 }
 
 int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,

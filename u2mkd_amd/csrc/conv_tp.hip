@@ -16,7 +16,7 @@
 //   2. walks the blocks in a software pipeline (details at the loop).  The waves split the output
 //      COLUMNS (16*NBW each): every wave does the same work on every block and owns its columns of the
 //      LDS-resident output tile exclusively.  The gathered rows of a block are read ONCE by the
-//      workgroup, coalesced (16 lanes per row), through a 3-slot LDS image; the MFMA computes
+//      workgroup, coalesced (16 lanes per row), through a 2-slot LDS image; the MFMA computes
 //      D^T = B_k x rows^T (weights as the A operand), which leaves each lane with 4 CONSECUTIVE output
 //      columns of ONE pair: the accumulate into the output tile is one ds_read_b128 + ds_write_b128;
 //   3. weights come in MFMA-fragment order (u2mkd_weight_fragments), so a wave's fragment load is
@@ -52,6 +52,10 @@ __global__ void weight_fragments_kernel(const float *__restrict__ w, int rows, i
                                         float *__restrict__ wf, int64_t total) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
+    if (transpose == 2) {      // both orientations in one launch: [transpose = 1 | transpose = 0]
+        transpose = 1 - (int)blockIdx.y;
+        wf += (size_t)blockIdx.y * total;
+    }
     const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
     const int c = (int)(t & 3);
     const int lane = (int)((t >> 2) & 63);
@@ -92,6 +96,10 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
                                            bf16x8 *__restrict__ wf, int64_t total) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
+    if (transpose == 2) {      // both orientations in one launch: [transpose = 1 | transpose = 0]
+        transpose = 1 - (int)blockIdx.y;
+        wf += (size_t)blockIdx.y * total * 3;
+    }
     const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
     const int lane = (int)(t & 63);
     int64_t u = t >> 6;
@@ -149,8 +157,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     constexpr int KPW = (32 + NW - 1) / NW;       // offsets a wave compacts (K <= 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_out = reinterpret_cast<float *>(smem);                           // [T][OS]
-    float *s_a = s_out + T * OS;                                              // [3][16][AS] gathered rows of blocks t .. t+2
-    int *s_idx = reinterpret_cast<int *>(s_a + 3 * 16 * AS);                  // [K+1][T] compacted input rows (+ sentinel row)
+    float *s_a = s_out + T * OS;                                              // [2][16][AS] gathered rows of blocks t, t+1
+    int *s_idx = reinterpret_cast<int *>(s_a + 2 * 16 * AS);                  // [K+1][T] compacted input rows (+ sentinel row)
     int *s_cnt = s_idx + (K + 1) * T;                                         // [32] pairs per offset
     int *s_rid = s_cnt + 32;                                                  // [T] original output row
     int *s_blk = s_rid + T;                                                   // [4K + 8] block descriptors
@@ -227,14 +235,16 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         if (lane < 8) s_blk[total + lane] = K << 8;          // desc(t + 6) is read at the last step
     }
 
-    // ---- 3. software pipeline over the blocks.  Block b's data moves through five steps, all waves in
+    // ---- 3. software pipeline over the blocks.  Block b's data moves through four steps, all waves in
     // lockstep (one barrier per step; every wave does the same work in every step):
-    //   step b-4  gather issue: 16 rows x CIN floats, one 16-byte chunk per thread, 16 consecutive lanes read
+    //   step b-3  gather issue: 16 rows x CIN floats, one 16-byte chunk per thread, 16 consecutive lanes read
     //             one row's contiguous bytes (a gather straight into MFMA operand registers is 64 uncoalesced
     //             16-byte accesses per wave instruction -- measured texture-addresser-bound -- and repeats the
     //             gather in every column-split wave);
-    //   step b-2  the rows are stored into one third of the LDS row image (3 slots: the slot stored at step t
-    //             was last read at step t-1, one barrier earlier);
+    //   step b-1  the rows are stored into one half of the LDS row image (2 slots: the slot stored at the end of
+    //             step t was last read at the top of step t-1, one barrier earlier, and is read at step t+1, one
+    //             barrier later; a third slot and a store one step earlier cost 6.4 KB of LDS = the fourth
+    //             workgroup per CU: 42.9 -> 39.9 us at 64 -> 64);
     //   step b-1  this wave's weight fragment of block b's offset is issued (1 KiB contiguous per instruction; re-loading an unchanged
     //             offset is an L1 hit -- loads stay UNCONDITIONAL so that the compiler's s_waitcnt counters
     //             stay exact: with conditional loads in the loop they degrade to vmcnt(0) before every use);
@@ -246,7 +256,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // columns of ONE pair.  Lanes of a padded last block (idx < 0) multiply row 0 and drop the result.
     float4 bw[2][NF][NBW], a[NF];
     f32x4 g[3][LPT];      // (native vector type: the HIP float4 struct kept this ring in scratch memory)
-    int gix[LPT];                                  // gather row of this thread's chunk(s), block t+4
+    int gix[LPT];                                  // gather row of this thread's chunk(s), block t+3
     int pidx[2], prow[2];                          // (input row, output tile row) of pair r, blocks t / t+1
     const int kf = kflip & 1;
     const int ncb = cout / 16;
@@ -324,7 +334,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     };
 
     if (total > 0) {
-        int d1 = desc(1), d2 = desc(2), d5 = desc(5);
+        int d1 = desc(1), d2 = desc(2), d4 = desc(4);
         {
             const int d0 = desc(0);
             read_gix(d0); issue_G(g[0]);
@@ -332,9 +342,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             read_gix(d2); issue_G(g[2]);
             issue_B(d0, bw[0]);
             store_G(g[0], 0);
-            read_gix(desc(3)); issue_G(g[0]);
-            store_G(g[1], 1);
-            read_gix(desc(4));
+            read_gix(desc(3));
             pidx[0] = s_idx[dbase(d0) + r];
             prow[0] = s_row[dbase(d0) + r];
             __syncthreads();
@@ -343,13 +351,13 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         auto step = [&](auto U, int t) __attribute__((always_inline)) {
             constexpr int u = decltype(U)::value;
                 // -- issue everything later steps need
-            read_frag(u % 3, a);                                     // block t (stored at step t-2, barrier since)
+            read_frag(u & 1, a);                                     // block t (stored at step t-1, barrier since)
             issue_B(d1, bw[(u + 1) & 1]);                            // block t+1
-            issue_G(g[(u + 4) % 3]);                                 // block t+4
-            read_gix(d5);                                            // block t+5
+            issue_G(g[u % 3]);                                       // block t+3 (block t left these registers at step t-1)
+            read_gix(d4);                                            // block t+4
             pidx[(u + 1) & 1] = s_idx[dbase(d1) + r];                // block t+1
             prow[(u + 1) & 1] = s_row[dbase(d1) + r];
-            const int d6 = desc(t + 6);
+            const int d5 = desc(t + 5);
             // -- block t: the old output values first (in flight under the MFMAs), then the products
             const bool live = pidx[u & 1] >= 0;
             float4 *po[NBW];
@@ -395,10 +403,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     *po[n] = o[n];
                 }
             }
-            store_G(g[(u + 2) % 3], (u + 2) % 3);                    // block t+2 (gathered at step t-2)
+            store_G(g[(u + 1) % 3], (u + 1) & 1);                    // block t+1 (gathered at step t-2); the slot was last read at step t-1
             d1 = d2;
             d2 = desc(t + 3);
-            d5 = d6;
+            d4 = d5;
             if (STAMP) ++n_blocks;
             // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. it would drain the gathers and
             // weight fragments in flight for the next steps at every step
@@ -443,7 +451,7 @@ static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const f
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
-    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)3 * 16 * (X3 ? 6 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
+    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * (X3 ? 6 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
                        (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
     hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, X3>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
                        items, n_items, K, kflip, out, stamps);
@@ -519,10 +527,10 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
     if (elems == 0) return 0;
     if (conv_tp_arith(arith) == 2) {
         const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
-        hipLaunchKernelGGL(weight_fragments_x3_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, w, rows, cols,
+        hipLaunchKernelGGL(weight_fragments_x3_kernel, dim3((unsigned)ceil_div(total, 256), transpose == 2 ? 2 : 1), dim3(256), 0, st, w, rows, cols,
                            transpose, reinterpret_cast<bf16x8 *>(wf), total);
     } else {
-        hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, w, rows, cols,
+        hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(elems, 256), transpose == 2 ? 2 : 1), dim3(256), 0, st, w, rows, cols,
                            transpose, wf, elems);
     }
     return check_launch("u2mkd_weight_fragments");

@@ -309,7 +309,9 @@ class TileSchedule:
         # Work items of the tile-pair kernel (u2mkd_conv_forward_tiles): a tile is a SERIAL chain of blocks, so
         # the heaviest tiles (rows with rare neighbour masks: up to 62 blocks against a mean of 16) are cut into
         # halves / quarters; items are listed heaviest first.  item = tile << 4 | sub << 2 | lg.  Built without a
-        # host sync: 7 candidates per tile, the ones not chosen (or without rows) sort to the end.
+        # host sync: 7 candidates per tile, the ones not chosen (or without rows) sort to the end.  (Measured, MI355X:
+        # listing the light items first or in the middle of the launch order instead of last changes nothing --
+        # 39.8-41 us at 64 -> 64 -- the kernel is bound by the per-CU step rate, not by the order.)
         lg = (b1 > _TILE_SPLIT[0]).int() + (b1 > _TILE_SPLIT[1]).int()          # [t] 0 / 1 / 2
         tid = torch.arange(t, dtype=torch.int32, device=dev)
         rows_left = n - tid * 64                                                # rows of the tile that exist
@@ -322,8 +324,9 @@ class TileSchedule:
             cand_code.append(((tid.view(t, 1) << 4) | (sub << 2) | l).reshape(-1))
         w = torch.cat(cand_w)
         srt = torch.argsort(w, descending=True, stable=True)
-        self.items = torch.cat(cand_code)[srt].int().contiguous()
+        items = torch.cat(cand_code)[srt].int()
         self.n_items = (w >= 0).sum().int().view(1)
+        self.items = items.contiguous()
 
     def tiles(self):
         return self.nbr_s, self.order
@@ -551,25 +554,33 @@ def _weight_layout(weight, transpose, fragments):
     """The layout of `kernel` [K, R, C] a conv kernel reads: rows of B_k = output columns, reduction contiguous.
     transpose: B_k[col][red] = weight[k][red][col] (else weight[k][col][red], the tensor as it is).
     fragments: MFMA operand-fragment order (u2mkd_weight_fragments) instead of row-major [K, ncol, nred].
-    For FROZEN weights (requires_grad False: the KD teacher, inference) the result is cached on the tensor
-    together with its in-place version; trained weights are re-laid out per call."""
+    Fragments of BOTH orientations come from one launch (latency-bound: 5 us for one or for two) and are cached
+    on the tensor with its in-place version and storage address, so the forward's launch also serves the input
+    gradient of the same step; row-major layouts are cached for FROZEN weights only (requires_grad False: the KD
+    teacher, inference), trained weights are re-laid out per call."""
     if not transpose and not fragments:
         return weight
     k, r, c = weight.shape
     frozen = not weight.requires_grad
-    key = '_u2mkd_w%d%d' % (int(transpose), int(fragments))
+    stamp = (weight._version, weight.data_ptr())
+    if fragments:
+        hit = weight.__dict__.get('_u2mkd_wfrag')
+        if hit is None or hit[0] != stamp:
+            nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, 0)
+            both = torch.empty(2, nbytes, dtype=torch.uint8, device=weight.device)
+            L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, 2, 0, L.ptr(both), L.stream())
+            hit = (stamp, both)
+            weight.__dict__['_u2mkd_wfrag'] = hit
+        return hit[1][0 if transpose else 1]
+    key = '_u2mkd_wt'
     if frozen:
         hit = weight.__dict__.get(key)
-        if hit is not None and hit[0] == weight._version:
+        if hit is not None and hit[0] == stamp:
             return hit[1]
-    if fragments:
-        out = torch.empty(L.load().u2mkd_weight_fragments_bytes(k, r, c, 0), dtype=torch.uint8, device=weight.device)
-        L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, int(transpose), 0, L.ptr(out), L.stream())
-    else:
-        out = torch.empty(k, c, r, dtype=torch.float32, device=weight.device)
-        L.call('u2mkd_transpose_weights', L.ptr(weight), k, r, c, L.ptr(out), L.stream())
+    out = torch.empty(k, c, r, dtype=torch.float32, device=weight.device)
+    L.call('u2mkd_transpose_weights', L.ptr(weight), k, r, c, L.ptr(out), L.stream())
     if frozen:
-        weight.__dict__[key] = (weight._version, out)
+        weight.__dict__[key] = (stamp, out)
     return out
 
 
