@@ -171,6 +171,17 @@ int u2mkd_debug_wgrad_stamps(const float *a, const float *b, const int32_t *pair
 int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const float *wt, int32_t cout,
                              const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
                              int32_t k, int32_t kc, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
+/* The same product in bf16x3 arithmetic (csrc/conv_px3.hip) for cin, cout multiples of 32
+ * (u2mkd_conv_pairs_x3_supported; 0 when U2MKD_CONV_ARITH=f32): wf = the arith-2 FRAGMENT layout of
+ * u2mkd_weight_fragments (forward: transpose = 1; input gradient / transposed roles: transpose = 0).  A workgroup
+ * multiplies 64 pairs by 96 / 128 output columns, the gathered rows are split into their three bf16 planes once
+ * per workgroup (LDS image) and every weight fragment is used for 4 row blocks from registers: fp32 GEMM accuracy
+ * at 2.7x fewer matrix-pipe cycles than the f32-MFMA kernel above.  The y rows of padding entries are NOT written
+ * (u2mkd_pairs_gather_sum never reads them).                                                                    */
+int32_t u2mkd_conv_pairs_x3_supported(int32_t cin, int32_t cout);
+int u2mkd_conv_forward_pairs_x3(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                int32_t k, float *y /*[capacity,cout]*/, u2mkd_stream_t s);
 /* y = x * w^T (+ bias): nn.Linear on the rows of a feature matrix (the point-branch MLPs of
  * core/models/semantickitti/spvcnn.py:58-74 and the 1x1x1 convs of ResidualBlock.downsample,
  * build_blocks.py:69-72), on the pair kernel's pipeline with the identity schedule.  w is

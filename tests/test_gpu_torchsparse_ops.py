@@ -221,6 +221,20 @@ def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
     gi_p = torch.empty(n_in, cin, device='cuda')
     ps.run(g.cuda(), w.cuda().contiguous(), cin, not transposed, gi_p)
     assert _rel(gi_p, wgi) < 1e-4
+    # the bf16x3 pair kernel (csrc/conv_px3.hip, what the wide layers run by default): same gates, both roles,
+    # bitwise reproducible; NaN-prefilled scratch shows that every y row the gather-sum reads is written
+    if L.load().u2mkd_conv_pairs_x3_supported(cin, cout):
+        buf = F._scratch(ps.cap * max(cin, cout) * 4, torch.device('cuda', torch.cuda.current_device()))
+        buf[:buf.numel() // 4 * 4].view(torch.float32).fill_(float('nan'))
+        o_x = torch.full((n_out, cout), float('nan'), device='cuda')
+        ps.run(x.cuda(), F._weight_layout(w.cuda(), True, True), cout, transposed, o_x, fragments=True)
+        assert _rel(o_x, want) < 1e-4 and float((o_x - o_p).abs().max()) < 1e-4
+        gi_x = torch.full((n_in, cin), float('nan'), device='cuda')
+        ps.run(g.cuda(), F._weight_layout(w.cuda(), False, True), cin, not transposed, gi_x, fragments=True)
+        assert _rel(gi_x, wgi) < 1e-4
+        again = torch.empty_like(gi_x)
+        ps.run(g.cuda(), F._weight_layout(w.cuda(), False, True), cin, not transposed, again, fragments=True)
+        assert torch.equal(gi_x, again)
     gi_t = torch.empty(n_in, cin, device='cuda')
     if kind == 'subm':
         ts_.run(g.cuda(), w.cuda().contiguous(), False, cin, 1, gi_t)   # mirrored offsets on the same table

@@ -1058,6 +1058,23 @@ int u2mkd_conv_forward_pairs(const float *in, int64_t n_in, int32_t cin, const f
     return check_launch("u2mkd_conv_forward_pairs");
 }
 
+int32_t u2mkd_conv_pairs_x3_supported(int32_t cin, int32_t cout) {
+    return (conv_px3_supported(cin, cout) && conv_tp_arith(0) == 2) ? 1 : 0;
+}
+
+int u2mkd_conv_forward_pairs_x3(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                 const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                 int32_t k, float *y, u2mkd_stream_t s) {
+    if (capacity == 0) return 0;
+    U2_REQUIRE(in && wf && pair_idx && tile_k && meta && y, "u2mkd_conv_forward_pairs_x3: null pointer");
+    U2_REQUIRE(k > 0 && n_in > 0 && capacity % 64 == 0, "u2mkd_conv_forward_pairs_x3: the capacity must be a multiple of 64");
+    int rc = launch_conv_px3("u2mkd_conv_forward_pairs_x3", in, cin, reinterpret_cast<const float *>(wf), cout, pair_idx,
+                             tile_k, meta + 1, capacity, y, as_stream(s));
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_pairs_x3: cin=%d and cout=%d must be multiples of 32 "
+               "(ask u2mkd_conv_pairs_x3_supported first)", cin, cout);
+    return rc;
+}
+
 int u2mkd_linear_forward(const float *x, int64_t n, int32_t cin, const float *w, int32_t cout, const float *bias,
                          int32_t variant, float *y, u2mkd_stream_t s) {
     if (n == 0) return 0;

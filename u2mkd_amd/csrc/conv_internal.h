@@ -23,4 +23,9 @@ int conv_tp_arith(int arith);
 size_t weight_fragments_bytes(int k, int rows, int cols, int arith);
 int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st);
 
+// Global pair schedule in bf16x3 arithmetic (conv_px3.hip); wf = arith-2 fragments.  -1 = shape not supported.
+bool conv_px3_supported(int cin, int cout);
+int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st);
+
 }  // namespace u2mkd

@@ -1,0 +1,241 @@
+// Sparse conv forward / input gradient of the WIDE layers: the global pair schedule in bf16x3 arithmetic
+// (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+// Replaces torchsparse v1.4.0 convolution_forward_cuda / the dX half of convolution_backward_cuda
+// (gather -> cuBLAS mm -> scatter-add per kernel offset) behind the spnn.Conv3d
+// calls of core/models/build_blocks.py:25-80 for layers with cin * cout >= 8192 (the 96..768-channel
+// stages of SPVCNN cr 1.0 / 2.0), on the pair schedule of u2mkd_pairs_build: every 64-pair tile of the
+// offset-grouped pair list is ONE dense [64 x cin] x [cin x cout] product into the scratch rows y.
+//
+// conv_pairs_kernel (conv.hip) does this product on v_mfma_f32_16x16x4_f32 with every wave gathering its own
+// 16 pairs straight into operand registers: matrix-pipe bound at ~80 TF (256 x 256), half of the fp32 MFMA
+// peak.  Here the product runs in the bf16x3 arithmetic of conv_tp.hip (each fp32 operand split exactly into
+// three bf16, the six partial products above 2^-24 relative accumulated in fp32: fp32 GEMM accuracy at 2.7x
+// fewer matrix-pipe cycles), organised so that the run-time split of the gathered rows is paid ONCE per
+// workgroup and amortised over all of its output columns:
+//   * a workgroup (NW waves) owns 64 pairs x 16*NW*NBW output columns; the waves split the COLUMNS, every
+//     wave multiplies all 64 pairs (4 row blocks) by its NBW column blocks: 4*NBW accumulators, 24*NBW MFMAs
+//     per 32-channel step, each weight fragment used 4 times from registers;
+//   * the 64 gathered rows of a step (32 channels = one full 128-byte line per row, 8 lanes per row) are
+//     split into the h | m | l planes at the LDS store and read back as ready MFMA operand fragments
+//     (ds_read_b128, conflict-free: row stride 208 B);
+//   * weights come in the MFMA-fragment order of u2mkd_weight_fragments (arith = 2), 1 KiB contiguous per
+//     wave load instruction, straight from L2 into registers;
+//   * (tile, 32-channel step) pairs form ONE software pipeline over the workgroup's contiguous run of tiles:
+//     gather of step i+2 and weight fragments of step i+1 in flight while step i multiplies, rows of step i+1
+//     stored into the other LDS image, one LDS-only barrier per step; all loads in the loop are unconditional
+//     so the compiler's s_waitcnt counters stay exact.
+// Results differ from the f32-MFMA kernel by fp32 rounding only (tests hold both to the same gates).
+#include <type_traits>
+
+#include "conv_internal.h"
+
+namespace u2mkd {
+
+typedef __bf16 px_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 px_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void px_split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    float r1 = x - (float)h;
+    m = (__bf16)r1;
+    float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+__device__ __forceinline__ px_bf16x8 px_bf8(const float4 &x) {
+    f32x4 v = (f32x4){x.x, x.y, x.z, x.w};
+    return __builtin_bit_cast(px_bf16x8, v);
+}
+
+template <int NW, int NBW>
+__global__ void __launch_bounds__(64 * NW)
+conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wf, int cout,
+                const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
+                const int32_t *__restrict__ n_tiles, float *__restrict__ y) {
+    constexpr int NT = 64 * NW, TN = 16 * NW * NBW;
+    constexpr int RS = 208;                       // bytes per row of the LDS image: 3 planes x 32 bf16 + 16 pad
+    constexpr int LPT = (512 + NT - 1) / NT;      // 16-byte chunks a thread gathers per step (64 rows x 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int ntile = *n_tiles;
+    const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntile);
+    if (t0 >= t1) return;
+    const int ns = cin / 32;
+    const int nsteps = (t1 - t0) * ns;
+    const int ncb = cout / 16;
+    const int cbw = blockIdx.y * (TN / 16) + NBW * wave;      // this wave's first column block
+
+    // chunk e of a step: row e >> 3 of the tile, 16-byte chunk e & 7 of the row's 128-byte line
+    int crow[LPT], cch[LPT];
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+        const int e = min(tid + l * NT, 511);
+        crow[l] = e >> 3;
+        cch[l] = e & 7;
+    }
+
+    f32x4 acc[4][NBW];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[b][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 bw[2][3 * NBW];
+    f32x4 g[2][LPT];
+    int gix[LPT];        // pair entries of the tile the NEXT gather reads
+    int kw;              // offset of the tile the NEXT weight issue reads
+
+    auto load_idx = [&](int t, int (&ix)[LPT]) __attribute__((always_inline)) {
+        const int tt = min(t, t1 - 1);
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) ix[l] = pair_idx[(size_t)tt * 64 + crow[l]];
+    };
+    auto issue_G = [&](const int (&ix)[LPT], int s, f32x4 (&gg)[LPT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            const int row = ix[l] >= 0 ? ix[l] : 0;       // padding entries multiply row 0; their y rows are never read
+            gg[l] = *reinterpret_cast<const f32x4 *>(in + (size_t)row * cin + 32 * s + 4 * cch[l]);
+        }
+    };
+    auto issue_B = [&](int k, int s, float4 (&bb)[3 * NBW]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+            const int cb = min(cbw + n, ncb - 1);         // column blocks past cout: computed, never stored
+            const float *pb = wf + ((((size_t)k * ncb + cb) * ns + s) * 3 * 64 + lane) * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bb[3 * n + p] = *reinterpret_cast<const float4 *>(pb + p * 256);
+        }
+    };
+    auto store_G = [&](const f32x4 (&gg)[LPT], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < LPT; ++l) {
+            if (tid + l * NT < 512) {
+                px_bf16x4 h, m, lo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    __bf16 hh, mm, ll;
+                    px_split3(gg[l][c], hh, mm, ll);
+                    h[c] = hh; m[c] = mm; lo[c] = ll;
+                }
+                char *row = smem + (slot * 64 + crow[l]) * RS + 8 * cch[l];
+                *reinterpret_cast<px_bf16x4 *>(row) = h;
+                *reinterpret_cast<px_bf16x4 *>(row + 64) = m;
+                *reinterpret_cast<px_bf16x4 *>(row + 128) = lo;
+            }
+        }
+    };
+    auto read_frag = [&](int slot, int rb, float4 (&aa)[3]) __attribute__((always_inline)) {
+        const char *row = smem + (slot * 64 + 16 * rb + r) * RS + 16 * q;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
+    };
+    auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto tile_offset = [&](int t) __attribute__((always_inline)) { return tile_k[min(t, t1 - 1)]; };
+
+    // positions (tile, step) of flattened step i + d; advance = next 32-channel step, then next tile
+    int tc = t0, sc = 0;                 // step i   (multiplied)
+    int tw = t0, sw = 0;                 // step i+1 (weights issued)
+    int tg = t0, sg = 0;                 // step i+2 (rows gathered)
+    auto adv = [&](int &t, int &s) __attribute__((always_inline)) {
+        if (++s == ns) { s = 0; ++t; }
+    };
+
+    // ---- prologue: rows of steps 0 and 1 in flight, step 0 stored, weights of step 0 in registers
+    {
+        int ix0[LPT];
+        load_idx(tg, ix0);
+        issue_G(ix0, sg, g[0]);
+        issue_B(tile_offset(tw), sw, bw[0]);
+        adv(tg, sg);
+        adv(tw, sw);
+        load_idx(tg, ix0);
+        issue_G(ix0, sg, g[1]);
+        adv(tg, sg);
+        load_idx(tg, gix);               // tile of step 2
+        kw = tile_offset(tw);            // tile of step 1
+        store_G(g[0], 0);
+        lds_barrier();
+    }
+
+    auto step = [&](auto U, int i) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;      // i mod 2: ring positions are static register names
+        // -- issue what later steps need (all unconditional)
+        const int kcur = __builtin_amdgcn_readfirstlane(kw);
+        issue_B(kcur, sw, bw[u ^ 1]);              // weights of step i+1
+        issue_G(gix, sg, g[u]);                    // rows of step i+2 (the rows of step i left g[u] at step i-1)
+        adv(tw, sw);
+        adv(tg, sg);
+        kw = tile_offset(tw);                      // step i+2's tile
+        load_idx(tg, gix);                         // step i+3's tile
+        // -- multiply step i from LDS image u
+        float4 a[2][3];
+        read_frag(u, 0, a[0]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            if (rb < 3) read_frag(u, rb + 1, a[(rb + 1) & 1]);
+            const px_bf16x8 xh = px_bf8(a[rb & 1][0]), xm = px_bf8(a[rb & 1][1]), xl = px_bf8(a[rb & 1][2]);
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                const px_bf16x8 wh = px_bf8(bw[u][3 * n]), wm = px_bf8(bw[u][3 * n + 1]), wl = px_bf8(bw[u][3 * n + 2]);
+                // the six partial products, low order first; weights = A operand: D[col][pair]
+                f32x4 c = acc[rb][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                acc[rb][n] = c;
+            }
+        }
+        // -- last channel step of a tile: lane (r, q) holds columns 4q .. 4q+3 of pair r of every row block
+        if (sc + 1 == ns) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    const int col = 16 * (cbw + n) + 4 * q;
+                    if (cbw + n < ncb)
+                        *reinterpret_cast<f32x4 *>(y + ((size_t)tc * 64 + 16 * rb + r) * cout + col) = acc[rb][n];
+                    acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        adv(tc, sc);
+        // -- rows of step i+1 (gathered at step i-1) into the other image (last read at step i-1, a barrier ago)
+        store_G(g[u ^ 1], u ^ 1);
+        (void)i;
+        lds_barrier();
+    };
+    for (int i = 0; i < nsteps; i += 2) {
+        step(std::integral_constant<int, 0>{}, i);
+        if (i + 1 >= nsteps) break;
+        step(std::integral_constant<int, 1>{}, i + 1);
+    }
+}
+
+// (cin, cout) the kernel takes: whole 32-channel steps and fragment-layout weights (multiples of 32)
+bool conv_px3_supported(int cin, int cout) { return cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0; }
+
+int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st) {
+    if (!conv_px3_supported(cin, cout)) return -1;
+    // column tiles: 128 (4 waves x 2 blocks) or 96 (3 waves x 2 blocks: 96- and 192-column layers exactly)
+    const bool w3 = cout % 96 == 0 && cout % 128 != 0;
+    const int tn = w3 ? 96 : 128;
+    int64_t gx = capacity / 64;
+    const int64_t cap_x = 3 * 256;            // 3 workgroups per CU, each a contiguous run of tiles
+    const int gy = (int)ceil_div(cout, tn);
+    if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
+    if (gx < 1) gx = 1;
+    const size_t lds = (size_t)2 * 64 * 208;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    if (w3)
+        hipLaunchKernelGGL((conv_px3_kernel<3, 2>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
+    else
+        hipLaunchKernelGGL((conv_px3_kernel<4, 2>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
+    return check_launch(who);
+}
+
+}  // namespace u2mkd

@@ -8,6 +8,8 @@ the reference reads from the global torchpack ``configs`` are explicit arguments
 Module / parameter names equal the reference's (checkpoint compatible)."""
 from copy import deepcopy
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -201,11 +203,53 @@ class TSDFull(nn.Module):
             PointLinear(self.model_s.cs[4], self.model_t.cs[4]), PointBatchNorm1d(self.model_t.cs[4]), nn.ReLU(True))
 
     def forward(self, in_mod: dict):
+        """tsd_full.py:582-596.  The frozen teacher's forward is independent of the student's until the KD losses,
+        so (training, on the GPU) it runs on a side HIP stream underneath the student's forward: both are long
+        chains of kernels that rarely fill all 256 CUs on their own.  The side stream is ordered after everything
+        queued so far (the teacher's inputs) and the main stream waits for it before the outputs are used;
+        U2MKD_TEACHER_STREAM=0 runs the reference's sequential order."""
+        want_t = self.training or self.debug_val
+        side = _teacher_stream(in_mod['teacher']['lidar'].F) if want_t and _TEACHER_STREAM else None
+        if side is None:
+            ret = {'stu': self.model_s(in_mod['student'])}
+            if want_t:
+                with torch.no_grad():
+                    ret['t'] = self.model_t(in_mod['teacher'])
+            return ret
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            t = self.model_t(in_mod['teacher'])
         ret = {'stu': self.model_s(in_mod['student'])}
-        if self.training or self.debug_val:
-            with torch.no_grad():
-                ret['t'] = self.model_t(in_mod['teacher'])
+        main.wait_stream(side)
+        for v in _tensors(t):
+            v.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
+        ret['t'] = t
         return ret
+
+
+_TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
+_SIDE = {}
+
+
+def _teacher_stream(ref):
+    if not ref.is_cuda:
+        return None
+    key = ref.device.index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=ref.device)
+    return _SIDE[key]
+
+
+def _tensors(o):
+    if torch.is_tensor(o):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _tensors(v)
+    elif isinstance(o, (list, tuple)):
+        for v in o:
+            yield from _tensors(v)
 
 
 def teacher_to_student(x_t, inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full=None):

@@ -258,6 +258,9 @@ def _pairs_mode(cin, cout):
     return cin * cout >= 8192 and cout % 4 == 0
 
 
+# wide layers on the bf16x3 pair kernel (csrc/conv_px3.hip); U2MKD_PAIRS_X3=0 keeps them on the f32-MFMA pair kernel
+_PAIRS_X3 = os.environ.get('U2MKD_PAIRS_X3', '1') != '0'
+
 _SCRATCH = {}
 
 
@@ -380,18 +383,22 @@ class PairSchedule:
                    L.ptr(self.tile_k), L.ptr(self.meta), st)
         self.nbsizes = nbsizes
 
-    def run(self, feats, wt, cout, swap, out, variant=0):
+    def run(self, feats, wt, cout, swap, out, variant=0, fragments=False):
         """swap = False: out[j] = sum_k feats[in_k(j)] @ B_k  (rows of out = the map's outputs)
         swap = True:  out[i] = sum_k feats[out_k(i)] @ B_k (rows of out = the map's inputs);
-        B_k = wt[k] as [cout][cin]."""
+        B_k = wt[k] as [cout][cin], or (fragments) the arith-2 fragment layout of it for the bf16x3 kernel."""
         n, cin = feats.shape
         st = L.stream()
         idx, pos, n_rows = (self.pair_out, self.pos_in, self.n_in) if swap else (self.pair_in, self.pos_out, self.n_out)
         if n_rows == 0:
             return out
         y = _scratch(self.cap * cout * 4, feats.device)
-        L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
-               L.ptr(self.meta), self.cap, self.k, variant, L.ptr(y), st)
+        if fragments:
+            L.call('u2mkd_conv_forward_pairs_x3', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
+                   L.ptr(self.meta), self.cap, self.k, L.ptr(y), st)
+        else:
+            L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
+                   L.ptr(self.meta), self.cap, self.k, variant, L.ptr(y), st)
         L.call('u2mkd_pairs_gather_sum', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
         return out
 
@@ -541,8 +548,9 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
     pair schedule that is simply the swapped-role walk."""
     out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
     if _pairs_mode(feats.shape[1], cout):
-        wt = _weight_layout(weight, transpose, False)
-        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
+        x3 = _PAIRS_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(feats.shape[1], cout))
+        wt = _weight_layout(weight, transpose, x3)
+        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3)
     if inverse and kmap.nbr_inv is None:      # symmetric map: the inverse table is the mirrored forward table
         inverse, kflip = False, 1 - int(kflip)
     sch = kmap.schedule(inverse)
