@@ -89,6 +89,11 @@ int u2mkd_pairs_build(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int64_t n
  * replaces the arithmetic of F.spdownsample (Appendix A-4).                 */
 int u2mkd_downsample_keys(const int32_t *coords /*[n,4]*/, int64_t n, int32_t sx, int32_t sy, int32_t sz,
                           int64_t *keys /*[n]*/, u2mkd_stream_t s);
+/* The packed key holds x, y, z in [-131072, 131072) and b in [0, 512).  A row outside that range cannot be packed
+ * (torch.unique(dim=0) of the reference has no such limit): it gets the key INT64_MAX and *range_flag (device int32,
+ * caller-zeroed, may be NULL) is set to 1, so the caller can raise instead of merging voxels silently.            */
+int u2mkd_downsample_keys_checked(const int32_t *coords /*[n,4]*/, int64_t n, int32_t sx, int32_t sy, int32_t sz,
+                                  int64_t *keys /*[n]*/, int32_t *range_flag, u2mkd_stream_t s);
 int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords /*[n,4]*/, u2mkd_stream_t s);
 
 /* ---- sparse convolution ------------------------------------------------
@@ -195,6 +200,19 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, in
 /* neighbour mask of every output row: bit k set iff nbr[k][j] >= 0 (k <= 32). */
 int u2mkd_kmap_rowmask(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t *mask /*[n_out]*/,
                        u2mkd_stream_t s);
+/* The TILE SCHEDULE of a (mask-sorted) neighbour table, built on the device (csrc/schedule.hip): `mask` = the
+ * rows' neighbour masks (u2mkd_kmap_rowmask), `order` = the row permutation that sorts them (NULL: identity);
+ * a tile = 64 consecutive sorted rows, its weight = its 16-pair MFMA blocks (sum over offsets of ceil(pairs / 16)).
+ *   tile_order [ceil(n/64)]   tiles by descending weight (stable)                (offset-walking kernels)
+ *   items [7 ceil(n/64)]      work items of u2mkd_conv_forward_tiles, heaviest first: tile << 4 | sub << 2 | lg,
+ *                             a tile above split0 blocks as 2 halves, above split1 as 4 quarters; the first
+ *                             *n_items entries are live (the count never leaves the device)
+ * workspace: u2mkd_tile_schedule_workspace_bytes(n_rows).  Belongs to the kernel-map cache (torchsparse keeps
+ * nbmaps / nbsizes per (stride, kernel) key, core/models/utils.py:60-61).                                     */
+size_t u2mkd_tile_schedule_workspace_bytes(int64_t n_rows);
+int u2mkd_tile_schedule(const int32_t *mask /*[n_rows]*/, const int32_t *order /*[n_rows] or NULL*/, int64_t n_rows,
+                        int32_t k, int32_t split0, int32_t split1, void *workspace, int32_t *tile_order,
+                        int32_t *items, int32_t *n_items, u2mkd_stream_t s);
 /* dW[k] = sum over the pairs (i, j) of offset k of A_i^T B_j  (the dW half of torchsparse
  * convolution_backward_cuda), over the compacted pair list (the rulebook of u2mkd_kmap_compact; the
  * buffer may be over-allocated, only plan[0] = P pairs are read).  u2mkd_wgrad_plan turns

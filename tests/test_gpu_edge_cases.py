@@ -126,3 +126,18 @@ def test_spvcnn_step_on_a_tiny_scene(hip):
     l0 = float(run(feats, coords, labels))
     l1 = float(run(feats, coords, labels))
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+@pytest.mark.parametrize('bad', [(131072, 0, 0, 0), (0, -131073, 0, 0), (0, 0, 0, 512), (0, 0, 0, -1)])
+def test_downsample_rejects_coordinates_outside_the_key_range(F, bad):
+    """torch.unique(dim=0) of the reference has no coordinate limit; the packed int64 key has (18 bits per axis,
+    10 for the batch index).  A row outside it must raise, not merge silently into another voxel; rows at the
+    limits themselves are exact."""
+    ok = np.array([[131070, -131072, 6, 0], [2, 4, 6, 511], [0, 0, 0, 0], [1, 1, 1, 0]], np.int32)
+    out = F.spdownsample(_dev(ok), 2, 2, 1).cpu().numpy()
+    want = R.spdownsample(ok, 2, 2, 1)
+    assert np.array_equal(out, want)
+    with pytest.raises(ValueError):
+        F.spdownsample(_dev(np.concatenate([ok, np.array([bad], np.int32)])), 2, 2, 1)
+    out = F.spdownsample(_dev(ok), 2, 2, 1).cpu().numpy()          # the flag was cleared
+    assert np.array_equal(out, want)

@@ -452,3 +452,66 @@ def test_conv3d_accepts_any_channel_count(hip, cin, cout):
     out.backward(g.cuda())
     assert xd.grad.shape == x.shape and _rel(xd.grad, wgi) < 1e-4
     assert wd.grad.shape == w.shape and _rel(wd.grad, wgw) < 1e-4
+
+
+def _tile_schedule_torch(ms_sorted, n, k, split):
+    """The torch formulation csrc/schedule.hip replaced: block counts from bit planes, stable argsorts."""
+    dev = ms_sorted.device
+    t = (n + 63) // 64
+    ms = torch.zeros(t * 64, dtype=torch.int32, device=dev)
+    ms[:n] = ms_sorted
+    bits = (ms.view(t, 4, 16, 1) >> torch.arange(k, dtype=torch.int32, device=dev)) & 1
+    c16 = bits.sum(2)
+    b4 = ((c16 + 15) >> 4).sum(2)
+    b2 = ((c16.view(t, 2, 2, k).sum(2) + 15) >> 4).sum(2)
+    b1 = ((c16.sum(1) + 15) >> 4).sum(1)
+    tile_order = torch.argsort(b1, descending=True, stable=True).int()
+    lg = (b1 > split[0]).int() + (b1 > split[1]).int()
+    tid = torch.arange(t, dtype=torch.int32, device=dev)
+    rows_left = n - tid * 64
+    cand_w, cand_code = [], []
+    for l, bl in ((0, b1.view(t, 1)), (1, b2), (2, b4)):
+        nsub = 1 << l
+        sub = torch.arange(nsub, dtype=torch.int32, device=dev).view(1, nsub)
+        live = (lg.view(t, 1) == l) & (sub * (64 >> l) < rows_left.view(t, 1))
+        cand_w.append(torch.where(live, bl.int(), -1).reshape(-1))
+        cand_code.append(((tid.view(t, 1) << 4) | (sub << 2) | l).reshape(-1))
+    w = torch.cat(cand_w)
+    srt = torch.argsort(w, descending=True, stable=True)
+    return tile_order, torch.cat(cand_code)[srt].int(), int((w >= 0).sum())
+
+
+@pytest.mark.parametrize('n,stride', [(80000, 1), (30000, 1), (5000, 4), (63, 1), (64, 1), (65, 1), (1, 1)])
+def test_tile_schedule_kernels_match_the_torch_formulation(F, n, stride):
+    """u2mkd_tile_schedule (two launches) gives the tile order, the work items and the live-item count of the
+    stable-argsort formulation bit for bit, at the bench size, on a strided level and on ragged tails; every
+    row is covered by exactly one live item."""
+    from u2mkd_amd.synth import synth_batch
+    coords = synth_batch(n, 1, seed=5)['coords']
+    ts = 1
+    while ts < stride:
+        coords = R.spdownsample(coords, 2, 2, ts)
+        ts *= 2
+    km = F.build_kmap(_dev(coords), (ts,) * 3, (3,) * 3, (1,) * 3)
+    sch = km.schedule(False)
+    nn_, k = km.n_out, 27
+    mask = torch.zeros(nn_, dtype=torch.int32, device='cuda')
+    for kk in range(k):
+        mask |= (km.nbr[kk] >= 0).int() << kk
+    ms = mask[sch.order.long()]
+    assert bool((ms[1:] >= ms[:-1]).all())
+    want_order, want_items, want_n = _tile_schedule_torch(ms, nn_, k, F._TILE_SPLIT)
+    got_n = int(sch.n_items.item())
+    assert got_n == want_n
+    assert torch.equal(sch.tile_order, want_order)
+    assert torch.equal(sch.items[:got_n], want_items[:got_n])
+    it = sch.items[:got_n].long()
+    tile, sub, lg = it >> 4, (it >> 2) & 3, it & 3
+    rows = 64 >> lg
+    first = tile * 64 + sub * rows
+    cover = torch.zeros(nn_ + 64, dtype=torch.int32, device='cuda')
+    for r in (16, 32, 64):
+        sel = first[rows == r]
+        idx = (sel.view(-1, 1) + torch.arange(r, device='cuda').view(1, -1)).reshape(-1)
+        cover.index_add_(0, idx, torch.ones_like(idx, dtype=torch.int32))
+    assert bool((cover[:nn_] == 1).all())

@@ -30,6 +30,7 @@ SIGNATURES = {
     'u2mkd_kmap_sizes': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     'u2mkd_kmap_compact': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     'u2mkd_downsample_keys': (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_downsample_keys_checked': (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
@@ -49,6 +50,8 @@ SIGNATURES = {
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_kmap_rowmask': (C.c_int, [_p, _i64, _i32, _p, _p]),
+    'u2mkd_tile_schedule_workspace_bytes': (_sz, [_i64]),
+    'u2mkd_tile_schedule': (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_wgrad_plan_ints': (_i32, [_i32]),
     'u2mkd_wgrad_plan': (C.c_int, [_p, _i32, _i64, _p, _p]),
     'u2mkd_conv_wgrad_pairs_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),

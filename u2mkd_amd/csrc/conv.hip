@@ -455,12 +455,25 @@ conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__rest
 
     const int w = blockIdx.x;
     const int *wg = plan + 3 + K;
-    if (w >= wg[K]) return;
-    int k = 0;
-    while (w >= wg[k + 1]) ++k;
+    // this workgroup's (offset, chunk): ONE round trip -- lane l holds wg[l] and kofs[l], the offset is the number of
+    // prefix entries <= w (a serial scan of the prefix costs up to K dependent loads before the first pair index
+    // can be fetched: ~2 us at the head of every workgroup)
+    int k = 0, p_begin, p_end;
     const int ch = plan[1];
-    const int p_begin = plan[2 + k] + (w - wg[k]) * ch;
-    const int p_end = min(p_begin + ch, plan[2 + k + 1]);
+    if (K <= 63) {
+        const int l = min((int)(threadIdx.x & 63), K);
+        const int wgv = wg[l], kof = plan[2 + l];
+        const unsigned long long le = __ballot(wgv <= w) & ((2ULL << K) - 2ULL);      // lanes 1..K
+        k = __builtin_amdgcn_readfirstlane(__popcll(le));
+        if (k >= K) return;                                  // w >= wg[K]: surplus workgroup
+        p_begin = __builtin_amdgcn_readlane(kof, k) + (w - __builtin_amdgcn_readlane(wgv, k)) * ch;
+        p_end = min(p_begin + ch, __builtin_amdgcn_readlane(kof, k + 1));
+    } else {
+        if (w >= wg[K]) return;
+        while (w >= wg[k + 1]) ++k;
+        p_begin = plan[2 + k] + (w - wg[k]) * ch;
+        p_end = min(p_begin + ch, plan[2 + k + 1]);
+    }
 
     const int ta = blockIdx.y / tiles_b, tb = blockIdx.y % tiles_b;
     const int a0 = ta * TA, b0 = tb * TB;
@@ -634,9 +647,17 @@ wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__rest
     const int w0 = wg[k], w1 = wg[k + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < tile_elems) {
-        for (int w = w0 + g; w < w1; w += 16) {
-            float4 v = *reinterpret_cast<const float4 *>(slabs + (size_t)w * tile_elems + e);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        // four slab rows in flight per thread (the loads do not depend on the running sum; the order of the
+        // additions is fixed: slabs w0+g, +16, +32, ... as before)
+        for (int w = w0 + g; w < w1; w += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ww = w + 16 * i;
+                v[i] = ww < w1 ? *reinterpret_cast<const float4 *>(slabs + (size_t)ww * tile_elems + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
         }
     }
     part[g][lx] = acc;

@@ -136,11 +136,11 @@ __device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NW, int NBW, int CIN, bool STAMP, bool X3>
-__global__ void __launch_bounds__(64 * NW)
+template <int NW, int NBW, int CIN, bool STAMP, bool X3, bool SB = true>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((CIN * NBW <= 64 && (NW >= 3 || CIN <= 32)) ? 4 : 1)))
 conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int cout, const int32_t *__restrict__ nbr,
                const int32_t *__restrict__ order, RowRange rr_, const int32_t *__restrict__ items,
-               const int32_t *__restrict__ n_items_dev, int K, int kflip, float *__restrict__ out,
+               const int32_t *__restrict__ n_items_dev, int n_tiles, int K, int kflip, float *__restrict__ out,
                unsigned long long *__restrict__ stamps) {
     // STAMP (tools/stamps_tp.py only): per workgroup {realtime start, cycles start, after compaction, after the block
     // walk, end, realtime end, blocks, tile}; the product instantiation has none of it
@@ -164,18 +164,36 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     int *s_blk = s_rid + T;                                                   // [4K + 8] block descriptors
     unsigned char *s_row = reinterpret_cast<unsigned char *>(s_blk + 4 * K + 8);   // [K+1][T] tile row of each entry
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
     const int col0 = blockIdx.y * TN;
     const int64_t n_out = rr_.end, ld = rr_.ld;
     // Work items: a 64-row tile or, for tiles with many blocks, a half / a quarter of one (a tile is a serial
     // chain of blocks: the heaviest tiles would set the kernel time).  item = tile << 4 | sub << 2 | lg with
-    // 64 >> lg rows starting at row 64 tile + (64 >> lg) sub, listed heaviest first, one workgroup per item; the
-    // grid is sized by the host-known upper bound, surplus workgroups leave at once.
-    if (items && (int)blockIdx.x >= *n_items_dev) return;
-    const int code = items ? items[blockIdx.x] : ((int)blockIdx.x << 4);
+    // 64 >> lg rows starting at row 64 tile + (64 >> lg) sub, listed heaviest first.
+    // The grid is at most ONE resident wave of workgroups (launch_conv_tp: workgroups per CU x CUs); with more
+    // items than workgroups a workgroup takes several, dealt boustrophedon over the heaviest-first list (round r
+    // gives workgroup b item r G + b, or r G + G-1-b when r is odd), and runs its LIGHTEST item first.  Measured
+    // with one workgroup per item (MI355X, 64 -> 64, 80k voxels, 1415 items on 1024 slots): the 1024 resident
+    // items all end at 25-30 us whatever their block count (the CU's issue slots go oldest wave first: 1.6k
+    // cycles per block for the heaviest item of a CU, 4.8k for the lightest, 600 cycles per block per CU in
+    // total), and the 391 light items (<= 4 blocks) then run as a second wave that is pure latency -- 3 us of
+    // set-up + 5 us of pipeline fill each on a nearly empty chip: 9 of the kernel's 38 us.  A light item at the
+    // START of a young workgroup costs nothing: it waits for memory while the older workgroups use the CU.
+    const int n_it = items ? *n_items_dev : n_tiles;
+    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+#pragma nounroll
+    for (int rd = (n_it + G - 1) / G - 1; rd >= 0; --rd) {
+    const int it = rd * G + ((rd & 1) ? G - 1 - wg : wg);
+    if (it >= n_it) continue;
+    // the lane index is re-derived behind an opaque asm in every round: otherwise the compiler hoists every
+    // lane-dependent address out of the item loop and keeps it live (180 VGPRs instead of 118: 2 waves per SIMD)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int code = items ? items[it] : (it << 4);
     const int R = T >> (code & 3);                        // rows of this item
     const int64_t row0 = rr_.begin + (int64_t)(code >> 4) * T + ((code >> 2) & 3) * R;
+    if (STAMP) { t_rt0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_amdgcn_s_memtime(); n_blocks = 0; }
 
     // ---- 1. neighbour indices of the tile (one burst of independent loads), compaction per offset
     int v[KPW];
@@ -254,7 +272,11 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // MFMAs + one barrier (in-kernel stamps of the straightforward order: 2.0k cycles per step, 0.5k of them MFMA).
     // The MFMA computes D^T = B_k (A operand) x rows^T (B operand): a lane ends up with 4 consecutive output
     // columns of ONE pair.  Lanes of a padded last block (idx < 0) multiply row 0 and drop the result.
-    float4 bw[2][NF][NBW], a[NF];
+    // weight fragments: two register sets filled one step ahead (every step re-loads, also an unchanged offset), or
+    // (SB) ONE set re-loaded only when the next block's offset differs (64 % of the steps repeat the offset on the
+    // 80k scene: 24 KB of the 28 KB a step pulls through the texture path are weights)
+    float4 bw[SB ? 1 : 2][NF][NBW], a[NF];
+    int kcur = -1;
     f32x4 g[3][LPT];      // (native vector type: the HIP float4 struct kept this ring in scratch memory)
     int gix[LPT];                                  // gather row of this thread's chunk(s), block t+3
     int pidx[2], prow[2];                          // (input row, output tile row) of pair r, blocks t / t+1
@@ -341,6 +363,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             read_gix(d1); issue_G(g[1]);
             read_gix(d2); issue_G(g[2]);
             issue_B(d0, bw[0]);
+            kcur = d0 >> 8;
             store_G(g[0], 0);
             read_gix(desc(3));
             pidx[0] = s_idx[dbase(d0) + r];
@@ -352,7 +375,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             constexpr int u = decltype(U)::value;
                 // -- issue everything later steps need
             read_frag(u & 1, a);                                     // block t (stored at step t-1, barrier since)
-            issue_B(d1, bw[(u + 1) & 1]);                            // block t+1
+            if (!SB) issue_B(d1, bw[SB ? 0 : ((u + 1) & 1)]);       // block t+1
             issue_G(g[u % 3]);                                       // block t+3 (block t left these registers at step t-1)
             read_gix(d4);                                            // block t+4
             pidx[(u + 1) & 1] = s_idx[dbase(d1) + r];                // block t+1
@@ -374,8 +397,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     // the six partial products per 32-channel step, low order first; weights = A operand
 #pragma unroll
                     for (int sk = 0; sk < CIN / 32; ++sk) {
-                        const bf16x8 wh = as_bf8(bw[u & 1][3 * sk][n]), wm = as_bf8(bw[u & 1][3 * sk + 1][n]),
-                                     wl = as_bf8(bw[u & 1][3 * sk + 2][n]);
+                        const bf16x8 wh = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk][n]), wm = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 1][n]),
+                                     wl = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 2][n]);
                         const bf16x8 xh = as_bf8(a[3 * sk]), xm = as_bf8(a[3 * sk + 1]), xl = as_bf8(a[3 * sk + 2]);
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc1, 0, 0, 0);
@@ -388,10 +411,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].x, a[j].x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].y, a[j].y, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].z, a[j].z, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u & 1][j][n].w, a[j].w, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[SB ? 0 : (u & 1)][j][n].x, a[j].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[SB ? 0 : (u & 1)][j][n].y, a[j].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[SB ? 0 : (u & 1)][j][n].z, a[j].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[SB ? 0 : (u & 1)][j][n].w, a[j].w, acc1, 0, 0, 0);
                     }
                 }
                 // D^T: lane (r, q) holds columns 4q .. 4q+3 of pair r
@@ -402,6 +425,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     o[n].w += acc0[3] + acc1[3];
                     *po[n] = o[n];
                 }
+            }
+            if (SB && (d1 >> 8) != kcur) {                           // block t+1 starts another offset: its fragments now,
+                issue_B(d1, bw[0]);                                  // after the last MFMA that reads the old ones
+                kcur = d1 >> 8;
             }
             store_G(g[(u + 1) % 3], (u + 1) & 1);                    // block t+1 (gathered at step t-2); the slot was last read at step t-1
             d1 = d2;
@@ -440,21 +467,50 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                 *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
     }
     if (STAMP && tid == 0) {
-        unsigned long long *o = stamps + (size_t)blockIdx.x * 8;
+        unsigned long long *o = stamps + (size_t)it * 8;
         o[0] = t_rt0; o[1] = t_c0; o[2] = t_c1; o[3] = t_c2; o[4] = __builtin_amdgcn_s_memtime();
         o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = (unsigned long long)n_blocks; o[7] = (unsigned long long)code;
     }
+    __syncthreads();      // the next item re-initialises the LDS tile
+    }
 }
 
-template <int NW, int NBW, int CIN, bool STAMP = false, bool X3 = false>
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    return cus;
+}
+
+// workgroups per CU the launch may use: 0 = what the occupancy query says (the default), otherwise forced (tuning knob)
+static int tp_slots_override() {
+    static const int v = getenv("U2MKD_TP_SLOTS") ? atoi(getenv("U2MKD_TP_SLOTS")) : 0;
+    return v;
+}
+
+template <int NW, int NBW, int CIN, bool STAMP = false, bool X3 = false, bool SB = true>
 static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const float *wt, int cout, const int32_t *nbr,
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
     const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * (X3 ? 6 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
                        (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
-    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, X3>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
-                       items, n_items, K, kflip, out, stamps);
+    const int n_tiles = (int)ceil_div(rr.end - rr.begin, 64);
+    // one resident wave of workgroups at most (they deal the items among themselves, lightest first)
+    static int occ_by_k[33];                         // resident workgroups per CU of THIS instantiation at kernel volume K
+    if (occ_by_k[K] == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_tp_kernel<NW, NBW, CIN, STAMP, X3, SB>, 64 * NW, lds) != hipSuccess || n <= 0) n = 1;
+        occ_by_k[K] = n;
+    }
+    const int per_cu = tp_slots_override() > 0 ? tp_slots_override() : occ_by_k[K];
+    const unsigned slots = (unsigned)(per_cu * device_cus());
+    if (grid.x > slots) grid.x = slots;
+    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, X3, SB>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
+                       items, n_items, n_tiles, K, kflip, out, stamps);
 }
 
 // column split: cout -> (waves, 16-column blocks per wave, columns per workgroup)
@@ -494,8 +550,9 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     int nw = 0, nbw = 0;
     tp_split(cout, nw, nbw);
     const bool x3 = conv_tp_arith(arith) == 2;
+    static const bool double_buf = getenv("U2MKD_TP_SB") && atoi(getenv("U2MKD_TP_SB")) == 0;   // A/B knob: the double-buffered weight form at 64 -> 64
     const int64_t n_rows = rr.end - rr.begin;
-    dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile
+    dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile; launch_tp clamps it
 #define U2_TP(NW_, NBW_, CIN_)                                                                                          \
     do {                                                                                                                \
         if (x3) launch_tp<NW_, NBW_, CIN_, false, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
@@ -507,6 +564,7 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     } else if (nw == 4 && nbw == 1) {
         if (stamps && cin == 64 && x3) launch_tp<4, 1, 64, true, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
         else if (stamps && cin == 64) launch_tp<4, 1, 64, true, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        else if (cin == 64 && x3 && double_buf) launch_tp<4, 1, 64, false, true, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);
         else if (cin == 32) U2_TP(4, 1, 32); else if (cin == 64) U2_TP(4, 1, 64);
         else if (cin == 96) U2_TP(4, 1, 96); else U2_TP(4, 1, 128);
     } else if (nw == 3) {

@@ -213,14 +213,23 @@ pairs_build_kernel(const int32_t *__restrict__ nbr, int64_t n_out, int K, const 
 
 // ---- downsample keys: order-preserving (b,x,y,z) pack -----------------------
 // b: 10 bits, x/y/z: 18 bits each with bias 2^17 (|coord| < 131072).
+// A coordinate outside the packed range (the reference's torch.unique(dim=0) has none) would alias into another
+// voxel: such a row gets the key INT64_MAX and raises *range_flag, which the caller reads after its sort.
 __global__ void downsample_keys_kernel(const int4 *__restrict__ coords, int64_t n, int sx, int sy, int sz,
-                                       int64_t *__restrict__ keys) {
+                                       int64_t *__restrict__ keys, int32_t *__restrict__ range_flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = coords[i];
     auto fl = [](int v, int s) { int q = v / s; if ((v % s != 0) && ((v < 0) != (s < 0))) --q; return q * s; };
     int x = fl(c.x, sx), y = fl(c.y, sy), z = fl(c.z, sz);
     const int64_t bias = 1 << 17;
+    const int lim = 1 << 17;
+    const bool ok = x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim && c.w >= 0 && c.w < 512;
+    if (!ok) {
+        keys[i] = INT64_MAX;
+        if (range_flag) *range_flag = 1;
+        return;
+    }
     keys[i] = ((int64_t)c.w << 54) | ((int64_t)(x + bias) << 36) | ((int64_t)(y + bias) << 18) | (int64_t)(z + bias);
 }
 
@@ -367,14 +376,19 @@ int u2mkd_pairs_build(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k
     return check_launch("u2mkd_pairs_build");
 }
 
-int u2mkd_downsample_keys(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,
-                          u2mkd_stream_t s) {
+int u2mkd_downsample_keys_checked(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,
+                                  int32_t *range_flag, u2mkd_stream_t s) {
     if (n == 0) return 0;
     U2_REQUIRE(coords && keys, "u2mkd_downsample_keys: null pointer");
     U2_REQUIRE(sx > 0 && sy > 0 && sz > 0, "u2mkd_downsample_keys: strides must be positive");
     hipLaunchKernelGGL(downsample_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
-                       reinterpret_cast<const int4 *>(coords), n, sx, sy, sz, keys);
+                       reinterpret_cast<const int4 *>(coords), n, sx, sy, sz, keys, range_flag);
     return check_launch("u2mkd_downsample_keys");
+}
+
+int u2mkd_downsample_keys(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,
+                          u2mkd_stream_t s) {
+    return u2mkd_downsample_keys_checked(coords, n, sx, sy, sz, keys, nullptr, s);
 }
 
 int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords, u2mkd_stream_t s) {

@@ -240,11 +240,28 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     coords = _i32(coords).contiguous()
     n = coords.shape[0]
     keys = torch.empty(n, dtype=torch.int64, device=coords.device)
-    L.call('u2mkd_downsample_keys', L.ptr(coords), n, ss[0], ss[1], ss[2], L.ptr(keys), L.stream())
+    flag = _range_flag(coords.device)
+    L.call('u2mkd_downsample_keys_checked', L.ptr(coords), n, ss[0], ss[1], ss[2], L.ptr(keys), L.ptr(flag), L.stream())
     uniq = torch.unique(keys)  # sorted int64 == (b,x,y,z) lexicographic
+    # (the unique above has just synchronised the stream: reading the 4-byte flag costs no queue drain)
+    if n and int(flag) != 0:
+        flag.zero_()
+        raise ValueError('spdownsample: coordinates outside the packed key range (|x|, |y|, |z| < 131072 voxels, '
+                         '0 <= batch index < 512)')
     out = torch.empty(uniq.shape[0], 4, dtype=torch.int32, device=coords.device)
     L.call('u2mkd_unpack_keys', L.ptr(uniq), uniq.shape[0], L.ptr(out), L.stream())
     return out
+
+
+_RANGE_FLAGS = {}
+
+
+def _range_flag(device):
+    """Per-device int32 the key kernel raises when a coordinate cannot be packed (see u2mkd_downsample_keys_checked)."""
+    f = _RANGE_FLAGS.get(device.index)
+    if f is None:
+        f = _RANGE_FLAGS[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
 
 
 # -------------------------------------------------------------- kernel maps
@@ -300,36 +317,21 @@ class TileSchedule:
         self.nbr_s = tbl.index_select(1, order).contiguous()
         self.order = order.int()
         t = (n + 63) // 64
-        ms = torch.zeros(t * 64, dtype=torch.int32, device=dev)
-        ms[:n] = mask[order]
-        bits = (ms.view(t, 4, 16, 1) >> torch.arange(k, dtype=torch.int32, device=dev)) & 1
-        c16 = bits.sum(2)                                           # pairs per (tile, 16-row quarter, offset)
-        # work of a set of rows = its 16-pair MFMA blocks, sum over offsets of ceil(pairs / 16)
-        b4 = ((c16 + 15) >> 4).sum(2)                               # [t, 4]  quarters
-        b2 = ((c16.view(t, 2, 2, k).sum(2) + 15) >> 4).sum(2)       # [t, 2]  halves
-        b1 = ((c16.sum(1) + 15) >> 4).sum(1)                        # [t]     whole tiles
-        self.tile_order = torch.argsort(b1, descending=True, stable=True).int()   # offset-walking kernels
-        # Work items of the tile-pair kernel (u2mkd_conv_forward_tiles): a tile is a SERIAL chain of blocks, so
-        # the heaviest tiles (rows with rare neighbour masks: up to 62 blocks against a mean of 16) are cut into
-        # halves / quarters; items are listed heaviest first.  item = tile << 4 | sub << 2 | lg.  Built without a
-        # host sync: 7 candidates per tile, the ones not chosen (or without rows) sort to the end.  (Measured, MI355X:
-        # listing the light items first or in the middle of the launch order instead of last changes nothing --
-        # 39.8-41 us at 64 -> 64 -- the kernel is bound by the per-CU step rate, not by the order.)
-        lg = (b1 > _TILE_SPLIT[0]).int() + (b1 > _TILE_SPLIT[1]).int()          # [t] 0 / 1 / 2
-        tid = torch.arange(t, dtype=torch.int32, device=dev)
-        rows_left = n - tid * 64                                                # rows of the tile that exist
-        cand_w, cand_code = [], []
-        for l, bl in ((0, b1.view(t, 1)), (1, b2), (2, b4)):
-            nsub = 1 << l
-            sub = torch.arange(nsub, dtype=torch.int32, device=dev).view(1, nsub)
-            live = (lg.view(t, 1) == l) & (sub * (64 >> l) < rows_left.view(t, 1))
-            cand_w.append(torch.where(live, bl.int(), -1).reshape(-1))
-            cand_code.append(((tid.view(t, 1) << 4) | (sub << 2) | l).reshape(-1))
-        w = torch.cat(cand_w)
-        srt = torch.argsort(w, descending=True, stable=True)
-        items = torch.cat(cand_code)[srt].int()
-        self.n_items = (w >= 0).sum().int().view(1)
-        self.items = items.contiguous()
+        # Work of a set of rows = its 16-pair MFMA blocks, sum over offsets of ceil(pairs / 16).  tile_order = the
+        # 64-row tiles by descending blocks (offset-walking kernels).  Work items of the tile-pair kernel
+        # (u2mkd_conv_forward_tiles): a tile is a SERIAL chain of blocks, so the heaviest tiles (rows with rare
+        # neighbour masks: up to 62 blocks against a mean of 16) are cut into halves / quarters; items are listed
+        # heaviest first, item = tile << 4 | sub << 2 | lg.  Built on the device by two launches
+        # (csrc/schedule.hip: block counts per tile / half / quarter from ballots over the sorted masks, then one
+        # workgroup's stable counting sorts) -- the torch formulation it replaces (bit-plane sums, three argsorts,
+        # where / cat) was ~35 launches per schedule, a fifth of a training step's launches.  No host sync: the
+        # item count stays on the device.
+        self.tile_order = torch.empty(t, dtype=torch.int32, device=dev)
+        self.items = torch.empty(7 * t, dtype=torch.int32, device=dev)
+        self.n_items = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(t, 1) * 8, dtype=torch.int32, device=dev)
+        L.call('u2mkd_tile_schedule', L.ptr(mask), L.ptr(self.order), n, k, _TILE_SPLIT[0], _TILE_SPLIT[1], L.ptr(ws),
+               L.ptr(self.tile_order), L.ptr(self.items), L.ptr(self.n_items), L.stream())
 
     def tiles(self):
         return self.nbr_s, self.order
