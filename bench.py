@@ -152,6 +152,32 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
                                         L.ptr(plan), n, 27, 0, L.ptr(s['ws']), nbytes, L.ptr(s['dw']), st)
         return s
 
+    # bf16-storage variants of the same group (BASELINE.json configs[4]): bf16 rows in / out, one bf16 weight plane,
+    # fp32 accumulation; algorithmic bytes at s = 2 bytes per element
+    def bf16_group():
+        x = torch.randn(n, cin, device='cuda', generator=g).bfloat16()
+        gy = torch.randn(n, cout, device='cuda', generator=g).bfloat16()
+        w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
+        wf = torch.empty(2, lib.u2mkd_weight_fragments_bytes(27, cin, cout, 3), dtype=torch.uint8, device='cuda')
+        out = torch.empty(n, cout, device='cuda', dtype=torch.bfloat16)
+        dx = torch.empty(n, cin, device='cuda', dtype=torch.bfloat16)
+        dw = torch.empty_like(w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+
+        def conv(a, frag, flip, o):
+            if not flip:
+                L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, 2, 3, L.ptr(wf), st)
+            L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(a), n, cin, L.ptr(wf[frag]), cout, L.ptr(sch.nbr_s), L.ptr(sch.order),
+                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, L.ptr(o), st)
+        t = {'fwd': time_events([lambda: conv(x, 0, 0, out)], iters), 'dgrad': time_events([lambda: conv(gy, 1, 1, dx)], iters),
+             'wgrad': time_events([lambda: L.call('u2mkd_conv_wgrad_pairs_bf16', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(pairs),
+                                                  L.ptr(plan), n, 27, 0, L.ptr(ws), nbytes, L.ptr(dw), st)], iters)}
+        bb = sum(subm_algorithmic_bytes(n, p, cin, cout, s=2))
+        tt = sum(t.values())
+        return {'dtype': 'bf16 rows / bf16 weights / fp32 accumulate', 'algorithmic_bytes': bb,
+                'ms': dict({k: round(v, 4) for k, v in t.items()}, total=round(tt, 4)),
+                'achieved': round(bb / (tt * 1e-3) / 1e9, 1), 'frac': round(bb / (tt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     sets = [make_set() for _ in range(cold_sets)]
     set_bytes = sum(t.numel() * t.element_size() for t in sets[0].values() if torch.is_tensor(t))
     warm = {k: time_events([sets[0][k]], iters) for k in ('fwd', 'dgrad', 'wgrad')}
@@ -187,6 +213,7 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
                  'note': '%d operand sets of %.0f MB launched round-robin (%.0f MB > 256 MiB Infinity Cache)'
                          % (cold_sets, set_bytes / 1e6, cold_sets * set_bytes / 1e6)},
         'mfma_f32_tflops': round(flops / (t_warm * 1e-3) / 1e12, 2), 'mfma_f32_peak_tflops': 157.3,
+        'bf16_storage': bf16_group(),
     }
 
 

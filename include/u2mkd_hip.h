@@ -200,6 +200,20 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, in
 /* neighbour mask of every output row: bit k set iff nbr[k][j] >= 0 (k <= 32). */
 int u2mkd_kmap_rowmask(const int32_t *nbr /*[k,n_out]*/, int64_t n_out, int32_t k, int32_t *mask /*[n_out]*/,
                        u2mkd_stream_t s);
+/* BF16 STORAGE variants (BASELINE.json configs[4]; torchsparse runs its conv in half precision under autocast,
+ * custom_fwd(cast_inputs=half)): feature rows in and out are bf16 [n, c] (2 bytes per
+ * channel: half the gather bytes), weights = ONE bf16 plane in fragment order (u2mkd_weight_fragments arith = 3,
+ * u2mkd_weight_fragments_bytes(.., 3) = 2 bytes per weight), products on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation, every output rounded to bf16 once.  The weight gradient reads bf16 rows and returns fp32 (the
+ * optimizer's master dtype).  Parity statements stay in fp32; these are held against the fp32 kernels on
+ * bf16-rounded inputs (tests/test_gpu_torchsparse_ops.py).                                                     */
+int u2mkd_conv_forward_tiles_bf16(const void *in /*bf16 [n_in,cin]*/, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                  const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                                  const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip,
+                                  void *out /*bf16 [n_out,cout]*/, u2mkd_stream_t s);
+int u2mkd_conv_wgrad_pairs_bf16(const void *a /*bf16 [.,ca]*/, int32_t ca, const void *b /*bf16 [.,cb]*/, int32_t cb,
+                                const int32_t *pairs, const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap,
+                                void *workspace, size_t workspace_bytes, float *dw /*[k,ca,cb] fp32*/, u2mkd_stream_t s);
 /* The TILE SCHEDULE of a (mask-sorted) neighbour table, built on the device (csrc/schedule.hip): `mask` = the
  * rows' neighbour masks (u2mkd_kmap_rowmask), `order` = the row permutation that sorts them (NULL: identity);
  * a tile = 64 consecutive sorted rows, its weight = its 16-pair MFMA blocks (sum over offsets of ceil(pairs / 16)).
@@ -291,6 +305,12 @@ int u2mkd_bn_train_forward(const float *x /*[n,c]*/, int64_t n, int32_t c, const
                            float eps, float momentum, float *running_mean, float *running_var, int32_t relu,
                            float *partial, float *mean /*[c] out*/, float *invstd /*[c] out*/, float *y /*[n,c]*/,
                            u2mkd_stream_t s);
+/* the same with nn.BatchNorm's step counter: *num_batches_tracked (device int64, may be NULL) += 1 in the
+ * statistics kernel instead of a one-element launch of its own per layer and step                        */
+int u2mkd_bn_train_forward_counted(const float *x /*[n,c]*/, int64_t n, int32_t c, const float *gamma, const float *beta,
+                                   float eps, float momentum, float *running_mean, float *running_var,
+                                   int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean /*[c] out*/,
+                                   float *invstd /*[c] out*/, float *y /*[n,c]*/, u2mkd_stream_t s);
 int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                           const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c] out*/,
                           float *y, u2mkd_stream_t s);

@@ -515,3 +515,57 @@ def test_tile_schedule_kernels_match_the_torch_formulation(F, n, stride):
         idx = (sel.view(-1, 1) + torch.arange(r, device='cuda').view(1, -1)).reshape(-1)
         cover.index_add_(0, idx, torch.ones_like(idx, dtype=torch.int32))
     assert bool((cover[:nn_] == 1).all())
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 64), (32, 64), (64, 128)])
+def test_bf16_storage_conv_group_matches_fp32_kernels_on_rounded_inputs(F, cin, cout):
+    """BASELINE.json configs[4] kernels: bf16 feature rows in / out, one bf16 weight plane, fp32 accumulation.
+    Against the fp32 kernels (f32 MFMA) on the SAME bf16-rounded inputs the only difference is the final rounding
+    of each output to bf16 (2^-9 relative) and the accumulation order; the weight gradient (bf16 rows widened in
+    registers, f32 MFMA) is bit-identical to the fp32 kernel on the widened rows."""
+    from u2mkd_amd import _lib as L
+    from u2mkd_amd.synth import synth_batch
+    lib = L.load()
+    coords = synth_batch(20000, 1, seed=9)['coords']
+    km = F.build_kmap(_dev(coords), (1,) * 3, (3,) * 3, (1,) * 3)
+    n, k = km.n_out, 27
+    sch = km.schedule(False)
+    torch.manual_seed(3)
+    xb = torch.randn(n, cin, device='cuda').bfloat16()
+    gb = torch.randn(n, cout, device='cuda').bfloat16()
+    w = (torch.randn(k, cin, cout, device='cuda') / (k * cin) ** 0.5).bfloat16().float()
+    st = L.stream()
+
+    def frags(arith):
+        buf = torch.empty(2, lib.u2mkd_weight_fragments_bytes(k, cin, cout, arith), dtype=torch.uint8, device='cuda')
+        L.call('u2mkd_weight_fragments', L.ptr(w), k, cin, cout, 2, arith, L.ptr(buf), st)
+        return buf
+    f3, f1 = frags(3), frags(1)
+    assert f3.shape[1] * 2 == f1.shape[1]
+    for flip, a_b, ca, cb_, fi in ((0, xb, cin, cout, 0), (1, gb, cout, cin, 1)):      # forward, input gradient
+        if not lib.u2mkd_conv_tiles_supported(ca, cb_, k):
+            continue
+        ob = torch.full((n, cb_), float('nan'), device='cuda').bfloat16()
+        L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(a_b), n, ca, L.ptr(f3[fi]), cb_, L.ptr(sch.nbr_s), L.ptr(sch.order),
+               L.ptr(sch.items), L.ptr(sch.n_items), n, k, flip, L.ptr(ob), st)
+        of = torch.empty(n, cb_, device='cuda')
+        a_f = a_b.float()
+        L.call('u2mkd_conv_forward_tiles', L.ptr(a_f), n, ca, L.ptr(f1[fi]), cb_, L.ptr(sch.nbr_s), L.ptr(sch.order),
+               L.ptr(sch.items), L.ptr(sch.n_items), n, k, flip, 1, L.ptr(of), st)
+        err = (ob.float() - of).abs()
+        assert bool(torch.isfinite(ob.float()).all())
+        assert float((err / (of.abs() + 1e-3 * of.abs().max())).max()) < 2 ** -7
+        again = torch.empty_like(ob)
+        L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(a_b), n, ca, L.ptr(f3[fi]), cb_, L.ptr(sch.nbr_s), L.ptr(sch.order),
+               L.ptr(sch.items), L.ptr(sch.n_items), n, k, flip, L.ptr(again), st)
+        assert torch.equal(ob, again)
+    pairs, _, plan = km.pairs_plan()
+    nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    dwb, dwf = torch.empty(k, cin, cout, device='cuda'), torch.empty(k, cin, cout, device='cuda')
+    L.call('u2mkd_conv_wgrad_pairs_bf16', L.ptr(xb), cin, L.ptr(gb), cout, L.ptr(pairs), L.ptr(plan), n, k, 0, L.ptr(ws), nbytes,
+           L.ptr(dwb), st)
+    xf, gf = xb.float(), gb.float()          # (named: two temporaries would share one freed block)
+    L.call('u2mkd_conv_wgrad_pairs', L.ptr(xf), cin, L.ptr(gf), cout, L.ptr(pairs), L.ptr(plan), n, k, 0,
+           L.ptr(ws), nbytes, L.ptr(dwf), st)
+    assert torch.equal(dwb, dwf)

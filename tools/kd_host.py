@@ -32,7 +32,10 @@ if '--profile' in sys.argv:
     pr = cProfile.Profile(); pr.enable()
     for _ in range(5): run(d)
     torch.cuda.synchronize(); pr.disable()
-    pstats.Stats(pr).sort_stats('tottime').print_stats(35)
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime').print_stats(35)
+    if '--callers' in sys.argv:
+        st.sort_stats('ncalls').print_callers(r'built-in method torch\.(argsort|sort|where|arange|cat|zeros|full|empty_like|zeros_like|ones|stack|cumsum|bincount|unique|searchsorted|nonzero)|method .(int|long|float|to|clone|contiguous|fill_|copy_|zero_|index_select|masked_fill_|nonzero|sum|any|all|max|min|cumsum|repeat_interleave|expand|reshape). of')
 if '--syncs' in sys.argv:
     import warnings, collections, traceback
     sites = collections.Counter()

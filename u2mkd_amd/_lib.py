@@ -56,11 +56,14 @@ SIGNATURES = {
     'u2mkd_wgrad_plan': (C.c_int, [_p, _i32, _i64, _p, _p]),
     'u2mkd_conv_wgrad_pairs_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'u2mkd_conv_wgrad_pairs': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
+    'u2mkd_conv_forward_tiles_bf16': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    'u2mkd_conv_wgrad_pairs_bf16': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     'u2mkd_convolution_workspace_bytes': (_sz, [_i64, _i64, _i32, _i32, _p, _i32]),
     'u2mkd_convolution_forward': (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     'u2mkd_convolution_backward': (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     'u2mkd_bn_num_slabs': (_i64, [_i64]),
     'u2mkd_bn_train_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_train_forward_counted': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_eval_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_local_stats': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),

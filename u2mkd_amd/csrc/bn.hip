@@ -96,7 +96,10 @@ constexpr int kBnFinLanes = 64, kBnFinCh = 4;
 __global__ void __launch_bounds__(256)
 bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
                          float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
-                         float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ m2_out) {
+                         float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ m2_out,
+                         int64_t *__restrict__ num_batches_tracked = nullptr) {
+    // nn.BatchNorm's step counter (a separate one-element add_ launch per layer otherwise)
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     __shared__ float s_n[kBnFinLanes][kBnFinCh], s_m[kBnFinLanes][kBnFinCh], s_q[kBnFinLanes][kBnFinCh];
     const int cl = threadIdx.x & (kBnFinCh - 1), g = threadIdx.x / kBnFinCh;
     const int ch = blockIdx.x * kBnFinCh + cl;
@@ -168,6 +171,32 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int
     float4 v = reinterpret_cast<const float4 *>(x)[t];
     float4 m = *reinterpret_cast<const float4 *>(mean + j);
     float4 is = *reinterpret_cast<const float4 *>(invstd + j);
+    float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = (v.x - m.x) * is.x * g.x + b.x;
+    o.y = (v.y - m.y) * is.y * g.y + b.y;
+    o.z = (v.z - m.z) * is.z * g.z + b.z;
+    o.w = (v.w - m.w) * is.w * g.w + b.w;
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4 *>(y)[t] = o;
+}
+
+// eval mode: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta [, relu] in ONE launch (the separate
+// invstd pass was a launch per layer of the frozen KD teacher); workgroup 0 also writes invstd for a backward pass
+__global__ void bn_apply_eval_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
+                                     const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                     const float *__restrict__ beta, int relu, float *__restrict__ invstd_out,
+                                     float *__restrict__ y) {
+    if (blockIdx.x == 0 && invstd_out)
+        for (int ch = threadIdx.x; ch < 4 * c4; ch += blockDim.x) invstd_out[ch] = 1.f / sqrtf(var[ch] + eps);
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    int j = (int)(t % c4) * 4;
+    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 m = *reinterpret_cast<const float4 *>(mean + j);
+    float4 vr = *reinterpret_cast<const float4 *>(var + j);
+    float4 is = make_float4(1.f / sqrtf(vr.x + eps), 1.f / sqrtf(vr.y + eps), 1.f / sqrtf(vr.z + eps), 1.f / sqrtf(vr.w + eps));
     float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
     float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 o;
@@ -370,10 +399,23 @@ extern "C" {
 
 int64_t u2mkd_bn_num_slabs(int64_t n) { return n > 0 ? (n + kBnSlabRows - 1) / kBnSlabRows : 0; }
 
+int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
+                                   float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                   int32_t relu, float *partial /*[slabs,2,c]*/, float *mean /*[c]*/,
+                                   float *invstd /*[c]*/, float *y, u2mkd_stream_t s);
+
 int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                            float momentum, float *running_mean, float *running_var, int32_t relu,
                            float *partial /*[slabs,2,c]*/, float *mean /*[c]*/, float *invstd /*[c]*/, float *y,
                            u2mkd_stream_t s) {
+    return u2mkd_bn_train_forward_counted(x, n, c, gamma, beta, eps, momentum, running_mean, running_var, nullptr, relu,
+                                          partial, mean, invstd, y, s);
+}
+
+int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
+                                   float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                   int32_t relu, float *partial /*[slabs,2,c]*/, float *mean /*[c]*/,
+                                   float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
     U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward: c=%d must be a multiple of 4 in 4..1024", c);
     U2_REQUIRE(n > 0, "u2mkd_bn_train_forward: empty batch (n=%lld)", (long long)n);
     U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
@@ -381,7 +423,7 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
-                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr);
+                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
                        invstd, gamma, beta, relu, y);
@@ -395,10 +437,9 @@ int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gam
     if (n == 0) return 0;
     U2_REQUIRE(x && running_mean && running_var && invstd && y, "u2mkd_bn_eval_forward: null pointer");
     hipStream_t st = as_stream(s);
-    hipLaunchKernelGGL(bn_invstd_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, st, running_var, c, eps, invstd);
     int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
-                       running_mean, invstd, gamma, beta, relu, y);
+    hipLaunchKernelGGL(bn_apply_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
+                       running_mean, running_var, eps, gamma, beta, relu, invstd, y);
     return check_launch("u2mkd_bn_eval_forward");
 }
 

@@ -413,6 +413,17 @@ static void launch_conv_os3(dim3 grid, int K, hipStream_t st, const float *in, i
 //
 // plan layout (int32): [0] = P, [1] = CH, [2 .. 2+K] = pair offsets kofs[0..K],
 //                      [3+K .. 3+2K] = workgroup prefix wg[0..K].
+// 4 bf16 channels (8 bytes) -> f32x4: a bf16 is the upper half of the fp32 with the same value
+__device__ __forceinline__ f32x4 widen_bf16x4(const char *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    f32x4 v;
+    v[0] = __uint_as_float(u.x << 16);
+    v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16);
+    v[3] = __uint_as_float(u.y & 0xffff0000u);
+    return v;
+}
+
 __global__ void wgrad_plan_kernel(const int32_t *__restrict__ nbsizes, int K, int g_target, int cp,
                                   int32_t *__restrict__ plan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -429,7 +440,9 @@ __global__ void wgrad_plan_kernel(const int32_t *__restrict__ nbsizes, int K, in
     plan[3 + 2 * K] = w;
 }
 
-template <int WM, int WN, int CP, bool STAMP = false>
+// B16: a and b are BF16 rows (bf16 storage, BASELINE.json configs[4]): 8-byte gathers of 4 channels, widened to fp32
+// in registers; LDS images, MFMA arithmetic (f32) and slabs as in the fp32 form.
+template <int WM, int WN, int CP, bool STAMP = false, bool B16 = false>
 __global__ void __launch_bounds__(256)
 conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
                         const int32_t *__restrict__ pairs, const int32_t *__restrict__ plan, int K, int swap,
@@ -517,12 +530,14 @@ conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__rest
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int c = min(a0 + ((tid + 256 * i) % FA) * 4, ca_ok);
-            va[i] = *reinterpret_cast<const f32x4 *>(a + (size_t)xa[i] * ca + c);
+            if (B16) va[i] = widen_bf16x4(reinterpret_cast<const char *>(a) + ((size_t)xa[i] * ca + c) * 2);
+            else va[i] = *reinterpret_cast<const f32x4 *>(a + (size_t)xa[i] * ca + c);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int c = min(b0 + ((tid + 256 * i) % FB) * 4, cb_ok);
-            vb[i] = *reinterpret_cast<const f32x4 *>(b + (size_t)xb[i] * cb + c);
+            if (B16) vb[i] = widen_bf16x4(reinterpret_cast<const char *>(b) + ((size_t)xb[i] * cb + c) * 2);
+            else vb[i] = *reinterpret_cast<const f32x4 *>(b + (size_t)xb[i] * cb + c);
         }
     };
     auto store_chunk = [&](int p0, int buf, const f32x4 (&va)[PA], const f32x4 (&vb)[PB]) __attribute__((always_inline)) {
@@ -1019,7 +1034,7 @@ size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32
 int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
                            void *wf, u2mkd_stream_t s) {
     U2_REQUIRE(w && wf, "u2mkd_weight_fragments: null pointer");
-    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
+    U2_REQUIRE(arith >= 0 && arith <= 3, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32), 2 (bf16x3) or 3 (bf16 storage)");
     U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 32 == 0 && cols % 32 == 0,
                "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 32", k, rows, cols);
     U2_REQUIRE(transpose >= 0 && transpose <= 2, "u2mkd_weight_fragments: transpose must be 0, 1 or 2 (both)");
@@ -1151,9 +1166,9 @@ size_t u2mkd_conv_wgrad_pairs_workspace_bytes(int64_t n_rows, int32_t ca, int32_
     return ((size_t)wgrad_g_target(n_rows, k) + k) * (size_t)ca * cb * sizeof(float);
 }
 
-int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs,
-                           const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
-                           size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
+static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs,
+                            const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
+                            size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
     U2_REQUIRE(dw, "u2mkd_conv_wgrad_pairs: null pointer");
     if (n_rows == 0) {   // empty map: the gradient is zero
         (void)hipMemsetAsync(dw, 0, (size_t)k * ca * cb * sizeof(float), as_stream(s));
@@ -1187,6 +1202,13 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
         if (lds > 65536)                                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_pairs_kernel<WM_, WN_, CP_>),      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        if (b16) {                                                                                                  \
+            if (lds > 65536)                                                                                        \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_pairs_kernel<WM_, WN_, CP_, false, true>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            hipLaunchKernelGGL((conv_wgrad_pairs_kernel<WM_, WN_, CP_, false, true>), grid, dim3(256), lds, st, a, ca, b, cb, \
+                               pairs, plan, k, swap, tiles_b, slabs);                                               \
+        } else                                                                                                      \
         hipLaunchKernelGGL((conv_wgrad_pairs_kernel<WM_, WN_, CP_>), grid, dim3(256), lds, st, a, ca, b, cb, pairs, \
                            plan, k, swap, tiles_b, slabs);                                                          \
     } while (0)
@@ -1213,6 +1235,36 @@ int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t c
     hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(tile_elems, 64), k), dim3(256), 0, st,
                        slabs, plan, k, tile_elems, dw);
     return check_launch("u2mkd_conv_wgrad_pairs");
+}
+
+int u2mkd_conv_wgrad_pairs(const float *a, int32_t ca, const float *b, int32_t cb, const int32_t *pairs,
+                           const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
+                           size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
+    return wgrad_pairs_impl(false, a, ca, b, cb, pairs, plan, n_rows, k, swap, workspace, workspace_bytes, dw, s);
+}
+
+int u2mkd_conv_wgrad_pairs_bf16(const void *a, int32_t ca, const void *b, int32_t cb, const int32_t *pairs,
+                                const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap, void *workspace,
+                                size_t workspace_bytes, float *dw, u2mkd_stream_t s) {
+    return wgrad_pairs_impl(true, reinterpret_cast<const float *>(a), ca, reinterpret_cast<const float *>(b), cb, pairs, plan,
+                            n_rows, k, swap, workspace, workspace_bytes, dw, s);
+}
+
+int u2mkd_conv_forward_tiles_bf16(const void *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                  const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                                  const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, void *out,
+                                  u2mkd_stream_t s) {
+    if (n_out <= 0) return 0;
+    U2_REQUIRE(in && wf && nbr_sorted && out, "u2mkd_conv_forward_tiles_bf16: null pointer");
+    U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles_bf16: kflip must be 0 or 1");
+    U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles_bf16: empty input");
+    U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles_bf16: items and n_items go together");
+    int rc = launch_conv_tp("u2mkd_conv_forward_tiles_bf16", reinterpret_cast<const float *>(in), cin,
+                            reinterpret_cast<const float *>(wf), cout, nbr_sorted, order, RowRange{n_out, 0, n_out, nullptr},
+                            items, n_items, k, kflip, 3, reinterpret_cast<float *>(out), as_stream(s));
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_tiles_bf16: no instantiation for %d -> %d channels, kernel volume %d "
+               "(ask u2mkd_conv_tiles_supported first)", cin, cout, k);
+    return rc;
 }
 
 }  // extern "C"

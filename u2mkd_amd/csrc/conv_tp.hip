@@ -92,13 +92,14 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // B_k[16 cb + r][32 s + 8 q .. +7], lane = r + 16 q: the operand fragment of v_mfma_f32_16x16x32_bf16
 // (lane l holds A[row l & 15][k = 8 (l >> 4) + j]).  One thread reads 8 reduction channels of one column
 // and writes the three 16-byte fragments.
+template <int PLANES>
 __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows, int cols, int transpose,
                                            bf16x8 *__restrict__ wf, int64_t total) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     if (transpose == 2) {      // both orientations in one launch: [transpose = 1 | transpose = 0]
         transpose = 1 - (int)blockIdx.y;
-        wf += (size_t)blockIdx.y * total * 3;
+        wf += (size_t)blockIdx.y * total * PLANES;
     }
     const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
     const int lane = (int)(t & 63);
@@ -125,10 +126,12 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
         split3(x[i], h, m, l);
         vh[i] = h; vm[i] = m; vl[i] = l;
     }
-    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * 3 * 64 + lane;
-    o[0] = vh;
-    o[64] = vm;
-    o[128] = vl;
+    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * PLANES * 64 + lane;
+    o[0] = vh;              // PLANES == 1 (bf16 storage): the weights rounded to bf16
+    if (PLANES == 3) {
+        o[64] = vm;
+        o[128] = vl;
+    }
 }
 
 __device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
@@ -136,7 +139,7 @@ __device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NW, int NBW, int CIN, bool STAMP, bool X3, bool SB = true>
+template <int NW, int NBW, int CIN, bool STAMP, int AR, bool SB = true>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((CIN * NBW <= 64 && (NW >= 3 || CIN <= 32)) ? 4 : 1)))
 conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int cout, const int32_t *__restrict__ nbr,
                const int32_t *__restrict__ order, RowRange rr_, const int32_t *__restrict__ items,
@@ -147,12 +150,16 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     unsigned long long t_rt0 = 0, t_c0 = 0, t_c1 = 0, t_c2 = 0;
     int n_blocks = 0;
     if (STAMP) { t_rt0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_amdgcn_s_memtime(); }
+    // AR: 1 = fp32 rows, f32 MFMA; 2 = fp32 rows, bf16x3; 3 = BF16 STORAGE: `in` and `out` are bf16 rows, wf = one bf16
+    // plane (u2mkd_weight_fragments arith 3), one v_mfma_f32_16x16x32_bf16 per 32-channel step, fp32 accumulation in the
+    // LDS tile, outputs rounded to bf16 once (BASELINE.json configs[4]: half the gather bytes, no run-time split)
+    constexpr bool X3 = AR == 2, B16 = AR == 3;
     constexpr int T = 64, NT = 64 * NW, TN = 16 * NW * NBW, NJ = CIN / 16;
     constexpr int OS = TN + 4;                    // output tile row stride (floats)
     // gathered-row image: fp32 rows, or (X3) three bf16 planes h | m | l of CIN elements per row; + 16 B pad
-    constexpr int AS = X3 ? (6 * CIN + 16) / 4 : CIN + 4;        // row stride (floats)
-    constexpr int NF = X3 ? CIN / 32 * 3 : CIN / 16;             // 16-byte operand fragments per lane per block
-    constexpr int CPR = CIN / 4;                  // 16-byte chunks per gathered row
+    constexpr int AS = X3 ? (6 * CIN + 16) / 4 : B16 ? (2 * CIN + 16) / 4 : CIN + 4;   // row stride (floats)
+    constexpr int NF = X3 ? CIN / 32 * 3 : B16 ? CIN / 32 : CIN / 16;   // 16-byte operand fragments per lane per block
+    constexpr int CPR = B16 ? CIN / 8 : CIN / 4;  // 16-byte chunks per gathered row
     constexpr int LPT = (16 * CPR + NT - 1) / NT; // chunks a thread moves per block
     constexpr int KPW = (32 + NW - 1) / NW;       // offsets a wave compacts (K <= 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,7 +324,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             const int e = tid + i * NT;
             const int ch = e % CPR;
             const int ix = gix[i] >= 0 ? gix[i] : 0;
-            gg[i] = *reinterpret_cast<const f32x4 *>(in + (size_t)ix * CIN + 4 * ch);
+            gg[i] = *reinterpret_cast<const f32x4 *>(in + (B16 ? (size_t)ix * (CIN / 2) : (size_t)ix * CIN) + 4 * ch);
         }
     };
     auto store_G = [&](const f32x4 (&gg)[LPT], int slot) __attribute__((always_inline)) {
@@ -338,7 +345,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     *reinterpret_cast<bf16x4 *>(row) = h;
                     *reinterpret_cast<bf16x4 *>(row + 2 * CIN) = m;
                     *reinterpret_cast<bf16x4 *>(row + 4 * CIN) = l;
-                } else {
+                } else {   // fp32 rows, or bf16 rows as they are: 16 bytes = 4 floats / 8 bf16 channels
                     *reinterpret_cast<f32x4 *>(s_a + (slot * 16 + pr) * AS + 4 * ch) = gg[i];
                 }
             }
@@ -350,6 +357,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             if (X3)    // fragment j = 3 s + p: 8 consecutive channels 32 s + 8 q .. of plane p
                 aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) +
                                                           (j % 3) * 2 * CIN + 64 * (j / 3) + 16 * q);
+            else if (B16)   // fragment j: 8 consecutive bf16 channels 32 j + 8 q ..
+                aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) + 64 * j + 16 * q);
             else
                 aa[j] = *reinterpret_cast<const float4 *>(s_a + (slot * 16 + r) * AS + 16 * j + 4 * q);
         }
@@ -407,6 +416,12 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc1, 0, 0, 0);
                     }
+                } else if (B16) {
+#pragma unroll
+                    for (int sk = 0; sk < CIN / 32; ++sk) {
+                        if (sk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc0, 0, 0, 0);
+                    }
                 } else {
                     // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)
 #pragma unroll
@@ -462,9 +477,16 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         const int row = e / F4, c4 = e - row * F4;
         const int rid = s_rid[row];
         const int col = col0 + 4 * c4;
-        if (rid >= 0 && col < cout)
-            *reinterpret_cast<float4 *>(out + (size_t)rid * cout + col) =
-                *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
+        if (rid >= 0 && col < cout) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
+            if (B16) {
+                bf16x4 b;
+                b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+                *reinterpret_cast<bf16x4 *>(reinterpret_cast<char *>(out) + ((size_t)rid * cout + col) * 2) = b;
+            } else {
+                *reinterpret_cast<float4 *>(out + (size_t)rid * cout + col) = v;
+            }
+        }
     }
     if (STAMP && tid == 0) {
         unsigned long long *o = stamps + (size_t)it * 8;
@@ -491,25 +513,25 @@ static int tp_slots_override() {
     return v;
 }
 
-template <int NW, int NBW, int CIN, bool STAMP = false, bool X3 = false, bool SB = true>
+template <int NW, int NBW, int CIN, bool STAMP = false, int AR = 1, bool SB = true>
 static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const float *wt, int cout, const int32_t *nbr,
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
-    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * (X3 ? 6 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
+    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * (AR == 2 ? 6 * CIN + 16 : AR == 3 ? 2 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
                        (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
     const int n_tiles = (int)ceil_div(rr.end - rr.begin, 64);
     // one resident wave of workgroups at most (they deal the items among themselves, lightest first)
     static int occ_by_k[33];                         // resident workgroups per CU of THIS instantiation at kernel volume K
     if (occ_by_k[K] == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_tp_kernel<NW, NBW, CIN, STAMP, X3, SB>, 64 * NW, lds) != hipSuccess || n <= 0) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_tp_kernel<NW, NBW, CIN, STAMP, AR, SB>, 64 * NW, lds) != hipSuccess || n <= 0) n = 1;
         occ_by_k[K] = n;
     }
     const int per_cu = tp_slots_override() > 0 ? tp_slots_override() : occ_by_k[K];
     const unsigned slots = (unsigned)(per_cu * device_cus());
     if (grid.x > slots) grid.x = slots;
-    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, X3, SB>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
+    hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, AR, SB>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
                        items, n_items, n_tiles, K, kflip, out, stamps);
 }
 
@@ -535,7 +557,7 @@ bool conv_tp_supported(int cin, int cout, int k) {
 // arithmetic of the tile-pair kernel: 1 = f32 MFMA (bitwise fma chain), 2 = bf16x3 (fp32 accuracy, 2.7x fewer
 // matrix-pipe cycles); 0 = the library default (U2MKD_CONV_ARITH=f32|bf16x3, default bf16x3)
 int conv_tp_arith(int arith) {
-    if (arith == 1 || arith == 2) return arith;
+    if (arith == 1 || arith == 2 || arith == 3) return arith;
     static const int dflt = [] {
         const char *e = getenv("U2MKD_CONV_ARITH");
         return (e && e[0] == 'f') ? 1 : 2;
@@ -549,22 +571,24 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     if (!conv_tp_supported(cin, cout, k)) return -1;
     int nw = 0, nbw = 0;
     tp_split(cout, nw, nbw);
-    const bool x3 = conv_tp_arith(arith) == 2;
+    const int ar = conv_tp_arith(arith);
+    const bool x3 = ar == 2;
     static const bool double_buf = getenv("U2MKD_TP_SB") && atoi(getenv("U2MKD_TP_SB")) == 0;   // A/B knob: the double-buffered weight form at 64 -> 64
     const int64_t n_rows = rr.end - rr.begin;
     dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile; launch_tp clamps it
 #define U2_TP(NW_, NBW_, CIN_)                                                                                          \
     do {                                                                                                                \
-        if (x3) launch_tp<NW_, NBW_, CIN_, false, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
-        else launch_tp<NW_, NBW_, CIN_, false, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);    \
+        if (ar == 3) launch_tp<NW_, NBW_, CIN_, false, 3>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
+        else if (x3) launch_tp<NW_, NBW_, CIN_, false, 2>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
+        else launch_tp<NW_, NBW_, CIN_, false, 1>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);    \
     } while (0)
     if (nw == 2) {
         if (cin == 32) U2_TP(2, 1, 32); else if (cin == 64) U2_TP(2, 1, 64);
         else if (cin == 96) U2_TP(2, 1, 96); else U2_TP(2, 1, 128);
     } else if (nw == 4 && nbw == 1) {
-        if (stamps && cin == 64 && x3) launch_tp<4, 1, 64, true, true>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
-        else if (stamps && cin == 64) launch_tp<4, 1, 64, true, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
-        else if (cin == 64 && x3 && double_buf) launch_tp<4, 1, 64, false, true, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);
+        if (stamps && cin == 64 && x3) launch_tp<4, 1, 64, true, 2>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        else if (stamps && cin == 64) launch_tp<4, 1, 64, true, 1>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
+        else if (cin == 64 && x3 && double_buf) launch_tp<4, 1, 64, false, 2, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);
         else if (cin == 32) U2_TP(4, 1, 32); else if (cin == 64) U2_TP(4, 1, 64);
         else if (cin == 96) U2_TP(4, 1, 96); else U2_TP(4, 1, 128);
     } else if (nw == 3) {
@@ -577,16 +601,23 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
 }
 
 size_t weight_fragments_bytes(int k, int rows, int cols, int arith) {
-    return (size_t)k * rows * cols * (conv_tp_arith(arith) == 2 ? 6 : 4);
+    const int ar = conv_tp_arith(arith);
+    return (size_t)k * rows * cols * (ar == 2 ? 6 : ar == 3 ? 2 : 4);
 }
 
 int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st) {
     const int64_t elems = (int64_t)k * rows * cols;
     if (elems == 0) return 0;
-    if (conv_tp_arith(arith) == 2) {
+    const int ar = conv_tp_arith(arith);
+    if (ar == 2 || ar == 3) {
         const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
-        hipLaunchKernelGGL(weight_fragments_x3_kernel, dim3((unsigned)ceil_div(total, 256), transpose == 2 ? 2 : 1), dim3(256), 0, st, w, rows, cols,
-                           transpose, reinterpret_cast<bf16x8 *>(wf), total);
+        const dim3 grid((unsigned)ceil_div(total, 256), transpose == 2 ? 2 : 1);
+        if (ar == 2)
+            hipLaunchKernelGGL(weight_fragments_x3_kernel<3>, grid, dim3(256), 0, st, w, rows, cols, transpose,
+                               reinterpret_cast<bf16x8 *>(wf), total);
+        else
+            hipLaunchKernelGGL(weight_fragments_x3_kernel<1>, grid, dim3(256), 0, st, w, rows, cols, transpose,
+                               reinterpret_cast<bf16x8 *>(wf), total);
     } else {
         hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(elems, 256), transpose == 2 ? 2 : 1), dim3(256), 0, st, w, rows, cols,
                            transpose, wf, elems);

@@ -825,7 +825,7 @@ class BatchNormFunction(Function):
     csrc/bn.hip; statistics identical to nn.BatchNorm1d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None):
         L.require_cuda(x)
         x = x.contiguous().float()
         n, c = x.shape
@@ -836,9 +836,9 @@ class BatchNormFunction(Function):
             slabs = L.load().u2mkd_bn_num_slabs(n)
             partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
-            L.call('u2mkd_bn_train_forward', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps), float(momentum),
-                   L.ptr(running_mean), L.ptr(running_var), int(relu), L.ptr(partial), L.ptr(mean), L.ptr(invstd),
-                   L.ptr(y), L.stream())
+            L.call('u2mkd_bn_train_forward_counted', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps), float(momentum),
+                   L.ptr(running_mean), L.ptr(running_var), L.ptr(counter), int(relu), L.ptr(partial), L.ptr(mean),
+                   L.ptr(invstd), L.ptr(y), L.stream())
         else:
             mean = running_mean
             L.call('u2mkd_bn_eval_forward', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
@@ -861,7 +861,7 @@ class BatchNormFunction(Function):
         L.call('u2mkd_bn_backward', L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
                int(ctx.relu), int(ctx.training), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.stream())
         return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class SyncBatchNormFunction(Function):
@@ -944,15 +944,21 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
         raise RuntimeError(f'batch_norm expects [N, C] features, got {tuple(x.shape)}')
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     factor = 0.0 if bn.momentum is None else bn.momentum
+    sync = _sync_group(bn) if training else None
+    counter = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
-            factor = 1.0 / float(bn.num_batches_tracked)
+        # the step counter is bumped inside the statistics kernel (no launch of its own) unless its value is
+        # needed on the host (momentum=None: cumulative average) or the synchronising path runs
+        if bn.momentum is None or sync is not None or x.shape[0] < 2 or not bn.num_batches_tracked.is_cuda:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                factor = 1.0 / float(bn.num_batches_tracked)
+        else:
+            counter = bn.num_batches_tracked
     rm = bn.running_mean if (not training or bn.track_running_stats) else None
     rv = bn.running_var if (not training or bn.track_running_stats) else None
-    sync = _sync_group(bn) if training else None
     if sync is not None:
         return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1])
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
-    return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu)
+    return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter)
