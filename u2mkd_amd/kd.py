@@ -107,18 +107,51 @@ class StudentMSP2IFM(nn.Module):
         ib, ncam, ic, ih, iw = im.shape
         im = im.reshape(-1, ic, ih, iw)
         pixel_coordinates, masks, fov_mask = in_mod['pixel_coordinates'], in_mod['masks'], in_mod['fov_mask']
+        # The camera branch is independent of the LiDAR branch between two fusion points (stem + layer1 before the first
+        # one, one ResNet layer per stage after, the decoder at the end), and it is a few LARGE MIOpen kernels where
+        # the LiDAR branch is hundreds of small ones with host synchronisations in between (the voxel-set sizes):
+        # it runs on a side HIP stream, queued BEFORE the LiDAR work of the same stage, so the GPU has the camera
+        # kernels to run while the host waits for a torch.unique; autograd replays the same streams in the backward
+        # (MIOpen's backward next to the sparse-conv backward).  U2MKD_CAMERA_STREAM=0: everything on one stream.
+        main = torch.cuda.current_stream() if im.is_cuda else None
+        side = _side_stream(im, 'camera') if (_CAMERA_STREAM and im.is_cuda) else None
+
+        def on_side(fn, *inputs):
+            """fn() on the side stream, ordered after everything queued on the main stream so far."""
+            if side is None:
+                return fn()
+            side.wait_stream(main)
+            for t in inputs:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                return fn()
+
+        def join(*outs):
+            """the main stream waits for the side stream; `outs` were allocated there and are used (and freed) here."""
+            if side is not None:
+                main.wait_stream(side)
+                for t in outs:
+                    t.record_stream(main)
+
+        def cam_stage(x_in, idx):
+            x_o, skip_o = self.pix_branch.forward_resblock(x_in, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
+            if idx == n_stage - 1:
+                skip_o = self.pix_branch.spp(skip_o)
+            return x_o, skip_o
+
+        n_stage = len(self.vox_downs)
+        cam = on_side(lambda: cam_stage(self.pix_branch.forward_stem(im), 0), im)
         z = PointTensor(x.F, x.C.float())
         x0 = initial_voxelize(z, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())
         spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)     # all down-sample syncs up front
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
-
-        x_im = self.pix_branch.forward_stem(im)
         vox_feats = [point_to_voxel(x0, z0)]
         img_feats, mse_loss, pts_feats = [], [], []
-        n_stage = len(self.vox_downs)
         for idx in range(n_stage):
+            if idx > 0:
+                cam = on_side(lambda: cam_stage(x_im, idx), x_im)      # queued ahead of this stage's LiDAR kernels
             vox_out = self.vox_downs[idx](vox_feats[idx])
             tmp_p = point_to_voxel(vox_out, zz)
             coord_xyz, batch = tmp_p.F[:, :3], tmp_p.C[:, 3]
@@ -127,9 +160,8 @@ class StudentMSP2IFM(nn.Module):
             if idx == n_stage - 1:
                 pts_feats.append(self.adapt_layer(pts_feat.F))
 
-            x_im, skip = self.pix_branch.forward_resblock(x_im, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
-            if idx == n_stage - 1:
-                skip = self.pix_branch.spp(skip)
+            x_im, skip = cam
+            join(x_im, skip)
             _, ifc, ifh, ifw = skip.shape
 
             # LiDAR -> camera: multi-scale scatter-mean of the point features into every camera's map
@@ -146,6 +178,15 @@ class StudentMSP2IFM(nn.Module):
             pts_feat.F = self.c2l_fusion_blocks[idx](pts_feat.F, img_feat_tensor)
             vox_feats.append(point_to_voxel(vox_out, pts_feat))
 
+        # the pixel decoder (camera side) next to the voxel decoder (LiDAR side)
+        x_pix = None
+        if self.run_pix_decoder:
+            def pix_decoder():
+                up = self.pix_branch.forward_up(img_feats, im_size=(ih, iw))
+                fmap = self.classifier_pix(up)
+                fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
+                return feature_fetch(masks, pixel_coordinates, fmap)
+            x_pix = on_side(pix_decoder, *img_feats)
         _, x1, x2, x3, x4 = vox_feats
         z1 = pts_feat
         z1.F = z1.F + self.point_transforms[0](z0.F)
@@ -168,11 +209,9 @@ class StudentMSP2IFM(nn.Module):
 
         ret = {'x_vox': self.classifier_vox(z3.F), 'num_pts': [c.shape[1] for c in pixel_coordinates],
                'mse_loss': mse_loss, 'pts_feats': pts_feats}
-        if self.run_pix_decoder:
-            up = self.pix_branch.forward_up(img_feats, im_size=(ih, iw))
-            fmap = self.classifier_pix(up)
-            fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
-            ret['x_pix'] = feature_fetch(masks, pixel_coordinates, fmap)
+        if x_pix is not None:
+            join(x_pix)
+            ret['x_pix'] = x_pix
         return ret
 
 
@@ -209,7 +248,7 @@ class TSDFull(nn.Module):
         queued so far (the teacher's inputs) and the main stream waits for it before the outputs are used;
         U2MKD_TEACHER_STREAM=0 runs the reference's sequential order."""
         want_t = self.training or self.debug_val
-        side = _teacher_stream(in_mod['teacher']['lidar'].F) if want_t and _TEACHER_STREAM else None
+        side = _side_stream(in_mod['teacher']['lidar'].F, 'teacher') if want_t and _TEACHER_STREAM else None
         if side is None:
             ret = {'stu': self.model_s(in_mod['student'])}
             if want_t:
@@ -229,13 +268,15 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
+_CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 _SIDE = {}
 
 
-def _teacher_stream(ref):
+def _side_stream(ref, role):
+    """One side HIP stream per (device, role)."""
     if not ref.is_cuda:
         return None
-    key = ref.device.index
+    key = (ref.device.index, role)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=ref.device)
     return _SIDE[key]
