@@ -101,6 +101,20 @@ class StudentMSP2IFM(nn.Module):
         self.run_pix_decoder = run_pix_decoder
         self.adapt_layer = None          # attached by TSDFull (tsd_full.py:576-580)
 
+    def _camera_stage(self, x_in, idx):
+        x_o, skip_o = self.pix_branch.forward_resblock(x_in, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
+        if idx == len(self.vox_downs) - 1:
+            skip_o = self.pix_branch.spp(skip_o)
+        return x_o, skip_o
+
+    def camera_head(self, in_mod):
+        """SwiftNet stem + layer1 (everything of the camera branch ahead of the first fusion point) queued on the
+        camera stream; returns (x_im, skip) for ``forward``."""
+        im = in_mod['images']
+        im = im.reshape(-1, *im.shape[2:])
+        return _Fork(im, 'camera', _CAMERA_STREAM).on_side(
+            lambda: self._camera_stage(self.pix_branch.forward_stem(im), 0), im)
+
     def forward(self, in_mod):
         x = in_mod['lidar']
         im = in_mod['images']                                   # [B, ncam, 3, H, W]
@@ -113,34 +127,13 @@ class StudentMSP2IFM(nn.Module):
         # it runs on a side HIP stream, queued BEFORE the LiDAR work of the same stage, so the GPU has the camera
         # kernels to run while the host waits for a torch.unique; autograd replays the same streams in the backward
         # (MIOpen's backward next to the sparse-conv backward).  U2MKD_CAMERA_STREAM=0: everything on one stream.
-        main = torch.cuda.current_stream() if im.is_cuda else None
-        side = _side_stream(im, 'camera') if (_CAMERA_STREAM and im.is_cuda) else None
-
-        def on_side(fn, *inputs):
-            """fn() on the side stream, ordered after everything queued on the main stream so far."""
-            if side is None:
-                return fn()
-            side.wait_stream(main)
-            for t in inputs:
-                t.record_stream(side)
-            with torch.cuda.stream(side):
-                return fn()
-
-        def join(*outs):
-            """the main stream waits for the side stream; `outs` were allocated there and are used (and freed) here."""
-            if side is not None:
-                main.wait_stream(side)
-                for t in outs:
-                    t.record_stream(main)
-
-        def cam_stage(x_in, idx):
-            x_o, skip_o = self.pix_branch.forward_resblock(x_in, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
-            if idx == n_stage - 1:
-                skip_o = self.pix_branch.spp(skip_o)
-            return x_o, skip_o
-
+        fork = _Fork(im, 'camera', _CAMERA_STREAM)
+        on_side, join = fork.on_side, fork.join
         n_stage = len(self.vox_downs)
-        cam = on_side(lambda: cam_stage(self.pix_branch.forward_stem(im), 0), im)
+        cam_stage = self._camera_stage
+        cam = in_mod.get('_camera_head')          # queued already by TSDFull (ahead of the teacher's forward)
+        if cam is None:
+            cam = self.camera_head(in_mod)
         z = PointTensor(x.F, x.C.float())
         x0 = initial_voxelize(z, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())
@@ -256,10 +249,14 @@ class TSDFull(nn.Module):
                     ret['t'] = self.model_t(in_mod['teacher'])
             return ret
         main = torch.cuda.current_stream()
+        stu_in = in_mod['student']
+        if _CAMERA_STREAM and self.training:
+            # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
+            stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             t = self.model_t(in_mod['teacher'])
-        ret = {'stu': self.model_s(in_mod['student'])}
+        ret = {'stu': self.model_s(stu_in)}
         main.wait_stream(side)
         for v in _tensors(t):
             v.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
@@ -270,6 +267,29 @@ class TSDFull(nn.Module):
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 _SIDE = {}
+
+
+class _Fork:
+    """fn() on a side stream ordered after the main stream's queue (`on_side`), and the way back (`join`)."""
+
+    def __init__(self, ref, role, enabled):
+        self.main = torch.cuda.current_stream() if ref.is_cuda else None
+        self.side = _side_stream(ref, role) if (enabled and ref.is_cuda) else None
+
+    def on_side(self, fn, *inputs):
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        for t in inputs:
+            t.record_stream(self.side)       # allocated on the main stream, read on the side stream
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self, *outs):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                t.record_stream(self.main)   # allocated on the side stream, used (and freed) on the main one
 
 
 def _side_stream(ref, role):
