@@ -269,6 +269,12 @@ _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 _SIDE = {}
 
 
+# Under DDP the AccumulateGrad nodes of the camera parameters are created on the default stream while their gradients
+# arrive from the camera stream: intended here (autograd inserts the stream synchronisation), so the notice is off.
+if _CAMERA_STREAM and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
+
 class _Fork:
     """fn() on a side stream ordered after the main stream's queue (`on_side`), and the way back (`join`)."""
 
