@@ -331,13 +331,15 @@ _T0 = time.perf_counter()
 
 
 # --------------------------------------------------------------------------------- workloads
-def build_step(args, rank, workload, image_hw):
-    """(step closure, points per step on this rank, description)."""
+def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=None):
+    """(step closure, points per step on this rank, description).  sweeps / dtype / voxels: the configs[4] variant
+    (multi-sweep teacher scene of `voxels` voxels, bf16 autocast)."""
     import torch
     from u2mkd_amd import lidar, train as T
     from u2mkd_amd.synth import synth_batch, synth_kd_batch
     torch.manual_seed(0)
-    amp = 'bf16' if args.dtype == 'bf16' else False
+    amp = 'bf16' if (dtype or args.dtype) == 'bf16' else False
+    n_vox = voxels or args.voxels
     if workload == 'spvcnn':
         b = synth_batch(args.voxels, 1, seed=1234 + rank)
         feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
@@ -351,12 +353,18 @@ def build_step(args, rank, workload, image_hw):
     model = KD.TSDFull(cr=args.cr, cr_t=args.cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
     runner = T.KDStep(model, num_epochs=50, batch_size=1, amp=amp)
     runner.train_mode()
-    nb = synth_kd_batch(args.voxels, 1, seed=1234 + rank, image_hw=tuple(image_hw))
+    nb = synth_kd_batch(n_vox, 1, seed=1234 + rank, image_hw=tuple(image_hw), sweeps=sweeps)
     n_pts = int(sum(nb['teacher']['num_pts']))
     dbatch = T.kd_batch_to_device(nb)
     desc = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t %g, frozen) + SwiftNet18/SPVCNN+SphereFormer student '
             '(cr %g) + KD losses train step, one %d-point scene + 6 cameras %dx%d per GPU'
             % (args.cr_t, args.cr, n_pts, image_hw[0], image_hw[1]))
+    if sweeps:
+        n_agg = n_pts
+        n_pts = int(nb['teacher']['keyframe_mask_full'].sum())       # the metric counts raw KEY-FRAME points
+        desc = ('BASELINE.json configs[4] on ONE GPU: the same KD step with a multi-sweep teacher scene (%d aggregated points, '
+                '%d teacher voxels, key frame %d student voxels), %s autocast, 6 cameras %dx%d'
+                % (n_agg, int(sum(nb['teacher']['num_vox'])), int(sum(nb['student']['num_vox'])), amp or 'f32', image_hw[0], image_hw[1]))
     return (lambda: runner(dbatch)), n_pts, desc
 
 
@@ -418,12 +426,14 @@ def run_rank(args):
         if world == 1 and not args.no_secondary:
             sec = {}
             torch.cuda.empty_cache()
-            for name, wl, hw, w_, k_ in (('lidar_only_configs1', 'spvcnn', args.image_hw, 3, 10),
-                                         ('kd_6cam_900x1600', 'kd', (900, 1600), 2, 4)):
-                if wl == args.workload and tuple(hw) == tuple(args.image_hw):
+            for name, wl, hw, w_, k_, extra in (('lidar_only_configs1', 'spvcnn', args.image_hw, 3, 10, {}),
+                                                ('configs4_multisweep_bf16_1gpu', 'kd', args.image_hw, 2, 5,
+                                                 {'sweeps': 9, 'dtype': 'bf16', 'voxels': 300000}),
+                                                ('kd_6cam_900x1600', 'kd', (900, 1600), 2, 4, {})):
+                if wl == args.workload and tuple(hw) == tuple(args.image_hw) and not extra:
                     continue
                 try:
-                    s2, n2, d2 = build_step(args, rank, wl, hw)
+                    s2, n2, d2 = build_step(args, rank, wl, hw, **extra)
                     dt2, l2 = timed_run(s2, w_, k_, 1)
                     sec[name] = {'value': round(n2 * k_ / dt2, 1), 'unit': 'points/s', 'ms_per_step': round(dt2 / k_ * 1e3, 3),
                                  'steps': k_, 'warmup': w_, 'workload': d2}

@@ -1,0 +1,84 @@
+"""The two BASELINE.json configurations no other GPU test steps through as a whole:
+configs[3] -- the `_B` student (cr 2.0) + cr_t 2.0 teacher, batch 2 per GPU, DDP + SyncBatchNorm;
+configs[4] -- multi-sweep teacher input (keyframe masks) under bf16 autocast.
+Small scenes and images: these check the wiring of the step (shapes, re-index, streams, collectives, autocast),
+parity of the operators is held elsewhere (test_kd_path.py goldens at cr 2.0, test_gpu_torchsparse_ops.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _runner(cr, cr_t, amp=False):
+    from u2mkd_amd import kd as KD, lidar, train as T
+    torch.manual_seed(0)
+    sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+    model = KD.TSDFull(cr=cr, cr_t=cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+    run = T.KDStep(model, num_epochs=50, batch_size=2, amp=amp)
+    run.train_mode()
+    for m in model.modules():                      # deterministic comparison runs: no dropout / drop-path masks
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    return run
+
+
+def test_configs3_cr2_student_batch2_under_ddp_and_syncbn(hip):
+    """_B.yaml (cr 2.0 / cr_t 2.0), two scenes per GPU, the N>1 code path forced on one GPU (NCCL group of one rank,
+    DDP wrap, SyncBatchNorm conversion of the student): the first step's loss equals the plain single-process
+    step's, every student parameter receives a gradient, the teacher none, the loss stays finite over three steps."""
+    import torch.distributed as dist
+    from u2mkd_amd import train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    d = T.kd_batch_to_device(synth_kd_batch(2500, 2, seed=21, image_hw=(64, 112)))
+    plain = _runner(2.0, 2.0)
+    want = float(plain(d))
+    del plain
+    torch.cuda.empty_cache()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    os.environ['U2MKD_FORCE_DDP'] = '1'
+    os.environ['U2MKD_FORCE_SYNC_BN'] = '1'
+    try:
+        run = _runner(2.0, 2.0)
+        assert isinstance(run.net, torch.nn.parallel.DistributedDataParallel)
+        assert any(type(m).__name__.endswith('SyncBatchNorm') or 'Sync' in type(m).__name__ for m in run.model.model_s.modules())
+        losses = [float(run(d)) for _ in range(3)]
+        assert abs(losses[0] - want) < 2e-3 * abs(want), (losses[0], want)
+        # (lr 0.24 on a tiny scene with random labels: the loss is not monotone; it has to stay finite and bounded)
+        assert all(np.isfinite(losses)) and max(losses) < 10 * losses[0]
+        for n, p in run.model.model_s.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        assert all(p.grad is None for p in run.model.model_t.parameters())
+    finally:
+        os.environ.pop('U2MKD_FORCE_DDP', None)
+        os.environ.pop('U2MKD_FORCE_SYNC_BN', None)
+        dist.destroy_process_group()
+
+
+def test_configs4_multisweep_teacher_under_bf16_autocast(hip):
+    """Three aggregated sweeps for the teacher (keyframe_mask_full over all points, the student on the key frame),
+    the step under bf16 autocast as `amp_enabled` does in the reference trainer: the first loss is within bf16
+    noise of the fp32 step's, it stays finite, master weights and gradients stay fp32."""
+    from u2mkd_amd import train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    nb = synth_kd_batch(7000, 1, seed=33, image_hw=(64, 112), sweeps=3)
+    assert nb['teacher']['num_pts'][0] > nb['teacher']['keyframe_mask_full'].sum() > 0
+    d = T.kd_batch_to_device(nb)
+    assert d['keyframe_mask_full'] is not None
+    f32 = _runner(1.0, 2.0)
+    want = float(f32(d))
+    del f32
+    torch.cuda.empty_cache()
+    run = _runner(1.0, 2.0, amp='bf16')
+    losses = [float(run(d)) for _ in range(3)]
+    assert abs(losses[0] - want) < 0.05 * abs(want), (losses[0], want)
+    assert all(np.isfinite(losses)) and max(losses) < 10 * losses[0]
+    for n, p in run.model.model_s.named_parameters():
+        assert p.dtype == torch.float32 and p.grad is not None and p.grad.dtype == torch.float32, n

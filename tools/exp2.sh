@@ -1,2 +1,3 @@
-U2MKD_FORCE_DDP=1 U2MKD_FORCE_SYNC_BN=1 timeout -k 10 400 python bench.py --no-secondary --no-cpu-baseline --steps 8 --warmup 3 > gpurun_out/e15_ddp.log 2> gpurun_out/e15_ddp.err; echo "ddp rc=$?"; tail -1 gpurun_out/e15_ddp.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('KD forced DDP+SyncBN (1 GPU)', r['ms_per_step'], r['config']['final_loss'])"; tail -3 gpurun_out/e15_ddp.err
-U2MKD_FORCE_DDP=1 U2MKD_FORCE_SYNC_BN=1 timeout -k 10 400 python bench.py --workload spvcnn --no-secondary --no-cpu-baseline --steps 8 --warmup 3 > gpurun_out/e15_ddp1.log 2> gpurun_out/e15_ddp1.err; echo "ddp rc=$?"; tail -1 gpurun_out/e15_ddp1.log | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('configs1 forced DDP+SyncBN (1 GPU)', r['ms_per_step'], r['config']['final_loss'])"
+timeout -k 10 900 python bench.py --no-cpu-baseline > gpurun_out/e19_b.log 2> gpurun_out/e19_b.err; echo rc=$?; tail -1 gpurun_out/e19_b.log | python -c "
+import json,sys; r=json.loads(sys.stdin.read()); print('KD', r['ms_per_step'], r['value'])
+for k,v in r['secondary'].items(): print(k, v.get('ms_per_step'), v.get('value'), v.get('error'), v.get('workload','')[:160])"; grep "bench " gpurun_out/e19_b.err | tail -8

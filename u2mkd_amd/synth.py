@@ -185,23 +185,31 @@ def _yaw(xyz, deg):
     return xyz @ r.T
 
 
-def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 640), ncam: int = 6):
+def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 640), ncam: int = 6,
+                   sweeps: int | None = None):
     """Student + teacher feed dicts with the collate schema of
     core/datasets/lc_semantic_nusc_tsd_full.py:436-486, numpy payloads.
 
     One LiDAR scene per sample.  The student sees it under one random yaw and its voxels in a
     shuffled order; the teacher sees the same key-frame points under another yaw, re-voxelised
     (so points may merge: ``inverse_map`` point -> teacher voxel).  ``inds`` maps every student
-    voxel to its key-frame point, as core/nusc_trainers.py:295-324 consumes it."""
+    voxel to its key-frame point, as core/nusc_trainers.py:295-324 consumes it.
+
+    ``sweeps`` = k > 1: the TEACHER sees k aggregated sweeps (BASELINE.json configs[4]; the reference's
+    ``multisweeps``, lc_semantic_nusc_tsd_full.py:198-206): ``n_vox`` then counts the voxels of the aggregate, the
+    student sees the key-frame points only, the teacher dict carries ``keyframe_mask_full`` (over all points;
+    ``num_pts`` = all points) and the re-index of core/nusc_trainers.py:288-324 selects the key-frame rows."""
     rng = np.random.default_rng(seed + 7919)
     H, W = image_hw
     S = {'coords': [], 'feats': [], 'targets': [], 'pixel_coordinates': [], 'masks': [], 'fov_mask': [], 'inds': [],
          'num_vox': []}
-    T = {'coords': [], 'feats': [], 'targets': [], 'inverse_map': [], 'num_pts': [], 'num_vox': []}
+    T = {'coords': [], 'feats': [], 'targets': [], 'inverse_map': [], 'num_pts': [], 'num_vox': [], 'keyframe_mask_full': []}
     for b in range(batch):
-        sc = synth_scene(n_vox, seed + b)
-        xyz, inten, labels = sc['feats'][:, :3], sc['feats'][:, 3:], sc['labels']
-        npts = xyz.shape[0]
+        sc = synth_scene(n_vox, seed + b, sweeps)
+        xyz_all, inten_all, labels_all = sc['feats'][:, :3], sc['feats'][:, 3:], sc['labels']
+        kf = sc['keyframe'] if (sweeps or 0) > 1 else np.ones(len(xyz_all), bool)
+        # the student (and the re-index `inds`) live on the key-frame points only
+        xyz, inten, labels = xyz_all[kf], inten_all[kf], labels_all[kf]
         # ---- student: yaw, voxelise (unique by construction up to rounding), shuffled voxel order
         xs = _yaw(xyz, rng.uniform(-180, 180))
         vs = np.round(xs / VOXEL_SIZE).astype(np.int32)
@@ -219,17 +227,18 @@ def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 
         S['inds'].append([inds.astype(np.int64)])
         S['num_vox'].append(len(inds))
         # ---- teacher: another yaw, re-voxelised; inverse_map over ALL key-frame points
-        xt = _yaw(xyz, rng.uniform(-180, 180))
+        xt = _yaw(xyz_all, rng.uniform(-180, 180))
         vt = np.round(xt / VOXEL_SIZE).astype(np.int32)
         vt -= vt.min(0, keepdims=True)
         keyt = (vt[:, 0].astype(np.int64) << 40) | (vt[:, 1].astype(np.int64) << 20) | vt[:, 2].astype(np.int64)
         _, firstt, inv = np.unique(keyt, return_index=True, return_inverse=True)
         T['coords'].append(np.concatenate([vt[firstt], np.full((len(firstt), 1), b, np.int32)], 1))
-        T['feats'].append(np.concatenate([xt[firstt], inten[firstt]], 1).astype(np.float32))
-        T['targets'].append(labels[firstt])
+        T['feats'].append(np.concatenate([xt[firstt], inten_all[firstt]], 1).astype(np.float32))
+        T['targets'].append(np.where(kf, labels_all, 0)[firstt])      # non-key-frame points carry the ignore label
         T['inverse_map'].append(inv.astype(np.int64))
-        T['num_pts'].append(npts)
+        T['num_pts'].append(len(xyz_all))
         T['num_vox'].append(len(firstt))
+        T['keyframe_mask_full'].append(kf)
     images = rng.uniform(0, 255, (batch, ncam, H, W, 3)).astype(np.float32)
     student = {'coords': np.concatenate(S['coords']), 'feats': np.concatenate(S['feats']),
                'targets': np.concatenate(S['targets']), 'images': images,
@@ -238,4 +247,6 @@ def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 
     teacher = {'coords': np.concatenate(T['coords']), 'feats': np.concatenate(T['feats']),
                'targets': np.concatenate(T['targets']), 'inverse_map': np.concatenate(T['inverse_map']),
                'num_pts': T['num_pts'], 'num_vox': T['num_vox']}
+    if (sweeps or 0) > 1:
+        teacher['keyframe_mask_full'] = np.concatenate(T['keyframe_mask_full'])
     return {'student': student, 'teacher': teacher}

@@ -2,6 +2,8 @@
 trainers): LiDAR-only (core/spformer_trainer.py:58-94) and KD
 (core/nusc_trainers.py:255-366).  One call = forward, losses, zero_grad, backward (DDP
 all-reduce overlapped), SGD-nesterov step, LR-scheduler step; no ``.item()`` host syncs."""
+import os
+
 import numpy as np
 import torch
 
@@ -109,7 +111,7 @@ class KDStep:
     def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0, amp=False):
         self.model = model
         self.amp = _Amp(amp)
-        if D.world() > 1:
+        if D.world() > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':      # (the knob: the N>1 code path on one GPU)
             from .lidar.point_voxel import SparseSyncBatchNorm
             model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
         self.net = D.wrap_model(model, sync_bn=False)
