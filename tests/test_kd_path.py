@@ -138,8 +138,27 @@ KD_GOLDENS = [(1.0, 1.0, 'kd_cr10_3000', 1500), (1.0, 2.0, 'kd_cr10_t20_2000', 1
 
 
 @pytest.mark.gpu
+def test_first_fixture_meets_the_gate_without_exception_when_the_angles_come_from_the_cpu_libm(hip, monkeypatch):
+    """The proof behind the allowance of the first KD fixture (seed 77): SphereFormer quantises atan2-derived angles
+    into windows and relative-position bins; the reference (and the golden) computed them with the CPU libm, the
+    product with the GPU's, and the two differ in the last place on a few tokens that sit within rounding of a bin
+    edge.  With the spherical coordinates taken from the CPU (same fp32 formula, spherical_transformer.py:31-36) --
+    nothing else changed, every kernel of the path still the HIP one -- EVERY row of the student's logits and of the
+    distilled features is within 1e-3 of the golden and the losses within 1e-3: the quantiser inputs are the only
+    source of the rows that miss in the unpatched run."""
+    from u2mkd_amd.lidar import sphereformer as SFM
+    gpu_fn = SFM.cart2sphere
+    monkeypatch.setattr(SFM, 'cart2sphere', lambda xyz: gpu_fn(xyz.detach().cpu()).to(xyz.device))
+    _kd_golden_check(1.0, 1.0, 'kd_cr10_3000', 1500, strict=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('cr,cr_t,fixture,n_vox', KD_GOLDENS)
 def test_hip_kd_step_matches_reference_golden(hip, cr, cr_t, fixture, n_vox):
+    _kd_golden_check(cr, cr_t, fixture, n_vox, strict=fixture != 'kd_cr10_3000')
+
+
+def _kd_golden_check(cr, cr_t, fixture, n_vox, strict):
     from oracle.spvcnn_ref import fill_state_by_name
     from u2mkd_amd import kd, torchsparse as ts
     gold = np.load(os.path.join(G, fixture + '.npz'))
@@ -175,7 +194,6 @@ def test_hip_kd_step_matches_reference_golden(hip, cr, cr_t, fixture, n_vox):
     # (0.2 % of the rows; median error 3e-6).  That fixture keeps a bounded allowance and documents the effect;
     # tests/test_gpu_sptr.py::test_quantiser_decisions_equal_on_equal_inputs shows the quantisers themselves
     # are bit-exact on identical inputs.
-    strict = fixture != 'kd_cr10_3000'
     for a, key in ((out['stu']['x_vox'], 'x_vox'), (out['stu']['pts_feats'][0][::16], 'pts_feats_s')):
         frac, med, mx = rows_off(a, key)
         print('KD-PARITY', fixture, key, 'rows above 1e-3: %.5f' % frac, 'median %.2e' % med, 'max %.2e' % mx)
