@@ -205,3 +205,25 @@ def test_collate_and_kd_batch(tree):
         lo = sum(st['num_vox'][:b])
         assert np.array_equal(got, st['coords'][lo:lo + st['num_vox'][b], :3])
         off_p += te['num_pts'][b]; off_v += te['num_vox'][b]
+
+
+@pytest.mark.gpu
+def test_loader_batch_drives_a_kd_step_on_the_gpu(tree):
+    """f1 end to end: the loader's collated batch (two samples, six cameras, images at the network size) through
+    ``collated_to_kd_batch`` / ``kd_batch_to_device`` into one KD training step on the HIP operators."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from u2mkd_amd import kd as KD, lidar, train as T
+    root, ver = tree
+    tb = D.NuScenesTables(root, ver)
+    ds = D.LCNuScenesDataset(tb, split='val', im_cr=0.08)             # 72 x 128 images
+    batch = T.kd_batch_to_device(D.collated_to_kd_batch(D.collate_fn([ds[0], ds[1]])))
+    assert batch['images'].shape == (2, 6, 3, 72, 128)
+    torch.manual_seed(0)
+    sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+    model = KD.TSDFull(cr=0.5, cr_t=0.5, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+    run = T.KDStep(model, num_epochs=50, batch_size=2)
+    run.train_mode()
+    losses = [float(run(batch)) for _ in range(2)]
+    assert all(np.isfinite(losses))
+    assert all(p.grad is not None for p in model.model_s.parameters())
