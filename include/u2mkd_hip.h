@@ -314,6 +314,20 @@ int u2mkd_bn_train_forward_counted(const float *x /*[n,c]*/, int64_t n, int32_t 
 int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                           const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c] out*/,
                           float *y, u2mkd_stream_t s);
+/* The tail of a ResidualBlock (core/models/build_blocks.py:80-83: relu(net(x) + downsample(x))) in the BatchNorm
+ * passes: y = relu(bn(x) + res) forward; backward masks dy with (bn(x) + res > 0), returns it as dres (the gradient
+ * of the residual branch) and continues with the BatchNorm gradients -- one read of res instead of an add kernel,
+ * a ReLU kernel and their two backward kernels.  res / dres [n, c]; relu must be set.                         */
+int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                               float eps, float momentum, float *running_mean, float *running_var,
+                               int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd,
+                               float *y, u2mkd_stream_t s);
+int u2mkd_bn_eval_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                              float eps, const float *running_mean, const float *running_var, int32_t relu,
+                              float *invstd /*[c] out*/, float *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s);
 int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
                       float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx /*[n,c]*/, u2mkd_stream_t s);

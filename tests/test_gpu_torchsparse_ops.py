@@ -380,6 +380,40 @@ def test_batch_norm_matches_torch_cpu(F, n, c, relu):
         ours.zero_grad()
 
 
+@pytest.mark.parametrize('n,c', [(5000, 32), (40000, 96), (777, 256)])
+def test_batch_norm_with_fused_residual_and_relu(F, n, c):
+    """relu(bn(x) + res) in the BatchNorm passes (the tail of ResidualBlock, build_blocks.py:80-83) vs nn.BatchNorm1d,
+    add and ReLU on the CPU in fp64: output, the gradients of x, res, gamma, beta; train and eval modes."""
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 2.0 + 1.0
+    r = torch.randn(n, c)
+    g = torch.randn(n, c)
+    ref = torch.nn.BatchNorm1d(c).double()
+    ref.weight.data.uniform_(0.5, 1.5)
+    ref.bias.data.normal_(0, 0.3)
+    ours = torch.nn.BatchNorm1d(c).cuda()
+    ours.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    for mode in ('train', 'eval'):
+        getattr(ref, mode)()
+        getattr(ours, mode)()
+        xr, rr = x.double().requires_grad_(True), r.double().requires_grad_(True)
+        yr = torch.relu(ref(xr) + rr)
+        yr.backward(g.double())
+        xo, ro = x.cuda().requires_grad_(True), r.cuda().requires_grad_(True)
+        yo = F.batch_norm(xo, ours, True, ro)
+        yo.backward(g.cuda())
+        assert _rel(yo, yr) < 2e-6, mode
+        for got, want, what in ((xo.grad, xr.grad, 'dx'), (ro.grad, rr.grad, 'dres')):
+            err = (got.double().cpu() - want).abs() / want.abs().max()
+            assert int((err > 2e-5).sum()) <= 4, (mode, what, float(err.max()))      # ReLU flips at fp32 rounding of 0
+        assert _rel(ours.weight.grad, ref.weight.grad) < 2e-3 and _rel(ours.bias.grad, ref.bias.grad) < 2e-3
+        assert _rel(ours.running_mean, ref.running_mean) < 1e-6 and _rel(ours.running_var, ref.running_var) < 1e-5
+        ref.zero_grad()
+        ours.zero_grad()
+    with pytest.raises(ValueError):
+        F.batch_norm(x.cuda(), ours, False, r.cuda())
+
+
 @pytest.mark.parametrize('kind', ['subm', 'down', 'up'])
 @pytest.mark.parametrize('cin,cout', [(32, 64), (96, 48)])
 def test_v140_backend_format_entries(F, kind, cin, cout):

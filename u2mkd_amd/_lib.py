@@ -65,6 +65,9 @@ SIGNATURES = {
     'u2mkd_bn_train_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_train_forward_counted': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_eval_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_train_forward_res': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_eval_forward_res': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward_res': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'u2mkd_bn_backward': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_local_stats': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     'u2mkd_bn_merge_stats': (C.c_int, [_p, _i32, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),

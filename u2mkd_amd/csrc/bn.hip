@@ -162,9 +162,11 @@ bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n
 }
 
 // y = (x - mean) * invstd * gamma + beta [, relu]; gamma / beta may be null (affine=False)
+// res (may be null): the residual branch of a ResidualBlock, y = relu(bn(x) + res) in the same pass
 __global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
                                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                const float *__restrict__ beta, int relu, float *__restrict__ y) {
+                                const float *__restrict__ beta, int relu, float *__restrict__ y,
+                                const float *__restrict__ res = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     int j = (int)(t % c4) * 4;
@@ -178,6 +180,10 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int
     o.y = (v.y - m.y) * is.y * g.y + b.y;
     o.z = (v.z - m.z) * is.z * g.z + b.z;
     o.w = (v.w - m.w) * is.w * g.w + b.w;
+    if (res) {
+        const float4 rv = reinterpret_cast<const float4 *>(res)[t];
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     reinterpret_cast<float4 *>(y)[t] = o;
 }
@@ -187,7 +193,7 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int
 __global__ void bn_apply_eval_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
                                      const float *__restrict__ var, float eps, const float *__restrict__ gamma,
                                      const float *__restrict__ beta, int relu, float *__restrict__ invstd_out,
-                                     float *__restrict__ y) {
+                                     float *__restrict__ y, const float *__restrict__ res = nullptr) {
     if (blockIdx.x == 0 && invstd_out)
         for (int ch = threadIdx.x; ch < 4 * c4; ch += blockDim.x) invstd_out[ch] = 1.f / sqrtf(var[ch] + eps);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,6 +210,10 @@ __global__ void bn_apply_eval_kernel(const float *__restrict__ x, int64_t total4
     o.y = (v.y - m.y) * is.y * g.y + b.y;
     o.z = (v.z - m.z) * is.z * g.z + b.z;
     o.w = (v.w - m.w) * is.w * g.w + b.w;
+    if (res) {
+        const float4 rv = reinterpret_cast<const float4 *>(res)[t];
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     reinterpret_cast<float4 *>(y)[t] = o;
 }
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t n, int c,
                       const float *__restrict__ mean, const float *__restrict__ invstd,
                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                      float *__restrict__ partial) {
+                      float *__restrict__ partial, const float *__restrict__ res = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];   // [2][rl][c4]
     const int c4 = c >> 2;
     const int nloop = (c4 + kBnThreads - 1) / kBnThreads;
@@ -237,10 +247,11 @@ bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                 float4 d = *reinterpret_cast<const float4 *>(dy + (r0 + rr) * c + 4 * j);
                 float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
                 if (relu) {
-                    if (hx * g.x + b.x <= 0.f) d.x = 0.f;
-                    if (hy * g.y + b.y <= 0.f) d.y = 0.f;
-                    if (hz * g.z + b.z <= 0.f) d.z = 0.f;
-                    if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+                    const float4 rv = res ? *reinterpret_cast<const float4 *>(res + (r0 + rr) * c + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
+                    if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
+                    if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
+                    if (hw * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
                 }
                 s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
                 s2.x += d.x * hx; s2.y += d.y * hy; s2.z += d.z * hz; s2.w += d.w * hw;
@@ -297,7 +308,8 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
                                     const float *__restrict__ mean, const float *__restrict__ invstd,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                     const float *__restrict__ dbeta, const float *__restrict__ dgamma,
-                                    float *__restrict__ dx) {
+                                    float *__restrict__ dx, const float *__restrict__ res = nullptr,
+                                    float *__restrict__ dres = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     const float inv_n = total_n ? 1.f / *total_n : inv_n_host;     // SyncBatchNorm: the count of all ranks
@@ -312,11 +324,13 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
     float4 dg = *reinterpret_cast<const float4 *>(dgamma + j);
     float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
     if (relu) {
-        if (hx * g.x + b.x <= 0.f) d.x = 0.f;
-        if (hy * g.y + b.y <= 0.f) d.y = 0.f;
-        if (hz * g.z + b.z <= 0.f) d.z = 0.f;
-        if (hw * g.w + b.w <= 0.f) d.w = 0.f;
+        const float4 rv = res ? reinterpret_cast<const float4 *>(res)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
+        if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
+        if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
+        if (hw * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
     }
+    if (dres) reinterpret_cast<float4 *>(dres)[t] = d;          // gradient of the residual branch = the masked dy
     float4 o;
     o.x = g.x * is.x * (d.x - db.x * inv_n - hx * dg.x * inv_n);
     o.y = g.y * is.y * (d.y - db.y * inv_n - hy * dg.y * inv_n);
@@ -329,7 +343,8 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
 __global__ void bn_bwd_eval_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                   float *__restrict__ dx) {
+                                   float *__restrict__ dx, const float *__restrict__ res = nullptr,
+                                   float *__restrict__ dres = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     int j = (int)(t % c4) * 4;
@@ -340,11 +355,13 @@ __global__ void bn_bwd_eval_kernel(const float *__restrict__ dy, const float *__
     float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
     float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (relu) {
-        if ((v.x - m.x) * is.x * g.x + b.x <= 0.f) d.x = 0.f;
-        if ((v.y - m.y) * is.y * g.y + b.y <= 0.f) d.y = 0.f;
-        if ((v.z - m.z) * is.z * g.z + b.z <= 0.f) d.z = 0.f;
-        if ((v.w - m.w) * is.w * g.w + b.w <= 0.f) d.w = 0.f;
+        const float4 rv = res ? reinterpret_cast<const float4 *>(res)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((v.x - m.x) * is.x * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
+        if ((v.y - m.y) * is.y * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
+        if ((v.z - m.z) * is.z * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
+        if ((v.w - m.w) * is.w * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
     }
+    if (dres) reinterpret_cast<float4 *>(dres)[t] = d;
     reinterpret_cast<float4 *>(dx)[t] = make_float4(d.x * g.x * is.x, d.y * g.y * is.y, d.z * g.z * is.z, d.w * g.w * is.w);
 }
 
@@ -399,10 +416,18 @@ extern "C" {
 
 int64_t u2mkd_bn_num_slabs(int64_t n) { return n > 0 ? (n + kBnSlabRows - 1) / kBnSlabRows : 0; }
 
+int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                               float eps, float momentum, float *running_mean, float *running_var,
+                               int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd, float *y,
+                               u2mkd_stream_t s);
+
 int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                                    float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                                    int32_t relu, float *partial /*[slabs,2,c]*/, float *mean /*[c]*/,
-                                   float *invstd /*[c]*/, float *y, u2mkd_stream_t s);
+                                   float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
+    return u2mkd_bn_train_forward_res(x, nullptr, n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                                      num_batches_tracked, relu, partial, mean, invstd, y, s);
+}
 
 int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                            float momentum, float *running_mean, float *running_var, int32_t relu,
@@ -412,10 +437,10 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
                                           partial, mean, invstd, y, s);
 }
 
-int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
-                                   float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
-                                   int32_t relu, float *partial /*[slabs,2,c]*/, float *mean /*[c]*/,
-                                   float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
+int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                               float eps, float momentum, float *running_mean, float *running_var,
+                               int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd, float *y,
+                               u2mkd_stream_t s) {
     U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward: c=%d must be a multiple of 4 in 4..1024", c);
     U2_REQUIRE(n > 0, "u2mkd_bn_train_forward: empty batch (n=%lld)", (long long)n);
     U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
@@ -426,43 +451,66 @@ int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const f
                        eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
-                       invstd, gamma, beta, relu, y);
+                       invstd, gamma, beta, relu, y, res);
     return check_launch("u2mkd_bn_train_forward");
 }
+
+int u2mkd_bn_eval_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                              float eps, const float *running_mean, const float *running_var, int32_t relu,
+                              float *invstd /*[c]*/, float *y, u2mkd_stream_t s);
 
 int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                           const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c]*/,
                           float *y, u2mkd_stream_t s) {
+    return u2mkd_bn_eval_forward_res(x, nullptr, n, c, gamma, beta, eps, running_mean, running_var, relu, invstd, y, s);
+}
+
+int u2mkd_bn_eval_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                              float eps, const float *running_mean, const float *running_var, int32_t relu,
+                              float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
     U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_eval_forward: c=%d must be a positive multiple of 4", c);
     if (n == 0) return 0;
     U2_REQUIRE(x && running_mean && running_var && invstd && y, "u2mkd_bn_eval_forward: null pointer");
     hipStream_t st = as_stream(s);
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
-                       running_mean, running_var, eps, gamma, beta, relu, invstd, y);
+                       running_mean, running_var, eps, gamma, beta, relu, invstd, y, res);
     return check_launch("u2mkd_bn_eval_forward");
 }
+
+int u2mkd_bn_backward_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s);
 
 int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
                       float *dgamma /*[c]*/, float *dbeta /*[c]*/, float *dx, u2mkd_stream_t s) {
+    return u2mkd_bn_backward_res(dy, x, nullptr, n, c, mean, invstd, gamma, beta, relu, training, partial, dgamma, dbeta, dx,
+                                 nullptr, s);
+}
+
+int u2mkd_bn_backward_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s) {
     U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE((res == nullptr) == (dres == nullptr), "u2mkd_bn_backward_res: res and dres go together");
+    U2_REQUIRE(res == nullptr || relu, "u2mkd_bn_backward_res: a residual input is only fused with the ReLU form");
     if (n == 0) return 0;
     U2_REQUIRE(dy && x && mean && invstd && partial && dgamma && dbeta && dx, "u2mkd_bn_backward: null pointer");
     hipStream_t st = as_stream(s);
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
-                       invstd, gamma, beta, relu, partial);
+                       invstd, gamma, beta, relu, partial, res);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
                        dbeta, dgamma);
     int64_t total4 = n * (c / 4);
     if (training)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
                            c / 4, 1.f / (float)n, (const float *)nullptr, mean, invstd, gamma, beta, relu, dbeta, dgamma,
-                           dx);
+                           dx, res, dres);
     else
         hipLaunchKernelGGL(bn_bwd_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
-                           c / 4, mean, invstd, gamma, beta, relu, dx);
+                           c / 4, mean, invstd, gamma, beta, relu, dx, res, dres);
     return check_launch("u2mkd_bn_backward");
 }
 

@@ -40,14 +40,24 @@ class FusedSequential(nn.Sequential):
     runs every BatchNorm -> ReLU pair as ONE fused HIP pass (BN statistics, normalise,
     affine and max(.,0) in a single read/write of the feature matrix)."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (a SparseTensor / tensor like the output): the sequence must END in a BatchNorm, and the
+        result is relu(sequence(x) + residual) with the add and the ReLU inside that BatchNorm's pass."""
         mods = list(self)
         i = 0
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             fusable = (type(m).__name__ in _FUSABLE_BN and type(nxt) in (spnn.ReLU, nn.ReLU))
-            if fusable:
+            if residual is not None and i == len(mods) - 1:
+                assert type(m).__name__ in _FUSABLE_BN, type(m).__name__
+                r = residual.F if isinstance(residual, SparseTensor) else residual
+                if isinstance(x, SparseTensor):
+                    x = fapply(x, spf.batch_norm, m, True, r)
+                else:
+                    x = spf.batch_norm(x, m, True, r)
+                i += 1
+            elif fusable:
                 if isinstance(x, SparseTensor):
                     x = fapply(x, spf.batch_norm, m, True)
                 else:
@@ -97,4 +107,5 @@ class ResidualBlock(nn.Module):
         self.relu = spnn.ReLU(True)
 
     def forward(self, x):
-        return self.relu(self.net(x) + self.downsample(x))
+        # relu(net(x) + downsample(x)): the add and the ReLU run inside the last BatchNorm's pass (forward and backward)
+        return self.net(x, residual=self.downsample(x))

@@ -825,31 +825,34 @@ class BatchNormFunction(Function):
     csrc/bn.hip; statistics identical to nn.BatchNorm1d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None, res=None):
         L.require_cuda(x)
         x = x.contiguous().float()
         n, c = x.shape
         dev = x.device
+        if res is not None:      # y = relu(bn(x) + res): the tail of a ResidualBlock in the same pass
+            assert relu and res.shape == x.shape, (relu, res.shape, x.shape)
+            res = res.contiguous().float()
         y = torch.empty_like(x)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
         if training:
             slabs = L.load().u2mkd_bn_num_slabs(n)
             partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
-            L.call('u2mkd_bn_train_forward_counted', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps), float(momentum),
-                   L.ptr(running_mean), L.ptr(running_var), L.ptr(counter), int(relu), L.ptr(partial), L.ptr(mean),
-                   L.ptr(invstd), L.ptr(y), L.stream())
+            L.call('u2mkd_bn_train_forward_res', L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+                   float(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(counter), int(relu), L.ptr(partial),
+                   L.ptr(mean), L.ptr(invstd), L.ptr(y), L.stream())
         else:
             mean = running_mean
-            L.call('u2mkd_bn_eval_forward', L.ptr(x), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+            L.call('u2mkd_bn_eval_forward_res', L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
                    L.ptr(running_mean), L.ptr(running_var), int(relu), L.ptr(invstd), L.ptr(y), L.stream())
-        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, res)
         ctx.relu, ctx.training = bool(relu), bool(training)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, res = ctx.saved_tensors
         dy = dy.contiguous().float()
         n, c = x.shape
         dev = x.device
@@ -858,10 +861,12 @@ class BatchNormFunction(Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
-        L.call('u2mkd_bn_backward', L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta),
-               int(ctx.relu), int(ctx.training), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.stream())
+        dres = torch.empty_like(x) if res is not None else None
+        L.call('u2mkd_bn_backward_res', L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+               L.ptr(beta), int(ctx.relu), int(ctx.training), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx),
+               L.ptr(dres), L.stream())
         return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, dres)
 
 
 class SyncBatchNormFunction(Function):
@@ -937,9 +942,11 @@ def _sync_group(bn):
     return None
 
 
-def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool = False) -> torch.Tensor:
+def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool = False,
+               residual: torch.Tensor = None) -> torch.Tensor:
     """nn.BatchNorm1d semantics (training or eval, running statistics, momentum=None =
-    cumulative average) on a [N, C] tensor, optionally fused with ReLU."""
+    cumulative average) on a [N, C] tensor, optionally fused with ReLU; ``residual`` [N, C] (with relu):
+    relu(bn(x) + residual), the tail of a ResidualBlock (build_blocks.py:80-83), in the same pass."""
     if x.dim() != 2:
         raise RuntimeError(f'batch_norm expects [N, C] features, got {tuple(x.shape)}')
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
@@ -957,8 +964,13 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
             counter = bn.num_batches_tracked
     rm = bn.running_mean if (not training or bn.track_running_stats) else None
     rv = bn.running_var if (not training or bn.track_running_stats) else None
+    if residual is not None and not relu:
+        raise ValueError('batch_norm: a residual input is fused together with the ReLU only')
     if sync is not None:
+        if residual is not None:     # the synchronising path keeps the add and the ReLU as separate passes
+            y = SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, False, sync[0], sync[1])
+            return torch.relu(y + residual)
         return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1])
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
-    return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter)
+    return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual)
