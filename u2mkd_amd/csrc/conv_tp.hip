@@ -187,8 +187,11 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // START of a young workgroup costs nothing: it waits for memory while the older workgroups use the CU.
     const int n_it = items ? *n_items_dev : n_tiles;
     const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int n_rd = (n_it + G - 1) / G;
+    const bool asc = (kflip & 4) != 0;          // round order (launch_conv_tp: U2MKD_TP_ORDER)
 #pragma nounroll
-    for (int rd = (n_it + G - 1) / G - 1; rd >= 0; --rd) {
+    for (int rq = 0; rq < n_rd; ++rq) {
+    const int rd = asc ? rq : n_rd - 1 - rq;
     const int it = rd * G + ((rd & 1) ? G - 1 - wg : wg);
     if (it >= n_it) continue;
     // the lane index is re-derived behind an opaque asm in every round: otherwise the compiler hoists every
@@ -573,6 +576,8 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     tp_split(cout, nw, nbw);
     const int ar = conv_tp_arith(arith);
     const bool x3 = ar == 2;
+    static const bool order_asc = getenv("U2MKD_TP_ORDER") && getenv("U2MKD_TP_ORDER")[0] == 'a';      // A/B knob: main item first
+    if (order_asc) kflip |= 4;
     static const bool double_buf = getenv("U2MKD_TP_SB") && atoi(getenv("U2MKD_TP_SB")) == 0;   // A/B knob: the double-buffered weight form at 64 -> 64
     const int64_t n_rows = rr.end - rr.begin;
     dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile; launch_tp clamps it
