@@ -4,7 +4,7 @@ channels): forward and forward + backward times, pairs M = sum of squared window
 SURVEY.md section 8d (q, k, v, out rows + coordinates / indices; the fused kernels never write M-sized arrays) and
 what the reference's unfused dataflow would move for the same call (index_0/1 [M], rel_idx [M,3], attn [M,h] twice).
 Run it under rocprofv3 --kernel-trace --stats for the per-kernel figures in profiles/."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from u2mkd_amd import sptr
 from tools.ab_conv import ev
