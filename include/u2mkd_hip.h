@@ -95,6 +95,9 @@ int u2mkd_downsample_keys(const int32_t *coords /*[n,4]*/, int64_t n, int32_t sx
 int u2mkd_downsample_keys_checked(const int32_t *coords /*[n,4]*/, int64_t n, int32_t sx, int32_t sy, int32_t sz,
                                   int64_t *keys /*[n]*/, int32_t *range_flag, u2mkd_stream_t s);
 int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords /*[n,4]*/, u2mkd_stream_t s);
+/* voxel of every point at tensor stride s: (floor(xyz / s) * s, (int)b) from float (x, y, z, b) rows -- the hash
+ * input of point_to_voxel / voxel_to_point (core/models/utils.py:43-47,86-90), one launch instead of seven.    */
+int u2mkd_floor_coords(const float *pc /*[n,4]*/, int64_t n, int32_t stride, int32_t *out /*[n,4]*/, u2mkd_stream_t s);
 
 /* ---- sparse convolution ------------------------------------------------
  * replaces torchsparse.backend.convolution_forward_cuda /

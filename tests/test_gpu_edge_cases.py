@@ -141,3 +141,14 @@ def test_downsample_rejects_coordinates_outside_the_key_range(F, bad):
         F.spdownsample(_dev(np.concatenate([ok, np.array([bad], np.int32)])), 2, 2, 1)
     out = F.spdownsample(_dev(ok), 2, 2, 1).cpu().numpy()          # the flag was cleared
     assert np.array_equal(out, want)
+
+
+def test_floor_coords_kernel_equals_the_torch_formula(F):
+    """u2mkd_floor_coords vs torch.floor(xyz / s).int() * s | b.int() bit for bit, negative and fractional inputs."""
+    from u2mkd_amd.lidar.point_voxel import _floor_coords
+    g = torch.Generator().manual_seed(0)
+    pc = torch.cat([(torch.rand(5000, 3, generator=g) - 0.3) * 700.0, torch.randint(0, 4, (5000, 1), generator=g).float()], 1)
+    pc[:10, :3] = torch.tensor([[-0.0, 8.0, -8.0]] * 10)
+    for s in (1, 2, 8, 16):
+        want = torch.cat([torch.floor(pc[:, :3] / s).int() * s, pc[:, -1].int().view(-1, 1)], 1)
+        assert torch.equal(_floor_coords(pc.cuda(), s).cpu(), want)

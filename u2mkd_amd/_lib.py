@@ -31,6 +31,7 @@ SIGNATURES = {
     'u2mkd_kmap_compact': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     'u2mkd_downsample_keys': (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_downsample_keys_checked': (C.c_int, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    'u2mkd_floor_coords': (C.c_int, [_p, _i64, _i32, _p, _p]),
     'u2mkd_unpack_keys': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_transpose_weights': (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),

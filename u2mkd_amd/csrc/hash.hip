@@ -233,6 +233,22 @@ __global__ void downsample_keys_kernel(const int4 *__restrict__ coords, int64_t 
     keys[i] = ((int64_t)c.w << 54) | ((int64_t)(x + bias) << 36) | ((int64_t)(y + bias) << 18) | (int64_t)(z + bias);
 }
 
+// int32 (floor(x / s) * s, floor(y / s) * s, floor(z / s) * s, (int)b) of float point coordinates (x, y, z, b):
+// the voxel a point falls into at tensor stride s (core/models/utils.py:43-47,86-90: torch.floor(z.C[:, :3] / s) * s
+// concatenated with the batch column and cast to int -- seven element-wise launches in torch)
+__global__ void floor_coords_kernel(const float4 *__restrict__ pc, int64_t n, int stride, int4 *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = pc[i];
+    const float s = (float)stride;
+    int4 o;
+    o.x = (int)floorf(c.x / s) * stride;
+    o.y = (int)floorf(c.y / s) * stride;
+    o.z = (int)floorf(c.z / s) * stride;
+    o.w = (int)c.w;
+    out[i] = o;
+}
+
 __global__ void unpack_keys_kernel(const int64_t *__restrict__ keys, int64_t n, int4 *__restrict__ coords) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -389,6 +405,15 @@ int u2mkd_downsample_keys_checked(const int32_t *coords, int64_t n, int32_t sx, 
 int u2mkd_downsample_keys(const int32_t *coords, int64_t n, int32_t sx, int32_t sy, int32_t sz, int64_t *keys,
                           u2mkd_stream_t s) {
     return u2mkd_downsample_keys_checked(coords, n, sx, sy, sz, keys, nullptr, s);
+}
+
+int u2mkd_floor_coords(const float *pc, int64_t n, int32_t stride, int32_t *out, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(pc && out, "u2mkd_floor_coords: null pointer");
+    U2_REQUIRE(stride > 0, "u2mkd_floor_coords: stride must be positive");
+    hipLaunchKernelGGL(floor_coords_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const float4 *>(pc), n, stride, reinterpret_cast<int4 *>(out));
+    return check_launch("u2mkd_floor_coords");
 }
 
 int u2mkd_unpack_keys(const int64_t *keys, int64_t n, int32_t *coords, u2mkd_stream_t s) {

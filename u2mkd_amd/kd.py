@@ -354,7 +354,10 @@ def kd_losses(outputs, targets, fov_mask, inverse_map, inds_s, num_pts, num_vox_
                                   keyframe_mask_full)
     x_vox, x_pix = outputs['stu']['x_vox'], outputs['stu']['x_pix']
     ld = {'ce_vox': crit.lovasz(x_vox, targets),
-          'ce_pix': crit.lovasz(x_pix[fov_mask], targets[fov_mask]),
+          # the reference compacts the rows a camera sees (`x_pix[fov_mask]`, two host synchronisations right after
+          # the forward); the criterion drops ignore-labelled rows itself (mask-based Lovasz, CE ignore_index), so
+          # the rows outside the field of view take the ignore label instead: same value, same gradient, no sync
+          'ce_pix': crit.lovasz(x_pix, torch.where(fov_mask, targets, torch.full_like(targets, crit.lovasz.ignore_index))),
           'kl': crit.kl(F.log_softmax(x_vox, dim=1), F.softmax(x_vox_t2s.detach(), dim=1)),
           'mse': outputs['stu']['mse_loss']}
     pts_feat_s = outputs['stu']['pts_feats'][0]

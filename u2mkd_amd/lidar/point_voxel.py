@@ -21,6 +21,12 @@ __all__ = ['initial_voxelize', 'point_to_voxel', 'voxel_to_point', 'fetch_idx', 
 
 def _floor_coords(pc, stride):
     """int32 (floor(xyz / s) * s, b) of float point coords [N,4]."""
+    if pc.is_cuda and pc.dtype == torch.float32 and pc.shape[1] == 4:
+        from .. import _lib as L
+        pc = pc.contiguous()
+        out = torch.empty(pc.shape[0], 4, dtype=torch.int32, device=pc.device)
+        L.call('u2mkd_floor_coords', L.ptr(pc), pc.shape[0], int(stride), L.ptr(out), L.stream())
+        return out
     xyz = torch.floor(pc[:, :3] / stride).int() * stride
     return torch.cat([xyz, pc[:, -1].int().view(-1, 1)], 1)
 
