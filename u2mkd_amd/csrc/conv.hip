@@ -1181,6 +1181,17 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     const int g = wgrad_g_target(n_rows, k) + k;
     U2_REQUIRE(workspace_bytes >= (size_t)g * ca * cb * sizeof(float), "u2mkd_conv_wgrad_pairs: workspace too small");
     hipStream_t st = as_stream(s);
+    // bf16x3 form (conv_wgrad_x3.hip): U2MKD_WGRAD_X3 = 0 off, 1 (default) the 64 x 64 shape, 2 every multiple of 64
+    static const int x3_mode = getenv("U2MKD_WGRAD_X3") ? atoi(getenv("U2MKD_WGRAD_X3")) : 1;
+    const bool x3_shape = x3_mode == 2 ? (ca % 64 == 0 && cb % 64 == 0) : (ca == 64 && cb == 64);
+    if (!b16 && x3_mode > 0 && x3_shape && conv_tp_arith(0) == 2 && conv_wgrad_x3_supported(ca, cb, k)) {
+        int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st);
+        if (rc) return rc;
+        const int64_t te = (int64_t)ca * cb;
+        hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(te, 64), k), dim3(256), 0, st,
+                           reinterpret_cast<float *>(workspace), plan, k, te, dw);
+        return check_launch("u2mkd_conv_wgrad_pairs");
+    }
     // 32*W-channel tiles per operand: 96-channel layers get exact 96-wide tiles (W = 3)
     auto pick = [](int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : (c <= 96 ? 3 : 4)); };
     const int wm = pick(ca), wn = pick(cb);

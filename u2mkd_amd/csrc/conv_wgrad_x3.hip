@@ -1,0 +1,221 @@
+// Weight gradient over the compacted pair list in bf16x3 arithmetic (gfx950, v_mfma_f32_16x16x32_bf16 +
+// ds_read_b64_tr_b16).
+//
+// dW[k] = sum over the pairs (i, j) of offset k of A_i^T B_j -- the dW half of torchsparse v1.4.0
+// convolution_backward_cuda behind every spnn.Conv3d of core/models/build_blocks.py:25-80.
+// conv_wgrad_pairs_kernel (conv.hip) does it on v_mfma_f32_16x16x4_f32 and sits at 82 % of the fp32 matrix pipe in
+// steady state (in-kernel stamps): only fewer matrix cycles can make it faster.  Here the product
+// runs in the bf16x3 arithmetic of conv_tp.hip: every fp32 element of BOTH gathered operands is split exactly into three
+// bf16 (h + m + l = x) and the six partial products above 2^-24 relative are accumulated in fp32 -- 24 MFMAs of 16
+// cycles per 32 pairs and 32 x 32 channels instead of 32 of 32 cycles.  What makes it pay this time (a first attempt,
+// round 2, was slower than the f32 kernel):
+//   * the split is by TRUNCATION (x & 0xffff0000, exact residuals): 2 and + 2 sub + 3 byte-permutes per two
+//     elements and plane instead of the convert / widen / subtract chain (~30 % fewer VALU instructions);
+//   * the pairs are the REDUCTION dimension of the MFMA, so both operands are needed channel-major while the
+//     gathers arrive pair-major: the planes are stored pair-major ([plane][pair][channel], one 8-byte store per
+//     plane and 4 channels) and read back with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group fetches
+//     4 pairs x 16 channels and every lane receives its channel's 4 pairs) -- two reads per operand fragment and
+//     plane, no shuffles;
+//   * ONE LDS image per workgroup (27 KB: 4 workgroups per CU) filled between two barriers, the gathered rows of the
+//     next two chunks in registers -- the other workgroups of the CU cover the fill.
+// Same plan, slabs and fixed-order reduction as the f32 kernel (deterministic); 64 x 64-channel tiles.
+#include "conv_internal.h"
+
+namespace u2mkd {
+
+typedef short wx_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWxRow = 144;                    // bytes per (plane, pair) row: 64 bf16 channels + 16 pad (2-way at worst)
+constexpr int kWxCP = 32;                      // pairs per step = the K of one MFMA
+constexpr int kWxOperand = 3 * kWxCP * kWxRow; // bytes of one operand's image: [3 planes][32 pairs][row]
+
+// x = h + m + l, each the upper 16 bits of an fp32 (a bf16), by truncation: the residuals are exact
+struct WxPlanes { uint2 h, m, l; };
+__device__ __forceinline__ WxPlanes wx_split4(const f32x4 &v) {
+    uint32_t x[4], h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = __float_as_uint(v[i]);
+        h[i] = x[i] & 0xffff0000u;
+        const float r1 = v[i] - __uint_as_float(h[i]);
+        m[i] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(m[i]);
+        l[i] = __float_as_uint(r2);            // <= 8 significant bits left: its upper half is exact
+    }
+    WxPlanes p;
+    // two bf16 per dword: element i in the low half, i+1 in the high half
+    p.h = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    p.m = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    p.l = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+    return p;
+}
+
+__device__ __forceinline__ wx_bf16x8 wx_frag(const char *base_lo, const char *base_hi) {
+    // 8 consecutive pairs of this lane's channel: two transposing reads of 4 pairs each
+    const wx_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wx_s16x4 __attribute__((address_space(3))) *)(base_lo));
+    const wx_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wx_s16x4 __attribute__((address_space(3))) *)(base_hi));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(wx_bf16x8, v);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
+                     const int32_t *__restrict__ pairs, const int32_t *__restrict__ plan, int K, int swap,
+                     float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [A | B][3][32][kWxRow]
+    const int w = blockIdx.x;
+    const int *wg = plan + 3 + K;
+    int k = 0, p_begin, p_end;
+    const int ch = plan[1];
+    {
+        const int l = min((int)(threadIdx.x & 63), K);
+        const int wgv = wg[l], kof = plan[2 + l];
+        const unsigned long long le = __ballot(wgv <= w) & ((2ULL << K) - 2ULL);
+        k = __builtin_amdgcn_readfirstlane(__popcll(le));
+        if (k >= K) return;
+        p_begin = __builtin_amdgcn_readlane(kof, k) + (w - __builtin_amdgcn_readlane(wgv, k)) * ch;
+        p_end = min(p_begin + ch, __builtin_amdgcn_readlane(kof, k + 1));
+    }
+    const int a0 = (blockIdx.y / ((cb + 63) / 64)) * 64, b0 = (blockIdx.y % ((cb + 63) / 64)) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gq = lane >> 4, li = lane & 15;                // 16-lane group = 8 pairs of the K dimension; lane = channel
+    const int wy = wave >> 1, wx = wave & 1;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // gather: 32 pairs x 16 chunks of 4 channels per operand = 512 chunks, 2 per thread and operand
+    f32x4 ra[2][2], rb[2][2];
+    int ia[2][2], ib[2][2];
+    auto load_idx = [&](int p0, int (&xa)[2], int (&xb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr = (tid + 256 * i) >> 4;
+            const int pp = min(p0 + pr, p_end - 1);
+            xa[i] = pairs[2 * (size_t)pp + (swap ? 1 : 0)];
+            xb[i] = pairs[2 * (size_t)pp + (swap ? 0 : 1)];
+        }
+    };
+    auto load_rows = [&](const int (&xa)[2], const int (&xb)[2], f32x4 (&va)[2], f32x4 (&vb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = ((tid + 256 * i) & 15) * 4;
+            va[i] = *reinterpret_cast<const f32x4 *>(a + (size_t)xa[i] * ca + min(a0 + c, ca - 4));
+            vb[i] = *reinterpret_cast<const f32x4 *>(b + (size_t)xb[i] * cb + min(b0 + c, cb - 4));
+        }
+    };
+    auto store_chunk = [&](int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int pr = f >> 4, c = (f & 15) * 4;
+            const bool live = p0 + pr < p_end;
+            const WxPlanes pa = wx_split4((live && a0 + c < ca) ? va[i] : zero);
+            const WxPlanes pb = wx_split4((live && b0 + c < cb) ? vb[i] : zero);
+            char *da = smem + pr * kWxRow + c * 2, *db = smem + kWxOperand + pr * kWxRow + c * 2;
+            *reinterpret_cast<uint2 *>(da) = pa.h;
+            *reinterpret_cast<uint2 *>(da + kWxCP * kWxRow) = pa.m;
+            *reinterpret_cast<uint2 *>(da + 2 * kWxCP * kWxRow) = pa.l;
+            *reinterpret_cast<uint2 *>(db) = pb.h;
+            *reinterpret_cast<uint2 *>(db + kWxCP * kWxRow) = pb.m;
+            *reinterpret_cast<uint2 *>(db + 2 * kWxCP * kWxRow) = pb.l;
+        }
+    };
+    auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // transposing read: lane 4q+p of a 16-lane group supplies row q (of 4 pairs), channels 4p .. 4p+3; lane i receives
+    // channel i's 4 pairs.  Group gq covers pairs 8 gq .. 8 gq + 7 (two reads).
+    const int tq = li >> 2, tp = li & 3;
+    auto multiply = [&]() __attribute__((always_inline)) {
+        wx_bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const char *base = smem + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wy + m) + 4 * tp) * 2;
+                fa[m][pl] = wx_frag(base, base + 4 * kWxRow);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const char *base = smem + kWxOperand + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wx + n) + 4 * tp) * 2;
+                fb[n][pl] = wx_frag(base, base + 4 * kWxRow);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x4 c = acc[m][n];
+                // the six partial products, low order first (plane 0 = h, 1 = m, 2 = l)
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][2], fb[n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                acc[m][n] = c;
+            }
+    };
+
+    // prologue: chunk 0 in the image, rows of chunk 1 and indices of chunk 2 in flight
+    load_idx(p_begin, ia[0], ib[0]);
+    load_idx(p_begin + kWxCP, ia[1], ib[1]);
+    load_rows(ia[0], ib[0], ra[0], rb[0]);
+    load_idx(p_begin + 2 * kWxCP, ia[0], ib[0]);
+    load_rows(ia[1], ib[1], ra[1], rb[1]);
+    store_chunk(p_begin, ra[0], rb[0]);
+    lds_barrier();
+    for (int p0 = p_begin; p0 < p_end; p0 += 2 * kWxCP) {
+        // even chunk c: rows c+1 in set 1, indices c+2 in set 0
+        load_idx(p0 + 3 * kWxCP, ia[1], ib[1]);
+        load_rows(ia[0], ib[0], ra[0], rb[0]);                 // rows of chunk c+2
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();                                         // every wave has read chunk c
+        store_chunk(p0 + kWxCP, ra[1], rb[1]);
+        lds_barrier();
+        // odd chunk c+1: rows c+2 in set 0, indices c+3 in set 1
+        load_idx(p0 + 4 * kWxCP, ia[0], ib[0]);
+        load_rows(ia[1], ib[1], ra[1], rb[1]);                 // rows of chunk c+3
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();                                            // (a range with an odd number of chunks multiplies zeros)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        store_chunk(p0 + 2 * kWxCP, ra[0], rb[0]);
+        lds_barrier();
+    }
+    // D[i = a channel][j = b channel]: row = 4 gq + reg, col = li
+    float *slab = slabs + (size_t)w * ca * cb;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ach = a0 + 16 * (2 * wy + m) + 4 * gq + reg;
+            if (ach < ca) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int bch = b0 + 16 * (2 * wx + n) + li;
+                    if (bch < cb) slab[(size_t)ach * cb + bch] = acc[m][n][reg];
+                }
+            }
+        }
+}
+
+bool conv_wgrad_x3_supported(int ca, int cb, int k) { return ca % 4 == 0 && cb % 4 == 0 && ca >= 4 && cb >= 4 && k <= 63; }
+
+int launch_conv_wgrad_x3(const float *a, int ca, const float *b, int cb, const int32_t *pairs, const int32_t *plan,
+                         int k, int swap, int g, float *slabs, hipStream_t st) {
+    const int tiles_a = (ca + 63) / 64, tiles_b = (cb + 63) / 64;
+    dim3 grid(g, tiles_a * tiles_b);
+    const size_t lds = (size_t)2 * kWxOperand;
+    hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), lds, st, a, ca, b, cb, pairs, plan, k, swap, slabs);
+    return check_launch("u2mkd_conv_wgrad_pairs");
+}
+
+}  // namespace u2mkd
