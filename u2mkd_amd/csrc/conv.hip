@@ -1181,9 +1181,10 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     const int g = wgrad_g_target(n_rows, k) + k;
     U2_REQUIRE(workspace_bytes >= (size_t)g * ca * cb * sizeof(float), "u2mkd_conv_wgrad_pairs: workspace too small");
     hipStream_t st = as_stream(s);
-    // bf16x3 form (conv_wgrad_x3.hip): U2MKD_WGRAD_X3 = 0 off, 1 (default) the 64 x 64 shape, 2 every multiple of 64
-    static const int x3_mode = getenv("U2MKD_WGRAD_X3") ? atoi(getenv("U2MKD_WGRAD_X3")) : 1;
-    const bool x3_shape = x3_mode == 2 ? (ca % 64 == 0 && cb % 64 == 0) : (ca == 64 && cb == 64);
+    // bf16x3 form (conv_wgrad_x3.hip, 64 x 64-channel tiles): U2MKD_WGRAD_X3 = 0 off, 1 the 64 x 64 shape only,
+    // 2 (default) every multiple of 64, 3 every shape of at least 32 x 32 channels (partial tiles masked)
+    static const int x3_mode = getenv("U2MKD_WGRAD_X3") ? atoi(getenv("U2MKD_WGRAD_X3")) : 2;
+    const bool x3_shape = x3_mode == 3 ? (ca >= 32 && cb >= 32) : x3_mode == 2 ? (ca % 64 == 0 && cb % 64 == 0) : (ca == 64 && cb == 64);
     if (!b16 && x3_mode > 0 && x3_shape && conv_tp_arith(0) == 2 && conv_wgrad_x3_supported(ca, cb, k)) {
         int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st);
         if (rc) return rc;
