@@ -1185,8 +1185,9 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     // 2 (default) every multiple of 64, 3 every shape of at least 32 x 32 channels (partial tiles masked)
     static const int x3_mode = getenv("U2MKD_WGRAD_X3") ? atoi(getenv("U2MKD_WGRAD_X3")) : 2;
     const bool x3_shape = x3_mode == 3 ? (ca >= 32 && cb >= 32) : x3_mode == 2 ? (ca % 64 == 0 && cb % 64 == 0) : (ca == 64 && cb == 64);
-    if (!b16 && x3_mode > 0 && x3_shape && conv_tp_arith(0) == 2 && conv_wgrad_x3_supported(ca, cb, k)) {
-        int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st);
+    if (x3_mode > 0 && x3_shape && (b16 || conv_tp_arith(0) == 2) && conv_wgrad_x3_supported(ca, cb, k)) {
+        // (bf16 rows: the same kernel without the split -- one plane, one MFMA per product)
+        int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st, b16);
         if (rc) return rc;
         const int64_t te = (int64_t)ca * cb;
         hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(te, 64), k), dim3(256), 0, st,

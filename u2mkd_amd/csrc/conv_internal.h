@@ -31,6 +31,6 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
 // Weight gradient in bf16x3 arithmetic (conv_wgrad_x3.hip): 64 x 64-channel tiles, slabs as the f32 kernel.
 bool conv_wgrad_x3_supported(int ca, int cb, int k);
 int launch_conv_wgrad_x3(const float *a, int ca, const float *b, int cb, const int32_t *pairs, const int32_t *plan,
-                         int k, int swap, int g, float *slabs, hipStream_t st);
+                         int k, int swap, int g, float *slabs, hipStream_t st, bool b16 = false);
 
 }  // namespace u2mkd

@@ -60,11 +60,15 @@ __device__ __forceinline__ wx_bf16x8 wx_frag(const char *base_lo, const char *ba
     return __builtin_bit_cast(wx_bf16x8, v);
 }
 
+// B16: a and b are BF16 rows (bf16 storage): no split, ONE plane in the image, one MFMA per product.
+template <bool B16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
                      const int32_t *__restrict__ pairs, const int32_t *__restrict__ plan, int K, int swap,
                      float *__restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [A | B][3][32][kWxRow]
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [A | B][3 (B16: 1)][32][kWxRow]
+    constexpr int NPL = B16 ? 1 : 3;
+    constexpr int OPB = NPL * kWxCP * kWxRow;                         // bytes of one operand's image
     const int w = blockIdx.x;
     const int *wg = plan + 3 + K;
     int k = 0, p_begin, p_end;
@@ -105,8 +109,15 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = ((tid + 256 * i) & 15) * 4;
-            va[i] = *reinterpret_cast<const f32x4 *>(a + (size_t)xa[i] * ca + min(a0 + c, ca - 4));
-            vb[i] = *reinterpret_cast<const f32x4 *>(b + (size_t)xb[i] * cb + min(b0 + c, cb - 4));
+            if (B16) {     // 4 bf16 channels = 8 bytes, kept in the first two dwords
+                const uint2 ua = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(a) + ((size_t)xa[i] * ca + min(a0 + c, ca - 4)) * 2);
+                const uint2 ub = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(b) + ((size_t)xb[i] * cb + min(b0 + c, cb - 4)) * 2);
+                va[i] = (f32x4){__uint_as_float(ua.x), __uint_as_float(ua.y), 0.f, 0.f};
+                vb[i] = (f32x4){__uint_as_float(ub.x), __uint_as_float(ub.y), 0.f, 0.f};
+            } else {
+                va[i] = *reinterpret_cast<const f32x4 *>(a + (size_t)xa[i] * ca + min(a0 + c, ca - 4));
+                vb[i] = *reinterpret_cast<const f32x4 *>(b + (size_t)xb[i] * cb + min(b0 + c, cb - 4));
+            }
         }
     };
     auto store_chunk = [&](int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
@@ -116,9 +127,15 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             const int f = tid + 256 * i;
             const int pr = f >> 4, c = (f & 15) * 4;
             const bool live = p0 + pr < p_end;
+            char *da = smem + pr * kWxRow + c * 2, *db = smem + OPB + pr * kWxRow + c * 2;
+            if (B16) {
+                const f32x4 xa = (live && a0 + c < ca) ? va[i] : zero, xb = (live && b0 + c < cb) ? vb[i] : zero;
+                *reinterpret_cast<uint2 *>(da) = make_uint2(__float_as_uint(xa[0]), __float_as_uint(xa[1]));
+                *reinterpret_cast<uint2 *>(db) = make_uint2(__float_as_uint(xb[0]), __float_as_uint(xb[1]));
+                continue;
+            }
             const WxPlanes pa = wx_split4((live && a0 + c < ca) ? va[i] : zero);
             const WxPlanes pb = wx_split4((live && b0 + c < cb) ? vb[i] : zero);
-            char *da = smem + pr * kWxRow + c * 2, *db = smem + kWxOperand + pr * kWxRow + c * 2;
             *reinterpret_cast<uint2 *>(da) = pa.h;
             *reinterpret_cast<uint2 *>(da + kWxCP * kWxRow) = pa.m;
             *reinterpret_cast<uint2 *>(da + 2 * kWxCP * kWxRow) = pa.l;
@@ -132,9 +149,9 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
     // channel i's 4 pairs.  Group gq covers pairs 8 gq .. 8 gq + 7 (two reads).
     const int tq = li >> 2, tp = li & 3;
     auto multiply = [&]() __attribute__((always_inline)) {
-        wx_bf16x8 fa[2][3], fb[2][3];
+        wx_bf16x8 fa[2][NPL], fb[2][NPL];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const char *base = smem + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wy + m) + 4 * tp) * 2;
@@ -142,7 +159,7 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const char *base = smem + kWxOperand + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wx + n) + 4 * tp) * 2;
+                const char *base = smem + OPB + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wx + n) + 4 * tp) * 2;
                 fb[n][pl] = wx_frag(base, base + 4 * kWxRow);
             }
         }
@@ -151,13 +168,17 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 f32x4 c = acc[m][n];
-                // the six partial products, low order first (plane 0 = h, 1 = m, 2 = l)
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][2], fb[n][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[n][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][1], fb[n][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                if (B16) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                } else {
+                    // the six partial products, low order first (plane 0 = h, 1 = m, 2 = l)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL - 1], fb[n][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][NPL - 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL / 2], fb[n][NPL / 2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL / 2], fb[n][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][NPL / 2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                }
                 acc[m][n] = c;
             }
     };
@@ -210,11 +231,15 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
 bool conv_wgrad_x3_supported(int ca, int cb, int k) { return ca % 4 == 0 && cb % 4 == 0 && ca >= 4 && cb >= 4 && k <= 63; }
 
 int launch_conv_wgrad_x3(const float *a, int ca, const float *b, int cb, const int32_t *pairs, const int32_t *plan,
-                         int k, int swap, int g, float *slabs, hipStream_t st) {
+                         int k, int swap, int g, float *slabs, hipStream_t st, bool b16) {
     const int tiles_a = (ca + 63) / 64, tiles_b = (cb + 63) / 64;
     dim3 grid(g, tiles_a * tiles_b);
-    const size_t lds = (size_t)2 * kWxOperand;
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), lds, st, a, ca, b, cb, pairs, plan, k, swap, slabs);
+    if (b16)
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(256), (size_t)2 * kWxCP * kWxRow, st, a, ca, b, cb, pairs,
+                           plan, k, swap, slabs);
+    else
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<false>, grid, dim3(256), (size_t)2 * kWxOperand, st, a, ca, b, cb, pairs, plan,
+                           k, swap, slabs);
     return check_launch("u2mkd_conv_wgrad_pairs");
 }
 
