@@ -19,6 +19,8 @@
 //   * ONE LDS image per workgroup (27 KB: 4 workgroups per CU) filled between two barriers, the gathered rows of the
 //     next two chunks in registers -- the other workgroups of the CU cover the fill.
 // Same plan, slabs and fixed-order reduction as the f32 kernel (deterministic); 64 x 64-channel tiles.
+#include <type_traits>
+
 #include "conv_internal.h"
 
 namespace u2mkd {
@@ -120,22 +122,22 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             }
         }
     };
-    auto store_chunk = [&](int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
+    auto store_impl = [&](auto FULL, int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
+        constexpr bool kFull = decltype(FULL)::value;          // a whole chunk inside the range and whole tiles: no masks
         const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = tid + 256 * i;
             const int pr = f >> 4, c = (f & 15) * 4;
-            const bool live = p0 + pr < p_end;
+            const bool live = kFull || p0 + pr < p_end;
+            const f32x4 xa = (kFull || (live && a0 + c < ca)) ? va[i] : zero, xb = (kFull || (live && b0 + c < cb)) ? vb[i] : zero;
             char *da = smem + pr * kWxRow + c * 2, *db = smem + OPB + pr * kWxRow + c * 2;
             if (B16) {
-                const f32x4 xa = (live && a0 + c < ca) ? va[i] : zero, xb = (live && b0 + c < cb) ? vb[i] : zero;
                 *reinterpret_cast<uint2 *>(da) = make_uint2(__float_as_uint(xa[0]), __float_as_uint(xa[1]));
                 *reinterpret_cast<uint2 *>(db) = make_uint2(__float_as_uint(xb[0]), __float_as_uint(xb[1]));
                 continue;
             }
-            const WxPlanes pa = wx_split4((live && a0 + c < ca) ? va[i] : zero);
-            const WxPlanes pb = wx_split4((live && b0 + c < cb) ? vb[i] : zero);
+            const WxPlanes pa = wx_split4(xa), pb = wx_split4(xb);
             *reinterpret_cast<uint2 *>(da) = pa.h;
             *reinterpret_cast<uint2 *>(da + kWxCP * kWxRow) = pa.m;
             *reinterpret_cast<uint2 *>(da + 2 * kWxCP * kWxRow) = pa.l;
@@ -143,6 +145,10 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             *reinterpret_cast<uint2 *>(db + kWxCP * kWxRow) = pb.m;
             *reinterpret_cast<uint2 *>(db + 2 * kWxCP * kWxRow) = pb.l;
         }
+    };
+    auto store_chunk = [&](int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
+        if (p0 + kWxCP <= p_end && a0 + 64 <= ca && b0 + 64 <= cb) store_impl(std::true_type{}, p0, va, vb);      // (uniform)
+        else store_impl(std::false_type{}, p0, va, vb);
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // transposing read: lane 4q+p of a 16-lane group supplies row q (of 4 pairs), channels 4p .. 4p+3; lane i receives
