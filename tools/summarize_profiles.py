@@ -36,12 +36,12 @@ t = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `be
      'N': meta['N'], 'P': meta['P'],
      'conv_tp_fwd_or_dgrad': traffic('conv_tp_kernel'),
      'weight_fragments': traffic('weight_fragments'),
-     'conv_wgrad_pairs': traffic('conv_wgrad_pairs_kernel'),
+     'conv_wgrad_pairs': traffic('conv_wgrad_x3_kernel') or traffic('conv_wgrad_pairs_kernel'),
      'wgrad_reduce': traffic('wgrad_pairs_reduce_kernel')}
 t['group_fwd_dgrad_wgrad'] = 2 * t['conv_tp_fwd_or_dgrad'] + t['weight_fragments'] + t['conv_wgrad_pairs'] + t['wgrad_reduce']
 json.dump(t, open(os.path.join(P, f'{rnd}_traffic.json'), 'w'), indent=1)
 print(json.dumps(t, indent=1))
-for k in ('conv_tp_kernel', 'conv_wgrad_pairs_kernel'):
+for k in ('conv_tp_kernel', 'conv_wgrad_x3_kernel'):
     busy, wave, mf = mean(k, 'SQ_BUSY_CYCLES'), mean(k, 'SQ_WAVE_CYCLES'), mean(k, 'SQ_VALU_MFMA_BUSY_CYCLES')
     print(k, {c: round(mean(k, c)) for c in ('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_LDS_BANK_CONFLICT', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_LDS', 'SQ_LDS_IDX_ACTIVE', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_VMEM', 'SQ_INSTS_LDS', 'SQ_INSTS_VALU', 'SQ_INSTS_VMEM_RD')})
     print(k, 'MFMA_BUSY/WAVE_CYCLES', mf / max(wave, 1), 'WAIT_ANY/WAVE', mean(k, 'SQ_WAIT_ANY') / max(wave, 1), 'WAIT_INST/WAVE', mean(k, 'SQ_WAIT_INST_ANY') / max(wave, 1))
