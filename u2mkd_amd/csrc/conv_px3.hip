@@ -112,17 +112,20 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             if (tid + l * NT < 512) {
-                px_bf16x4 h, m, lo;
+                // split by truncation (x & 0xffff0000; exact residuals), two bf16 packed per dword by a byte permute
+                uint32_t hb[4], mb[4], lb[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    __bf16 hh, mm, ll;
-                    px_split3(gg[l][c], hh, mm, ll);
-                    h[c] = hh; m[c] = mm; lo[c] = ll;
+                    const float x = gg[l][c];
+                    hb[c] = __float_as_uint(x) & 0xffff0000u;
+                    const float r1 = x - __uint_as_float(hb[c]);
+                    mb[c] = __float_as_uint(r1) & 0xffff0000u;
+                    lb[c] = __float_as_uint(r1 - __uint_as_float(mb[c]));
                 }
                 char *row = smem + (slot * 64 + crow[l]) * RS + 8 * cch[l];
-                *reinterpret_cast<px_bf16x4 *>(row) = h;
-                *reinterpret_cast<px_bf16x4 *>(row + 64) = m;
-                *reinterpret_cast<px_bf16x4 *>(row + 128) = lo;
+                *reinterpret_cast<uint2 *>(row) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+                *reinterpret_cast<uint2 *>(row + 64) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+                *reinterpret_cast<uint2 *>(row + 128) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
             }
         }
     };
