@@ -189,30 +189,58 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     const int G = (int)gridDim.x, wg = (int)blockIdx.x;
     const int n_rd = (n_it + G - 1) / G;
     const bool asc = (kflip & 4) != 0;          // round order (launch_conv_tp: U2MKD_TP_ORDER)
+    // this workgroup's next item at or after round rq (-1: none)
+    auto next_item = [&](int &rq) __attribute__((always_inline)) {
+        for (; rq < n_rd; ++rq) {
+            const int rd = asc ? rq : n_rd - 1 - rq;
+            const int t = rd * G + ((rd & 1) ? G - 1 - wg : wg);
+            if (t < n_it) return t;
+        }
+        return -1;
+    };
+    auto item_code = [&](int t) __attribute__((always_inline)) { return items ? items[t] : (t << 4); };
+    // neighbour indices of an item's rows: one burst of independent loads, KPW per thread
+    auto load_nbr = [&](int code_, int lane_, int wave_, int (&vv)[KPW]) __attribute__((always_inline)) {
+        const int R_ = T >> (code_ & 3);
+        const int64_t row = rr_.begin + (int64_t)(code_ >> 4) * T + ((code_ >> 2) & 3) * R_ + lane_;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int kk = wave_ + i * NW;
+            vv[i] = (kk < K && lane_ < R_ && row < n_out) ? nbr[(int64_t)kk * ld + row] : -1;
+        }
+    };
+    int rq = 0;
+    int it = next_item(rq);
+    if (it < 0) return;
+    int code = item_code(it);
+    constexpr bool PF = CIN * NBW <= 64;      // (the 8 extra registers cost the wide instantiations a wave per SIMD)
+    int v[KPW];
+    if (PF) {
+        int t0_ = threadIdx.x;
+        asm volatile("" : "+v"(t0_));
+        load_nbr(code, t0_ & 63, __builtin_amdgcn_readfirstlane(t0_ >> 6), v);
+    }
 #pragma nounroll
-    for (int rq = 0; rq < n_rd; ++rq) {
-    const int rd = asc ? rq : n_rd - 1 - rq;
-    const int it = rd * G + ((rd & 1) ? G - 1 - wg : wg);
-    if (it >= n_it) continue;
+    while (true) {
+    // the item after this one: its code now (a scalar load), its neighbour indices once this item's compaction is
+    // done -- they arrive during the block walk, so the next set-up starts from registers instead of a memory
+    // round trip (set-up + pipeline fill of an item are ~4 us of pure latency for a workgroup with two items)
+    int rq_n = rq + 1;
+    const int it_n = next_item(rq_n);
+    const int code_n = it_n >= 0 ? item_code(it_n) : 0;
     // the lane index is re-derived behind an opaque asm in every round: otherwise the compiler hoists every
     // lane-dependent address out of the item loop and keeps it live (180 VGPRs instead of 118: 2 waves per SIMD)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int code = items ? items[it] : (it << 4);
     const int R = T >> (code & 3);                        // rows of this item
     const int64_t row0 = rr_.begin + (int64_t)(code >> 4) * T + ((code >> 2) & 3) * R;
     if (STAMP) { t_rt0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_amdgcn_s_memtime(); n_blocks = 0; }
 
-    // ---- 1. neighbour indices of the tile (one burst of independent loads), compaction per offset
-    int v[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        int kk = wave + i * NW;
-        int64_t row = row0 + lane;
-        v[i] = (kk < K && lane < R && row < n_out) ? nbr[(int64_t)kk * ld + row] : -1;
-    }
+    // ---- 1. compaction per offset of the tile's neighbour indices (in v: loaded before the loop / during the
+    // previous item's walk)
+    if (!PF) load_nbr(code, lane, wave, v);
     for (int e = tid; e < T * OS / 4; e += NT) reinterpret_cast<float4 *>(s_out)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = tid; e < T; e += NT) {
         int64_t row = row0 + e;
@@ -240,6 +268,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         }
     }
     __syncthreads();
+    int vn[PF ? KPW : 1];
+    if (PF && it_n >= 0) load_nbr(code_n, lane, wave, reinterpret_cast<int (&)[KPW]>(vn));
 
     if (STAMP) t_c1 = __builtin_amdgcn_s_memtime();
     // ---- 2. the tile's (offset, 16-pair block) sequence as a flat list: descriptor = offset << 8 | block.
@@ -504,6 +534,12 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = (unsigned long long)n_blocks; o[7] = (unsigned long long)code;
     }
     __syncthreads();      // the next item re-initialises the LDS tile
+    if (it_n < 0) break;
+    rq = rq_n; it = it_n; code = code_n;
+    if (PF) {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) v[i] = vn[PF ? i : 0];
+    }
     }
 }
 
