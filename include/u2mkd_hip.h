@@ -196,6 +196,12 @@ int u2mkd_conv_forward_pairs_x3(const float *in, int64_t n_in, int32_t cin, cons
  * nn.Linear's [cout, cin]; y must hold ceil(n / 64) * 64 rows (rows >= n receive the bias). */
 int u2mkd_linear_forward(const float *x /*[n,cin]*/, int64_t n, int32_t cin, const float *w /*[cout,cin]*/, int32_t cout,
                          const float *bias /*[cout] or NULL*/, int32_t kc, float *y, u2mkd_stream_t s);
+/* The same product in bf16x3 arithmetic (csrc/conv_px3.hip, identity pair list): wf = the fragment-order weights
+ * of u2mkd_weight_fragments(w, 1, cout_l, cin_l, ...) for nn.Linear's w [cout_l, cin_l] -- orientation 1
+ * (transpose = 0) for the forward y = x w^T, orientation 0 (transpose = 1) for the input gradient dx = dy w; cin
+ * and cout as u2mkd_conv_pairs_x3_supported asks.  y holds exactly n rows.                                      */
+int u2mkd_linear_forward_x3(const float *x /*[n,cin]*/, int64_t n, int32_t cin, const void *wf, int32_t cout,
+                            const float *bias /*[cout] or NULL*/, float *y /*[n,cout]*/, u2mkd_stream_t s);
 /* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
  * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,

@@ -280,9 +280,11 @@ def test_pair_schedule_is_the_padded_rulebook(F):
 
 
 @pytest.mark.parametrize('n,cin,cout,bias', [(5000, 32, 256, True), (80000, 256, 128, True), (777, 128, 96, False),
-                                             (64, 4, 4, True), (1, 96, 20, True), (130, 48, 64, False)])
+                                             (64, 4, 4, True), (1, 96, 20, True), (130, 48, 64, False),
+                                             (333, 64, 512, True), (1, 32, 32, True), (20001, 96, 96, False)])
 def test_linear_matches_torch_cpu(F, n, cin, cout, bias):
-    """LinearFunction (pair kernel dense mode + pair-list wgrad) vs nn.functional.linear in fp32 on the CPU."""
+    """LinearFunction (bf16x3 pair kernel dense mode for widths that are multiples of 32, the f32 pair kernel's
+    otherwise, + pair-list wgrad) vs nn.functional.linear in fp32 on the CPU."""
     torch.manual_seed(n + cin)
     x = torch.randn(n, cin)
     w = torch.randn(cout, cin) / cin ** 0.5

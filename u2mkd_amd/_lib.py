@@ -47,6 +47,7 @@ SIGNATURES = {
     'u2mkd_conv_pairs_x3_supported': (_i32, [_i32, _i32]),
     'u2mkd_conv_forward_pairs_x3': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_linear_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _p, _p]),
+    'u2mkd_linear_forward_x3': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

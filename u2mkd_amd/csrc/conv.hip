@@ -1129,6 +1129,18 @@ int u2mkd_linear_forward(const float *x, int64_t n, int32_t cin, const float *w,
     return check_launch("u2mkd_linear_forward");
 }
 
+int u2mkd_linear_forward_x3(const float *x, int64_t n, int32_t cin, const void *wf, int32_t cout, const float *bias,
+                            float *y, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(x && wf && y, "u2mkd_linear_forward_x3: null pointer");
+    U2_REQUIRE(n > 0 && n < ((int64_t)1 << 31) - 64, "u2mkd_linear_forward_x3: %lld rows out of range", (long long)n);
+    int rc = launch_linear_px3("u2mkd_linear_forward_x3", x, n, cin, reinterpret_cast<const float *>(wf), cout, bias, y,
+                               as_stream(s));
+    U2_REQUIRE(rc >= 0, "u2mkd_linear_forward_x3: cin=%d and cout=%d must be multiples of 32 "
+               "(ask u2mkd_conv_pairs_x3_supported first)", cin, cout);
+    return rc;
+}
+
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,
                             u2mkd_stream_t s) {
     if (n_rows == 0) return 0;

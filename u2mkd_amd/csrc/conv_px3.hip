@@ -48,18 +48,22 @@ __device__ __forceinline__ px_bf16x8 px_bf8(const float4 &x) {
     return __builtin_bit_cast(px_bf16x8, v);
 }
 
-template <int NW, int NBW>
+// DENSE (nn.Linear over point features, the learner / point_transforms MLPs of spvcnn.py:58-74 and tsd_full.py): the
+// "pair list" is the identity -- tile t = rows 64 t .. 64 t + 63 of `in`, one offset -- the bias is added at the
+// store and rows past n_rows are not written (y = the [n_rows, cout] output itself, no scratch rows).
+template <int NW, int NBW, bool DENSE = false>
 __global__ void __launch_bounds__(64 * NW)
 conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wf, int cout,
                 const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
-                const int32_t *__restrict__ n_tiles, float *__restrict__ y) {
+                const int32_t *__restrict__ n_tiles, float *__restrict__ y, const float *__restrict__ bias = nullptr,
+                int n_rows = 0) {
     constexpr int NT = 64 * NW, TN = 16 * NW * NBW;
     constexpr int RS = 208;                       // bytes per row of the LDS image: 3 planes x 32 bf16 + 16 pad
     constexpr int LPT = (512 + NT - 1) / NT;      // 16-byte chunks a thread gathers per step (64 rows x 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int ntile = *n_tiles;
+    const int ntile = DENSE ? (n_rows + 63) / 64 : *n_tiles;
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntile);
     if (t0 >= t1) return;
@@ -90,7 +94,14 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     auto load_idx = [&](int t, int (&ix)[LPT]) __attribute__((always_inline)) {
         const int tt = min(t, t1 - 1);
 #pragma unroll
-        for (int l = 0; l < LPT; ++l) ix[l] = pair_idx[(size_t)tt * 64 + crow[l]];
+        for (int l = 0; l < LPT; ++l) {
+            if (DENSE) {
+                const int row = tt * 64 + crow[l];
+                ix[l] = row < n_rows ? row : 0;
+            } else {
+                ix[l] = pair_idx[(size_t)tt * 64 + crow[l]];
+            }
+        }
     };
     auto issue_G = [&](const int (&ix)[LPT], int s, f32x4 (&gg)[LPT]) __attribute__((always_inline)) {
 #pragma unroll
@@ -135,7 +146,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         for (int p = 0; p < 3; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto tile_offset = [&](int t) __attribute__((always_inline)) { return tile_k[min(t, t1 - 1)]; };
+    auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[min(t, t1 - 1)]; };
 
     // positions (tile, step) of flattened step i + d; advance = next 32-channel step, then next tile
     int tc = t0, sc = 0;                 // step i   (multiplied)
@@ -200,8 +211,16 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const int col = 16 * (cbw + n) + 4 * q;
-                    if (cbw + n < ncb)
+                    if (DENSE) {
+                        const int row = tc * 64 + 16 * rb + r;
+                        if (cbw + n < ncb && row < n_rows) {
+                            f32x4 o = acc[rb][n];
+                            if (bias) o += *reinterpret_cast<const f32x4 *>(bias + col);
+                            *reinterpret_cast<f32x4 *>(y + (size_t)row * cout + col) = o;
+                        }
+                    } else if (cbw + n < ncb) {
                         *reinterpret_cast<f32x4 *>(y + ((size_t)tc * 64 + 16 * rb + r) * cout + col) = acc[rb][n];
+                    }
                     acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
         }
@@ -238,6 +257,27 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
         hipLaunchKernelGGL((conv_px3_kernel<3, 2>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
     else
         hipLaunchKernelGGL((conv_px3_kernel<4, 2>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
+    return check_launch(who);
+}
+
+// y[n_rows, cout] = in[n_rows, cin] x B (+ bias), B in the arith-2 fragment order of ONE offset
+int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
+                      const float *bias, float *y, hipStream_t st) {
+    if (!conv_px3_supported(cin, cout)) return -1;
+    const bool w3 = cout % 96 == 0 && cout % 128 != 0;
+    const int tn = w3 ? 96 : 128;
+    const int gy = (int)ceil_div(cout, tn);
+    int64_t gx = ceil_div(n_rows, 64);
+    const int64_t cap_x = 3 * 256;
+    if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
+    const size_t lds = (size_t)2 * 64 * 208;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    if (w3)
+        hipLaunchKernelGGL((conv_px3_kernel<3, 2, true>), grid, dim3(192), lds, st, in, cin, wf, cout, nullptr, nullptr, nullptr,
+                           y, bias, (int)n_rows);
+    else
+        hipLaunchKernelGGL((conv_px3_kernel<4, 2, true>), grid, dim3(256), lds, st, in, cin, wf, cout, nullptr, nullptr, nullptr,
+                           y, bias, (int)n_rows);
     return check_launch(who);
 }
 

@@ -16,6 +16,7 @@ from torch import nn
 
 from . import torchsparse
 from .camera import BNReluConv, SwiftNetRes18
+from .graphs import PieceCache, StaticPiece
 from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c_scatter
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
@@ -101,11 +102,36 @@ class StudentMSP2IFM(nn.Module):
         self.run_pix_decoder = run_pix_decoder
         self.adapt_layer = None          # attached by TSDFull (tsd_full.py:576-580)
 
-    def _camera_stage(self, x_in, idx):
+    def _camera_stage_eager(self, x_in, idx):
         x_o, skip_o = self.pix_branch.forward_resblock(x_in, getattr(self.pix_branch, 'layer%d' % (idx + 1)))
         if idx == len(self.vox_downs) - 1:
             skip_o = self.pix_branch.spp(skip_o)
         return x_o, skip_o
+
+    def _piece(self, name):
+        """The image-shaped (static-shape) pieces of the camera side as hipGraph-replayable callables
+        (graphs.StaticPiece; eager whenever a call does not qualify).  Built on first use; not modules."""
+        pieces = self.__dict__.setdefault('_pieces', PieceCache())
+        if name not in pieces:
+            pb, last = self.pix_branch, len(self.vox_downs) - 1
+            if name == 'head':
+                fn, mods = (lambda im: self._camera_stage_eager(pb.forward_stem(im), 0)), [pb.conv1, pb.bn1, pb.layer1]
+            elif name.startswith('stage'):
+                idx = int(name[5:])
+                fn = lambda x_in, idx=idx: self._camera_stage_eager(x_in, idx)                    # noqa: E731
+                mods = [getattr(pb, 'layer%d' % (idx + 1))] + ([pb.spp] if idx == last else [])
+            elif name.startswith('l2c'):
+                blk = self.l2c_fusion_blocks[int(name[3:])]
+                fn, mods = (lambda fmap, skip: blk(fmap, skip)), [blk]
+            else:
+                assert name == 'decoder', name
+                fn = lambda *feats: self.classifier_pix(pb.forward_up(list(feats), im_size=self._im_size))   # noqa: E731
+                mods = [pb.upsample, self.classifier_pix]
+            pieces[name] = StaticPiece(name, fn, mods)
+        return pieces[name]
+
+    def _camera_stage(self, x_in, idx):
+        return self._piece('head')(x_in) if idx == 0 else self._piece('stage%d' % idx)(x_in)
 
     def camera_head(self, in_mod):
         """SwiftNet stem + layer1 (everything of the camera branch ahead of the first fusion point) queued on the
@@ -113,7 +139,7 @@ class StudentMSP2IFM(nn.Module):
         im = in_mod['images']
         im = im.reshape(-1, *im.shape[2:])
         return _Fork(im, 'camera', _CAMERA_STREAM).on_side(
-            lambda: self._camera_stage(self.pix_branch.forward_stem(im), 0), im)
+            lambda: self._camera_stage(im, 0), im)
 
     def forward(self, in_mod):
         x = in_mod['lidar']
@@ -159,7 +185,7 @@ class StudentMSP2IFM(nn.Module):
 
             # LiDAR -> camera: multi-scale scatter-mean of the point features into every camera's map
             l2c_feat_map = l2c_scatter(pts_feat.F, pixel_coordinates, masks, ifh, ifw, n_stage - idx)
-            x_im, skip = self.l2c_fusion_blocks[idx](l2c_feat_map, skip)
+            x_im, skip = self._piece('l2c%d' % idx)(l2c_feat_map, skip)
             img_feats.append(skip)
 
             # camera -> LiDAR: bilinear gather, later cameras overwrite; points no camera sees take the
@@ -174,9 +200,10 @@ class StudentMSP2IFM(nn.Module):
         # the pixel decoder (camera side) next to the voxel decoder (LiDAR side)
         x_pix = None
         if self.run_pix_decoder:
+            self.__dict__['_im_size'] = (ih, iw)
+
             def pix_decoder():
-                up = self.pix_branch.forward_up(img_feats, im_size=(ih, iw))
-                fmap = self.classifier_pix(up)
+                fmap = self._piece('decoder')(*img_feats)
                 fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
                 return feature_fetch(masks, pixel_coordinates, fmap)
             x_pix = on_side(pix_decoder, *img_feats)

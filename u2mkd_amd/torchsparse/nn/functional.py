@@ -570,7 +570,7 @@ def _weight_layout(weight, transpose, fragments):
     teacher, inference), trained weights are re-laid out per call."""
     if not transpose and not fragments:
         return weight
-    k, r, c = weight.shape
+    k, r, c = weight.shape if weight.dim() == 3 else (1,) + tuple(weight.shape)     # 2-D: nn.Linear's [out, in], one offset
     frozen = not weight.requires_grad
     stamp = (weight._version, weight.data_ptr())
     if fragments:
@@ -619,6 +619,24 @@ def _identity_pairs(n, device):
     return hit
 
 
+_LINEAR_X3 = os.environ.get('U2MKD_LINEAR_X3', '1') != '0'
+
+
+def _dense_x3_ok(cin, cout):
+    return _PAIRS_X3 and _LINEAR_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(cin, cout))
+
+
+def _dense_x3(x, weight, forward, bias=None):
+    """x @ weight.T (+ bias) (forward) or x @ weight (the input gradient) for nn.Linear's weight [out, in] on the
+    bf16x3 pair kernel's dense mode; the fragment-order weights of both orientations come from one cached launch."""
+    n = x.shape[0]
+    cout = weight.shape[0] if forward else weight.shape[1]
+    wf = _weight_layout(weight, not forward, True)
+    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+    L.call('u2mkd_linear_forward_x3', L.ptr(x), n, x.shape[1], L.ptr(wf), cout, L.ptr(bias), L.ptr(y), L.stream())
+    return y
+
+
 def _dense(x, w_oc_ic, bias=None):
     """rows of x [n, cin] times w^T, w = [cout, cin] (+ bias) on the MFMA pair pipeline."""
     n, cin = x.shape
@@ -645,7 +663,9 @@ class LinearFunction(Function):
         ctx.has_bias = bias is not None
         if x.shape[0] == 0:
             return x.new_zeros(0, weight.shape[0])
-        return _dense(x, weight, bias.contiguous().float() if bias is not None else None)
+        b = bias.contiguous().float() if bias is not None else None
+        ctx.x3 = _dense_x3_ok(weight.shape[1], weight.shape[0])
+        return _dense_x3(x, weight, True, b) if ctx.x3 else _dense(x, weight, b)
 
     @staticmethod
     def backward(ctx, g):
@@ -656,7 +676,9 @@ class LinearFunction(Function):
         gx = gw = gb = None
         if n == 0:
             return x.new_zeros(x.shape), torch.zeros_like(weight), (weight.new_zeros(cout) if ctx.has_bias else None)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.x3:
+            gx = _dense_x3(g, weight, False)
+        elif ctx.needs_input_grad[0]:
             w_t = torch.empty(1, cin, cout, dtype=torch.float32, device=g.device)     # [cin][cout] = W^T rows
             L.call('u2mkd_transpose_weights', L.ptr(weight), 1, cout, cin, L.ptr(w_t), L.stream())
             gx = _dense(g, w_t[0])
