@@ -400,6 +400,28 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
                                   void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
                                   float *dtk, float *dtv, u2mkd_stream_t s);
 
+/* ---- BatchNorm2d over NCHW maps, fused with the ReLU / residual add that follow it (csrc/bn2d.hip) -----------------
+ * Replaces nn.BatchNorm2d -> nn.ReLU (and bn2(conv2(.)) + identity -> ReLU of BasicBlock) in the SwiftNet-18 camera
+ * branch and the LiDAR->camera fusion convs (core/models/image_branch/swiftnet.py:20-50,114-341; the L2C blocks of
+ * core/models/nuscenes/spvcnn_swiftnet18_spformer_tsd_full.py), i.e. torch.nn.functional.batch_norm +
+ * relu / add on [b, c, h*w] fp32 maps.  y = relu?((x - mean) * invstd * gamma + beta [+ res]); training mode uses
+ * the batch statistics (biased variance) and updates running_mean / running_var (momentum, unbiased variance) and
+ * num_batches_tracked when they are given; gamma / beta / res / running_* may be NULL.  Deterministic.            */
+size_t u2mkd_bn2d_workspace_bytes(int64_t b, int32_t c, int64_t hw);
+int u2mkd_bn2d_train_forward(const float *x, const float *res, int64_t b, int32_t c, int64_t hw, const float *gamma,
+                             const float *beta, float eps, float momentum, int32_t relu, float *running_mean,
+                             float *running_var, int64_t *num_batches_tracked, void *workspace,
+                             float *mean /*[c] out*/, float *invstd /*[c] out*/, float *y, u2mkd_stream_t s);
+int u2mkd_bn2d_eval_forward(const float *x, const float *res, int64_t b, int32_t c, int64_t hw, const float *gamma,
+                            const float *beta, float eps, int32_t relu, const float *running_mean,
+                            const float *running_var, float *y, u2mkd_stream_t s);
+/* dx, dgamma = sum dy' * xhat, dbeta = sum dy', dres = dy' (dy' = dy masked by the fused ReLU, recomputed from x and
+ * res); batch_stats = 0: the statistics were constants (evaluation mode), dx = dy' * gamma * invstd.              */
+int u2mkd_bn2d_backward(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                        const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                        int32_t batch_stats, void *workspace, float *dgamma, float *dbeta, float *dx,
+                        float *dres /*or NULL*/, u2mkd_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

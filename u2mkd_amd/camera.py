@@ -1,20 +1,101 @@
 """SwiftNet-18 camera branch (row a13; core/models/image_branch/swiftnet.py:20-50, 114-341).
 
-Plain torch.nn: the dense 2D convolutions ride PyTorch-ROCm / MIOpen as the north star
-prescribes.  ResNet-18 encoder whose 7x7 stem has stride 1 (feature
+The dense 2D convolutions ride PyTorch-ROCm / MIOpen as the north star prescribes; the BatchNorm2d
+layers (and the ReLU / residual add that follow them) run on the HIP kernels of csrc/bn2d.hip when the
+map is an fp32 NCHW tensor on the device, and on torch.nn otherwise (CPU, autocast, SyncBatchNorm).
+ResNet-18 encoder whose 7x7 stem has stride 1 (feature
 maps are H/2 after the stem), pre-activation lateral skips, a spatial pyramid pooling
 bottleneck (grids 8/4/2/1 scaled by the aspect ratio, BN momentum 0.012) and a 3-level
 up-sampling decoder.  Module / parameter names equal the reference's, so its ImageNet and
 U2MKD checkpoints load unchanged."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-__all__ = ['SwiftNetRes18', 'SwiftNetResNet', 'BNReluConv']
+__all__ = ['SwiftNetRes18', 'SwiftNetResNet', 'BNReluConv', 'BatchNorm2d', 'bn_act']
+
+_HIP_BN2D = os.environ.get('U2MKD_BN2D', '1') != '0'
 
 
 def _up(x, size):
     return F.interpolate(x, size, mode='bilinear', align_corners=True)
+
+
+class _BatchNorm2dFunction(torch.autograd.Function):
+    """relu?(batch_norm(x) [+ res]) on csrc/bn2d.hip (statistics, normalisation, residual add and ReLU in three
+    passes over the map; the backward recomputes the ReLU mask from x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, bn, relu):
+        from . import _lib as L
+        b, c, h, w = x.shape
+        hw = h * w
+        y = torch.empty_like(x)
+        st = L.stream()
+        batch_stats = bn.training or bn.running_mean is None
+        if batch_stats:
+            ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=x.device)
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty_like(mean)
+            track = bn.training and bn.running_mean is not None
+            L.call('u2mkd_bn2d_train_forward', L.ptr(x), L.ptr(res), b, c, hw, L.ptr(weight), L.ptr(bias), bn.eps,
+                   bn.momentum if track else 0.0, int(relu), L.ptr(bn.running_mean if track else None),
+                   L.ptr(bn.running_var if track else None), L.ptr(bn.num_batches_tracked if track else None),
+                   L.ptr(ws), L.ptr(mean), L.ptr(invstd), L.ptr(y), st)
+        else:
+            mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+            L.call('u2mkd_bn2d_eval_forward', L.ptr(x), L.ptr(res), b, c, hw, L.ptr(weight), L.ptr(bias), bn.eps, int(relu),
+                   L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(y), st)
+        ctx.save_for_backward(x, weight, bias, res, mean, invstd)
+        ctx.relu, ctx.batch_stats = bool(relu), batch_stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib as L
+        x, weight, bias, res, mean, invstd = ctx.saved_tensors
+        b, c, h, w = x.shape
+        hw = h * w
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if res is not None else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=x.device)
+        L.call('u2mkd_bn2d_backward', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd), L.ptr(weight),
+               L.ptr(bias), int(ctx.relu), int(ctx.batch_stats), L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.ptr(dres),
+               L.stream())
+        return dx, (dgamma if weight is not None else None), (dbeta if bias is not None else None), dres, None, None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) whose forward can take the ReLU and the residual
+    add that follow it: ``relu?(bn(x) [+ residual])`` -- one fused HIP pass on the device, torch.nn elsewhere."""
+
+    def forward(self, x, relu=False, residual=None):
+        if (_HIP_BN2D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+                and not torch.is_autocast_enabled() and (self.momentum is not None or not self.training)
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape))):
+            if residual is not None:
+                residual = residual.contiguous()
+            return _BatchNorm2dFunction.apply(x, self.weight, self.bias, residual, self, relu)
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+def bn_act(bn, x, relu=False, residual=None):
+    """relu?(bn(x) [+ residual]) for any BatchNorm flavour (this file's fused one, or what convert_sync_batchnorm
+    made of it)."""
+    if isinstance(bn, BatchNorm2d):
+        return bn(x, relu, residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -23,24 +104,29 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out), out          # (activated, pre-activation skip)
+        # relu(bn2(conv2(relu(bn1(conv1(x))))) + identity): the reference's ReLU is in place, so the "pre-activation
+        # skip" it returns next to the activated map IS the activated map (swiftnet.py BasicBlock.forward)
+        out = bn_act(self.bn1, self.conv1(x), relu=True)
+        out = bn_act(self.bn2, self.conv2(out), relu=True, residual=x if self.downsample is None else self.downsample(x))
+        return out, out
 
 
 class BNReluConv(nn.Sequential):
     def __init__(self, cin, cout, k=3, bn_momentum=0.1):
         super().__init__()
-        self.add_module('norm', nn.BatchNorm2d(cin, momentum=bn_momentum))
+        self.add_module('norm', BatchNorm2d(cin, momentum=bn_momentum))
         self.add_module('relu', nn.ReLU(inplace=True))
         self.add_module('conv', nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2, bias=False))
+
+    def forward(self, x):
+        return self.conv(bn_act(self.norm, x, relu=True))
 
 
 class SpatialPyramidPooling(nn.Module):
@@ -83,7 +169,7 @@ class SwiftNetResNet(nn.Module):
         self.inplanes = 64
         self.img_cs = [64, 64, 128, 256, num_features[0]]
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         skips = []
@@ -113,7 +199,7 @@ class SwiftNetResNet(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes:
             downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
-                                       nn.BatchNorm2d(planes))
+                                       BatchNorm2d(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
@@ -127,7 +213,7 @@ class SwiftNetResNet(nn.Module):
         return x, skip
 
     def forward_stem(self, image):
-        return self.maxpool(self.relu(self.bn1(self.conv1(image))))
+        return self.maxpool(bn_act(self.bn1, self.conv1(image), relu=True))
 
     def forward_down(self, image):
         x = self.forward_stem(image)

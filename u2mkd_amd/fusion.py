@@ -24,6 +24,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .camera import BatchNorm2d, bn_act
+
 __all__ = ['IA_Layer', 'Atten_Fusion_Conv', 'L2CAILayer', 'L2CFusion', 'feature_gather', 'c2l_gather',
            'l2c_scatter', 'feature_fetch', 'l2c_scatter_torch', 'c2l_gather_torch']
 
@@ -91,21 +93,21 @@ class L2CAILayer(nn.Module):
         super().__init__()
         self.ic, self.pc = channels
         rc = self.ic // 4
-        self.conv1 = nn.Sequential(nn.Conv2d(self.pc, self.ic, 1), nn.BatchNorm2d(self.ic), nn.ReLU(True))
+        self.conv1 = nn.Sequential(nn.Conv2d(self.pc, self.ic, 1), BatchNorm2d(self.ic), nn.ReLU(True))
         self.fc1 = nn.Conv2d(self.ic, rc, kernel_size=1)
         self.fc2 = nn.Conv2d(self.pc, rc, kernel_size=1)
         self.fc3 = nn.Conv2d(rc, 1, kernel_size=1)
 
     def forward(self, img_feats, point_feats):
         att = torch.sigmoid(self.fc3(torch.tanh(self.fc1(img_feats.contiguous()) + self.fc2(point_feats.contiguous()))))
-        return self.conv1(point_feats) * att
+        return bn_act(self.conv1[1], self.conv1[0](point_feats), relu=True) * att
 
 
 class L2CFusion(nn.Module):
     def __init__(self, inplanes_I, inplanes_P, outplanes):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes_I + inplanes_I, outplanes, kernel_size=1)
-        self.bn1 = nn.BatchNorm2d(outplanes)
+        self.bn1 = BatchNorm2d(outplanes)
         self.l2c_ai_layer = L2CAILayer(channels=[inplanes_I, inplanes_P])
 
     def forward(self, point_features, img_features):
