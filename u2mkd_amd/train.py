@@ -93,7 +93,7 @@ def kd_batch_to_device(b, device='cuda'):
     s, t = b['student'], b['teacher']
     dev = torch.device(device)
     f = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-    return {
+    out = {
         's_feats': f(s['feats']), 's_coords': f(s['coords']), 'targets': f(s['targets']),
         'images': f(s['images']).permute(0, 1, 4, 2, 3).contiguous(),
         'pixel_coordinates': [f(c) for c in s['pixel_coordinates']], 'masks': [f(m) for m in s['masks']],
@@ -102,6 +102,12 @@ def kd_batch_to_device(b, device='cuda'):
         'num_pts': list(t['num_pts']), 'num_vox_t': list(t['num_vox']),
         'keyframe_mask_full': f(t['keyframe_mask_full']) if 'keyframe_mask_full' in t else None,
     }
+    if dev.type == 'cuda':
+        # "the batch is on the device": what the frozen teacher's forward of this batch has to wait for -- not for
+        # the previous step's backward and optimizer, which precede it on the main stream (kd.TSDFull.forward)
+        out['ready'] = torch.cuda.Event()
+        out['ready'].record(torch.cuda.current_stream(dev))
+    return out
 
 
 class KDStep:
@@ -126,7 +132,7 @@ class KDStep:
     def __call__(self, d):
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
                'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
-        tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
+        tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords']), 'ready': d.get('ready')}
         with self.amp.autocast():
             out = self.net({'student': stu, 'teacher': tea})
             ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
