@@ -399,6 +399,26 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
                                   int32_t qc_span, int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
                                   void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
                                   float *dtk, float *dtv, u2mkd_stream_t s);
+/* The same two with row strides (in floats) and the query scale as arguments: q, k, v are read straight out of the
+ * packed [N, 3, H, 16] output of the qkv projection (`qkv(feats).reshape(N, 3, H, C // H)`, q = qkv[:, 0] * scale:
+ * core/models/sphereformer/spherical_transformer.py:192-205) -- a branch is a range of heads, pass the pointer of its
+ * first head and ld_qkv = 3 * H * 16 -- the heads of a branch go to their columns of the [N, H * 16] attention
+ * output (ld_out = H * 16: the torch.cat of the two branches, :228), and the backward writes d(qkv) in the packed
+ * layout (ld_grad = 3 * H * 16; dq already multiplied by q_scale).  The contiguous entries above are these with
+ * ld = h * 16 and q_scale = 1.                                                                                      */
+int u2mkd_sptr_attention_forward_strided(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
+                                         const int32_t *sort_idx, const int32_t *wstart, const int32_t *wlen,
+                                         const int32_t *qc, const float *radial, const float *tq, const float *tk,
+                                         const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n, int32_t h,
+                                         int32_t hdim, float *out, int64_t ld_out, float *lse, u2mkd_stream_t s);
+int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
+                                          const float *out, const float *dout, int64_t ld_out, const float *lse,
+                                          const int32_t *sort_idx, const int32_t *wstart, const int32_t *wlen,
+                                          const int32_t *qc, const float *radial, const float *tq, const float *tk,
+                                          const float *tv, int32_t L, int32_t qgl, float split_a, int32_t qc_span,
+                                          int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
+                                          void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv,
+                                          int64_t ld_grad, float *dtq, float *dtk, float *dtv, u2mkd_stream_t s);
 
 /* ---- BatchNorm2d over NCHW maps, fused with the ReLU / residual add that follow it (csrc/bn2d.hip) -----------------
  * Replaces nn.BatchNorm2d -> nn.ReLU (and bn2(conv2(.)) + identity -> ReLU of BasicBlock) in the SwiftNet-18 camera

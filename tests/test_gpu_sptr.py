@@ -139,3 +139,34 @@ def test_quantiser_decisions_equal_on_equal_inputs(hip, window, quant):
     want = torch.div((xyz - xyz.min(0)[0] + 0.0) % w, qz, rounding_mode='floor').int()
     assert torch.equal(qc.cpu(), want[order])
     assert int(want.max()) < span
+
+
+@pytest.mark.parametrize('dim,heads', [(32, 2), (128, 8), (48, 3)])
+def test_packed_attention_layer_equals_slice_scale_concat_form(hip, monkeypatch, dim, heads):
+    """SparseMultiheadSASphereConcat on the packed qkv (row-strided kernels: q scale, head slices of the two branches
+    and the concatenation inside the kernels) against the reference's dataflow around the contiguous kernels
+    (qkv[:, 0] * scale, per-branch slices, torch.cat): the same arithmetic in the same order, so outputs and every
+    gradient (input, qkv / proj parameters, the six tables) are EQUAL."""
+    from u2mkd_amd.lidar import sphereformer as SF
+    xyz, b = _tokens(3000, 5)
+    xyz = (xyz - torch.tensor([4.0, 4.0, 1.0])).cuda()
+    b = b.cuda().int()
+    torch.manual_seed(dim)
+    layer = SF.SparseMultiheadSASphereConcat(dim, heads, np.array([0.6, 0.6, 0.6]), np.array([1.5, 1.5, 80.0]),
+                                             np.array([0.025, 0.025, 0.025]), np.array([0.0625, 0.0625, 3.4]), 0.0125).cuda()
+    for n, p in layer.named_parameters():
+        if 'table' in n:
+            torch.nn.init.normal_(p, std=0.2)
+    feats = torch.randn(3000, dim, device='cuda')
+    g = torch.randn(3000, dim, device='cuda')
+    res = {}
+    for packed in (True, False):
+        monkeypatch.setattr(SF, '_PACKED', packed)
+        x = feats.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        y = layer(x, xyz, b)
+        y.backward(g)
+        res[packed] = [y.detach(), x.grad] + [p.grad.clone() for p in layer.parameters()]
+    names = ['out', 'dx'] + [n for n, _ in layer.named_parameters()]
+    for n, a, c in zip(names, res[True], res[False]):
+        assert torch.equal(a, c), (n, float((a - c).abs().max()))

@@ -104,6 +104,15 @@ __device__ __forceinline__ int exp_split(float d, float a) {
     return (int)idx + 24;
 }
 
+// row strides (floats) of the token-major operands and the scale applied to q on load: lets the kernels read q, k, v
+// straight out of the packed [N, 3, H, 16] output of the qkv projection (one branch = a range of heads), write the
+// heads of a branch into their columns of the [N, H * 16] attention output, and the gradients into a packed
+// [N, 3, H, 16] buffer -- without the slice / scale / concatenate copies around them
+struct SptrLayout {
+    int64_t ld_qkv, ld_out, ld_grad;
+    float q_scale;
+};
+
 struct RelCtx {
     int qgl;        // quant_grid_length
     float a;        // > 0: spherical branch (exponential radial split + clamp)
@@ -165,7 +174,7 @@ sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
                      const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
                      const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
                      const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ out,
-                     float *__restrict__ lse) {
+                     float *__restrict__ lse, SptrLayout ly) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
     const int hh = blockIdx.y;
     load_tables(s_tab, tq, tk, tv, L, h, hh);
@@ -174,9 +183,11 @@ sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int64_t t = sort_idx[p];
-    const size_t hc = (size_t)h * kHd;
+    const size_t hc = ly.ld_qkv;
     float qi[kHd];
     load16(q + t * hc + hh * kHd, qi);
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) qi[d] *= ly.q_scale;
     int qci[3] = {qc[p * 3], qc[p * 3 + 1], qc[p * 3 + 2]};
     float ri = radial ? radial[p] : 0.f;
     const int ws = wstart[p], wl = wlen[p];
@@ -210,7 +221,7 @@ sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
         m = mn;
     }
     float inv = 1.f / l;
-    float *o = out + t * hc + hh * kHd;
+    float *o = out + t * (size_t)ly.ld_out + hh * kHd;
 #pragma unroll
     for (int v4 = 0; v4 < 4; ++v4)
         reinterpret_cast<float4 *>(o)[v4] =
@@ -220,13 +231,14 @@ sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
 
 // delta[p,h] = sum_d dout[t,h,d] * out[t,h,d]
 __global__ void sptr_delta_kernel(const float *__restrict__ dout, const float *__restrict__ out,
-                                  const int32_t *__restrict__ sort_idx, int64_t n, int h, float *__restrict__ delta) {
+                                  const int32_t *__restrict__ sort_idx, int64_t n, int h, float *__restrict__ delta,
+                                  int64_t ld_out) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * h) return;
     int64_t p = e / h;
     int hh = (int)(e - p * h);
     int64_t t = sort_idx[p];
-    const float *a = dout + (t * h + hh) * kHd, *b = out + (t * h + hh) * kHd;
+    const float *a = dout + t * ld_out + hh * kHd, *b = out + t * ld_out + hh * kHd;
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < kHd; ++d) s += a[d] * b[d];
@@ -317,7 +329,7 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
                       const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
                       const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
                       const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
-                      float *__restrict__ slabs) {
+                      float *__restrict__ slabs, SptrLayout ly) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
     constexpr int NT = 2, HS = NT * kHistTab + 1;
     const int hh = blockIdx.y;
@@ -330,7 +342,7 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
     const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool sphere = rc.a > 0.f;
-    const size_t hc = (size_t)h * kHd;
+    const size_t hc = ly.ld_qkv;
     float *hist = s_hist + (size_t)tid * HS;
     f32x4 acc[NT][3][3];
 #pragma unroll
@@ -353,7 +365,9 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
             float ri = radial ? radial[p] : 0.f;
             const int ws = wstart[p], wl = wlen[p];
             load16(q + t * hc + hh * kHd, qi);
-            load16(dout + t * hc + hh * kHd, doi);
+#pragma unroll
+            for (int d = 0; d < kHd; ++d) qi[d] *= ly.q_scale;
+            load16(dout + t * (size_t)ly.ld_out + hh * kHd, doi);
             const float lse_i = lse[p * h + hh], del_i = delta[p * h + hh];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) base[ax] = hist_base(rc, qci[ax], true);
@@ -395,9 +409,9 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
                     }
                 }
             }
-            float *o1 = dq + t * hc + hh * kHd;
+            float *o1 = dq + t * (size_t)ly.ld_grad + hh * kHd;      // d(unscaled q) = q_scale * d(q)
 #pragma unroll
-            for (int d = 0; d < kHd; ++d) o1[d] = dqi[d];
+            for (int d = 0; d < kHd; ++d) o1[d] = dqi[d] * ly.q_scale;
         }
 #pragma unroll
         for (int d = 0; d < kHd; ++d) {
@@ -424,7 +438,7 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
                     const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
                     const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
                     const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dk,
-                    float *__restrict__ dv, float *__restrict__ slabs) {
+                    float *__restrict__ dv, float *__restrict__ slabs, SptrLayout ly) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
     constexpr int NT = 1, HS = NT * kHistTab + 1;
     const int hh = blockIdx.y;
@@ -437,7 +451,7 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
     const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool sphere = rc.a > 0.f;
-    const size_t hc = (size_t)h * kHd;
+    const size_t hc = ly.ld_qkv;
     float *hist = s_hist + (size_t)tid * HS;
     f32x4 acc[NT][3][3];
 #pragma unroll
@@ -474,7 +488,9 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
                 rel_rows(rc, qcj, rj, qci, ri, r);
                 float qj[kHd], doj[kHd], ts[kHd], tks[kHd], tvs[kHd];
                 load16(q + tj * hc + hh * kHd, qj);
-                load16(dout + tj * hc + hh * kHd, doj);
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) qj[d] *= ly.q_scale;
+                load16(dout + tj * (size_t)ly.ld_out + hh * kHd, doj);
                 tab_sum(Tq, r, ts);
                 tab_sum(Tk, r, tks);
                 float s2 = 0.f;
@@ -499,7 +515,7 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
                         hist[(radial_ax ? kHistAx : ax * kNB) + bin] += ds2;   // Hk
                 }
             }
-            float *o2 = dk + t * hc + hh * kHd, *o3 = dv + t * hc + hh * kHd;
+            float *o2 = dk + t * (size_t)ly.ld_grad + hh * kHd, *o3 = dv + t * (size_t)ly.ld_grad + hh * kHd;
 #pragma unroll
             for (int d = 0; d < kHd; ++d) { o2[d] = dki[d]; o3[d] = dvi[d]; }
         }
@@ -578,22 +594,35 @@ static int sptr_check(const char *who, int64_t n, int h, int hdim, int L, int qg
     return 0;
 }
 
-int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v, const int32_t *sort_idx,
-                                 const int32_t *wstart, const int32_t *wlen, const int32_t *qc, const float *radial,
-                                 const float *tq, const float *tk, const float *tv, int32_t L, int32_t qgl,
-                                 float split_a, int64_t n, int32_t h, int32_t hdim, float *out, float *lse,
-                                 u2mkd_stream_t s) {
+int u2mkd_sptr_attention_forward_strided(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
+                                         const int32_t *sort_idx, const int32_t *wstart, const int32_t *wlen,
+                                         const int32_t *qc, const float *radial, const float *tq, const float *tk,
+                                         const float *tv, int32_t L, int32_t qgl, float split_a, int64_t n, int32_t h,
+                                         int32_t hdim, float *out, int64_t ld_out, float *lse, u2mkd_stream_t s) {
     if (n == 0 || h == 0) return 0;
     U2_REQUIRE(q && k && v && sort_idx && wstart && wlen && qc && tq && tk && tv && out && lse,
                "u2mkd_sptr_attention_forward: null pointer");
     if (int rc = sptr_check("u2mkd_sptr_attention_forward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(split_a <= 0.f || radial, "u2mkd_sptr_attention_forward: spherical branch needs the radial coordinate");
+    U2_REQUIRE(ld_qkv >= (int64_t)h * kHd && ld_out >= (int64_t)h * kHd && ld_qkv % 4 == 0 && ld_out % 4 == 0,
+               "u2mkd_sptr_attention_forward: row strides %lld / %lld must be multiples of 4 floats and hold %d heads",
+               (long long)ld_qkv, (long long)ld_out, h);
     RelCtx rc{qgl, split_a};
+    SptrLayout ly{ld_qkv, ld_out, 0, q_scale};
     size_t lds = (size_t)3 * L * 3 * kTabRow * sizeof(float);
     hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
                        as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk, tv,
-                       L, rc, n, h, out, lse);
+                       L, rc, n, h, out, lse, ly);
     return check_launch("u2mkd_sptr_attention_forward");
+}
+
+int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v, const int32_t *sort_idx,
+                                 const int32_t *wstart, const int32_t *wlen, const int32_t *qc, const float *radial,
+                                 const float *tq, const float *tk, const float *tv, int32_t L, int32_t qgl,
+                                 float split_a, int64_t n, int32_t h, int32_t hdim, float *out, float *lse,
+                                 u2mkd_stream_t s) {
+    return u2mkd_sptr_attention_forward_strided(q, k, v, (int64_t)h * kHd, 1.f, sort_idx, wstart, wlen, qc, radial, tq, tk, tv,
+                                                L, qgl, split_a, n, h, hdim, out, (int64_t)h * kHd, lse, s);
 }
 
 static int sptr_bwd_grid(int64_t n) {
@@ -605,13 +634,14 @@ size_t u2mkd_sptr_backward_workspace_bytes(int64_t n, int32_t h, int32_t L) {
     return (size_t)2 * sptr_bwd_grid(n) * h * 3 * L * 3 * kHd * sizeof(float);   // one slab per wave
 }
 
-int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
+int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
+                                          const float *out, const float *dout, int64_t ld_out,
                                   const float *lse, const int32_t *sort_idx, const int32_t *wstart,
                                   const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
                                   const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a,
                                   int32_t qc_span, int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
-                                  void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
-                                  float *dtk, float *dtv, u2mkd_stream_t s) {
+                                  void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv,
+                                  int64_t ld_grad, float *dtq, float *dtk, float *dtv, u2mkd_stream_t s) {
     if (n == 0 || h == 0) return 0;
     U2_REQUIRE(q && k && v && out && dout && lse && sort_idx && wstart && wlen && qc && tq && tk && tv && delta &&
                    workspace && dq && dk && dv && dtq && dtk && dtv,
@@ -619,10 +649,14 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
     if (int rc = sptr_check("u2mkd_sptr_attention_backward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(workspace_bytes >= u2mkd_sptr_backward_workspace_bytes(n, h, L),
                "u2mkd_sptr_attention_backward: workspace too small");
+    U2_REQUIRE(ld_qkv >= (int64_t)h * kHd && ld_out >= (int64_t)h * kHd && ld_grad >= (int64_t)h * kHd && ld_qkv % 4 == 0 &&
+                   ld_out % 4 == 0 && ld_grad % 4 == 0,
+               "u2mkd_sptr_attention_backward: row strides must be multiples of 4 floats and hold %d heads", h);
     RelCtx rc{qgl, split_a};
+    SptrLayout ly{ld_qkv, ld_out, ld_grad, q_scale};
     hipStream_t st = as_stream(s);
     hipLaunchKernelGGL(sptr_delta_kernel, dim3((unsigned)ceil_div(n * h, 256)), dim3(256), 0, st, dout, out, sort_idx,
-                       n, h, delta);
+                       n, h, delta, ld_out);
     const int G = sptr_bwd_grid(n);
     float *slabs = reinterpret_cast<float *>(workspace);
     const float *rad = split_a > 0.f ? radial : nullptr;
@@ -642,12 +676,25 @@ int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     hipLaunchKernelGGL(sptr_bwd_query_kernel, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse, delta,
-                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs);
+                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs, ly);
     hipLaunchKernelGGL(sptr_bwd_key_kernel, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse, delta,
-                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs);
+                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs, ly);
     hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, 2 * G, L, h,
                        dtq, dtk, dtv);
     return check_launch("u2mkd_sptr_attention_backward");
+}
+
+int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                  const float *lse, const int32_t *sort_idx, const int32_t *wstart,
+                                  const int32_t *wlen, const int32_t *qc, const float *radial, const float *tq,
+                                  const float *tk, const float *tv, int32_t L, int32_t qgl, float split_a,
+                                  int32_t qc_span, int64_t n, int32_t h, int32_t hdim, float *delta /*[n,h] scratch*/,
+                                  void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv, float *dtq,
+                                  float *dtk, float *dtv, u2mkd_stream_t s) {
+    const int64_t ld = (int64_t)h * kHd;
+    return u2mkd_sptr_attention_backward_strided(q, k, v, ld, 1.f, out, dout, ld, lse, sort_idx, wstart, wlen, qc, radial, tq, tk,
+                                                 tv, L, qgl, split_a, qc_span, n, h, hdim, delta, workspace, workspace_bytes,
+                                                 dq, dk, dv, ld, dtq, dtk, dtv, s);
 }
 
 }  // extern "C"

@@ -7,11 +7,15 @@ relative-position tables for query, key and value.  Parameter names match the re
 (``norm1``, ``attn.qkv``, ``attn.relative_pos_*_table[_sphere]``, ``attn.proj``, ``norm2``,
 ``mlp.fc1/fc2``) so its checkpoints load unchanged.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
 
 from .. import sptr
+
+_PACKED = os.environ.get('U2MKD_SPTR_PACKED', '1') != '0'     # 0: slice / scale / concatenate around the contiguous kernels
 
 __all__ = ['SphereFormer', 'SparseMultiheadSASphereConcat', 'DropPath', 'cart2sphere']
 
@@ -91,21 +95,26 @@ class SparseMultiheadSASphereConcat(nn.Module):
     def forward(self, feats, xyz, batch):
         N, C = feats.shape
         qkv = self.qkv(feats).reshape(N, 3, self.num_heads, C // self.num_heads)
-        query = qkv[:, 0] * self.scale
-        key, value = qkv[:, 1], qkv[:, 2]
         h1 = self.num_heads_brc1
         xyz = xyz.float()
         xyz_sphere = cart2sphere(xyz)
         plan = sptr.WindowPlan(xyz, batch, self.window_size)
         plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
-        out1 = sptr.window_attention(query[:, :h1], key[:, :h1], value[:, :h1], xyz, plan, self.quant_size,
-                                     self.quant_grid_length, self.relative_pos_query_table,
-                                     self.relative_pos_key_table, self.relative_pos_value_table, None)
-        out2 = sptr.window_attention(query[:, h1:], key[:, h1:], value[:, h1:], xyz_sphere, plan_s,
-                                     self.quant_size_sphere, self.quant_grid_length_sphere,
-                                     self.relative_pos_query_table_sphere, self.relative_pos_key_table_sphere,
-                                     self.relative_pos_value_table_sphere, self.a)
-        x = torch.cat([out1, out2], 1).view(N, C)
+        cubic = (0, h1, xyz, plan, self.quant_size, self.quant_grid_length,
+                 (self.relative_pos_query_table, self.relative_pos_key_table, self.relative_pos_value_table), None)
+        sphere = (h1, self.num_heads - h1, xyz_sphere, plan_s, self.quant_size_sphere, self.quant_grid_length_sphere,
+                  (self.relative_pos_query_table_sphere, self.relative_pos_key_table_sphere,
+                   self.relative_pos_value_table_sphere), self.a)
+        if qkv.is_cuda and C // self.num_heads == 16 and _PACKED:
+            # q = qkv[:, 0] * scale, the per-branch head slices and torch.cat([out1, out2], 1) (spherical_transformer.py
+            # :192-228) all inside the two kernels, through row strides
+            x = sptr.packed_window_attention(qkv, self.scale, [cubic, sphere])
+        else:
+            query = qkv[:, 0] * self.scale
+            key, value = qkv[:, 1], qkv[:, 2]
+            outs = [sptr.window_attention(query[:, h0:h0 + h], key[:, h0:h0 + h], value[:, h0:h0 + h], pts, pl, qs, qgl, *tabs, a)
+                    for h0, h, pts, pl, qs, qgl, tabs, a in (cubic, sphere)]
+            x = torch.cat(outs, 1).view(N, C)
         return self.proj(x)
 
 

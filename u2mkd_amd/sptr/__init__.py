@@ -11,10 +11,10 @@ import numbers
 
 import numpy as np
 
-from .functional import WindowPlan, get_indices_params, sparse_self_attention, window_attention
+from .functional import WindowPlan, get_indices_params, packed_window_attention, sparse_self_attention, window_attention
 
 __all__ = ['to_3d_numpy', 'SparseTrTensor', 'sparse_self_attention', 'get_indices_params', 'WindowPlan',
-           'window_attention']
+           'window_attention', 'packed_window_attention']
 
 
 def to_3d_numpy(size):

@@ -129,6 +129,92 @@ class WindowAttentionFunction(Function):
         return dq, dk, dv, dtq, dtk, dtv, None, None, None, None, None, None
 
 
+class PackedAttentionFunction(Function):
+    """All branches of a SphereFormer attention layer on the PACKED projection output: ``qkv`` [N, 3, H, 16] (the
+    reshaped output of the qkv Linear), ``scale`` applied to q inside the kernels, branch b = heads h0..h0+h with its
+    own window plan and tables; returns [N, H * 16] with every branch's heads in their columns.  Equal, bit for bit,
+    to window_attention on (qkv[:, 0] * scale)[:, h0:h0+h], qkv[:, 1][:, h0:h0+h], qkv[:, 2][:, h0:h0+h] per branch
+    + torch.cat -- without the scale / slice / concatenate copies and, in the backward, without the zero-filled
+    [N, 3, H, 16] gradient of every slice: both kernels read and write the packed layouts through row strides
+    (u2mkd_sptr_attention_forward_strided / _backward_strided)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, branches, *tables):
+        L.require_cuda(qkv, *tables)
+        qkv = qkv.contiguous().float()
+        n, three, H, d = qkv.shape
+        assert three == 3 and d == 16 and len(tables) == 3 * len(branches)
+        tables = tuple(t.contiguous().float() for t in tables)
+        out = torch.empty(n, H, d, dtype=torch.float32, device=qkv.device)
+        lses = []
+        st = L.stream()
+        for b, br in enumerate(branches):
+            h0, h = br['h0'], br['h']
+            tq, tk, tv = tables[3 * b:3 * b + 3]
+            if tq.shape != (tq.shape[0], 3, h, d) or tk.shape != tq.shape or tv.shape != tq.shape:
+                raise RuntimeError(f'relative position tables must be [L,3,{h},{d}], got {tuple(tq.shape)}')
+            lse = torch.empty(n, h, dtype=torch.float32, device=qkv.device)
+            lses.append(lse)
+            if n == 0 or h == 0:
+                continue
+            plan = br['plan']
+            L.call('u2mkd_sptr_attention_forward_strided', L.ptr(qkv[:, 0, h0:]), L.ptr(qkv[:, 1, h0:]), L.ptr(qkv[:, 2, h0:]),
+                   3 * H * d, float(scale), L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(br['qc']),
+                   L.ptr(br['radial']), L.ptr(tq), L.ptr(tk), L.ptr(tv), tq.shape[0], int(br['qgl']), float(br['split_a']),
+                   n, h, d, L.ptr(out[:, h0:]), H * d, L.ptr(lse), st)
+        ctx.save_for_backward(qkv, out, *lses, *tables)
+        ctx.branches, ctx.scale = branches, float(scale)
+        return out.view(n, H * d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        branches = ctx.branches
+        nb = len(branches)
+        saved = ctx.saved_tensors
+        qkv, out, lses, tables = saved[0], saved[1], saved[2:2 + nb], saved[2 + nb:]
+        n, _, H, d = qkv.shape
+        dout = dout.contiguous().float()
+        dqkv = torch.empty_like(qkv)            # every (q | k | v, head) column belongs to exactly one branch
+        grads = []
+        st = L.stream()
+        for b, br in enumerate(branches):
+            h0, h = br['h0'], br['h']
+            tq, tk, tv = tables[3 * b:3 * b + 3]
+            dtq, dtk, dtv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
+            grads += [dtq, dtk, dtv]
+            if n == 0 or h == 0:
+                for t in (dtq, dtk, dtv):
+                    t.zero_()
+                continue
+            plan = br['plan']
+            tl = tq.shape[0]
+            delta = torch.empty(n, h, dtype=torch.float32, device=qkv.device)
+            nbytes = L.load().u2mkd_sptr_backward_workspace_bytes(n, h, tl)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=qkv.device)
+            L.call('u2mkd_sptr_attention_backward_strided', L.ptr(qkv[:, 0, h0:]), L.ptr(qkv[:, 1, h0:]), L.ptr(qkv[:, 2, h0:]),
+                   3 * H * d, ctx.scale, L.ptr(out[:, h0:]), L.ptr(dout[:, h0 * d:]), H * d, L.ptr(lses[b]),
+                   L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(br['qc']), L.ptr(br['radial']),
+                   L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, int(br['qgl']), float(br['split_a']), int(br['span']), n, h, d,
+                   L.ptr(delta), L.ptr(ws), nbytes, L.ptr(dqkv[:, 0, h0:]), L.ptr(dqkv[:, 1, h0:]), L.ptr(dqkv[:, 2, h0:]),
+                   3 * H * d, L.ptr(dtq), L.ptr(dtk), L.ptr(dtv), st)
+        if n == 0:
+            dqkv.zero_()
+        return (dqkv, None, None, *grads)
+
+
+def packed_window_attention(qkv, scale, branches):
+    """``branches``: [(h0, h, xyz, plan, quant_size, quant_grid_length, (table_q, table_k, table_v), split_a or None), ..]
+    covering heads 0..H of ``qkv`` [N, 3, H, 16]; returns the concatenated attention output [N, H * 16]."""
+    descs, tables = [], []
+    for h0, h, xyz, plan, quant_size, qgl, tabs, split_a in branches:
+        sphere = split_a is not None
+        qc, radial, span = plan.quant_coords(xyz, quant_size, sphere)
+        descs.append({'h0': int(h0), 'h': int(h), 'plan': plan, 'qc': qc, 'radial': radial, 'qgl': int(qgl),
+                      'split_a': float(split_a) if sphere else 0.0, 'span': int(span)})
+        tables += list(tabs)
+    return PackedAttentionFunction.apply(qkv, float(scale), descs, *tables)
+
+
 def window_attention(q, k, v, xyz, plan: WindowPlan, quant_size, quant_grid_length, table_q, table_k, table_v,
                      split_a=None):
     """softmax over each token's window of (q.k + q.Tq(rel) + k.Tk(rel)) applied to (v + Tv(rel));
