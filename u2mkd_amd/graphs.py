@@ -148,7 +148,8 @@ class StaticPiece:
 
         rec.pool = torch.cuda.graph_pool_handle()
         rec.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(rec.fwd, pool=rec.pool):
+        # (thread_local: a helper thread may be queueing the teacher on another stream meanwhile)
+        with torch.cuda.graph(rec.fwd, pool=rec.pool, capture_error_mode='thread_local'):
             outs = self.fn(*rec.sample)
         outs, rec.spec = tree_flatten(outs)
         rec.outs = tuple(outs)
@@ -158,7 +159,7 @@ class StaticPiece:
         # the training loop likes.
         keep = [torch.zeros_like(p) for p in rec.params]
         rec.bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(rec.bwd, pool=rec.pool):
+        with torch.cuda.graph(rec.bwd, pool=rec.pool, capture_error_mode='thread_local'):
             gins = list(backward(rec.outs, rec.gouts))
             first = len(gins) - len(rec.params)
             live = [(k, g) for k, g in zip(keep, gins[first:]) if g is not None]
