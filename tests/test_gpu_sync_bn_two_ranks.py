@@ -1,0 +1,115 @@
+"""The HIP SyncBatchNorm path at world size 2: local slab statistics -> all_gather of [2C+1] -> Chan merge ->
+normalise (+ReLU); backward: local sums -> all_reduce of [2C] -> apply with the global count.
+
+RCCL refuses two ranks on one device and the GPU box has one, so the two ranks are two fresh child processes on
+cuda:0 joined by a GLOO group: the kernels are the product's, only the two tiny collectives travel through host
+memory (functional._gather_rows / _sum_over_ranks).  UNEQUAL rows per rank.  Oracle: one process, nn.BatchNorm1d in
+fp64 over the concatenated rows with the loss summed over the ranks -- y and dx of a rank are its slice, dgamma /
+dbeta are the rank's own sums (DDP averages them afterwards), the running statistics use the global count."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+import torch, torch.distributed as dist
+from u2mkd_amd.lidar.point_voxel import PointSyncBatchNorm1d
+from u2mkd_amd.torchsparse.nn import functional as F
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+torch.cuda.set_device(0)
+C, rows = 64, (1500, 377)
+g = torch.Generator().manual_seed(7)
+xs = [torch.randn(n, C, generator=g) * 2.0 + 1.5 for n in rows]
+ws = [torch.randn(n, C, generator=g) for n in rows]
+bn = PointSyncBatchNorm1d(C, momentum=0.1).cuda().train()
+with torch.no_grad():
+    bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+res = {}
+for relu in (False, True):
+    x = xs[rank].cuda().requires_grad_(True)
+    bn.zero_grad(set_to_none=True)
+    assert F._sync_group(bn) is not None and F._sync_group(bn)[1] == 2
+    y = F.batch_norm(x, bn, relu)
+    (y * ws[rank].cuda()).sum().backward()
+    res['relu%d' % relu] = {'y': y.detach().cpu(), 'dx': x.grad.cpu(), 'dgamma': bn.weight.grad.cpu(), 'dbeta': bn.bias.grad.cpu()}
+res['running_mean'], res['running_var'] = bn.running_mean.cpu(), bn.running_var.cpu()
+res['tracked'] = int(bn.num_batches_tracked)
+torch.save(res, out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(600)
+def test_hip_sync_batchnorm_two_ranks_equals_batchnorm_over_all_rows(hip, tmp_path):
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    outs = [str(tmp_path / f'r{r}.pt') for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, '-c', _CHILD, ROOT, str(r), '2', str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    got = [torch.load(o) for o in outs]
+    # ---- oracle: one process, all rows, fp64
+    C, rows = 64, (1500, 377)
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(n, C, generator=g) * 2.0 + 1.5 for n in rows]
+    ws = [torch.randn(n, C, generator=g) for n in rows]
+    gamma = (torch.rand(C, generator=g) + 0.5).double()
+    beta = (torch.randn(C, generator=g) * 0.2).double()
+    for relu in (False, True):
+        x = torch.cat(xs).double().requires_grad_(True)
+        bn = torch.nn.BatchNorm1d(C, momentum=0.1).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        y = bn(x)
+        pre = y
+        if relu:
+            y = torch.relu(y)
+        (y * torch.cat(ws).double()).sum().backward()
+        clear = (pre.detach().abs() > 1e-4) if relu else torch.ones_like(pre, dtype=torch.bool)
+        xhat = (x.detach() - x.detach().mean(0)) / torch.sqrt(x.detach().var(0, unbiased=False) + bn.eps)
+        dyp = torch.cat(ws).double() * ((pre.detach() > 0) if relu else 1.0)
+        lo = 0
+        for r, n in enumerate(rows):
+            sl = slice(lo, lo + n)
+            lo += n
+            k = got[r]['relu%d' % relu]
+            assert float((k['y'].double() - y.detach()[sl]).abs().max()) < 2e-5 * float(y.detach().abs().max()), (relu, r)
+            assert float(((k['dx'].double() - x.grad[sl]) * clear[sl]).abs().max()) < 2e-4 * max(1.0, float(x.grad.abs().max())), (relu, r)
+            want_db, want_dg = dyp[sl].sum(0), (dyp[sl] * xhat[sl]).sum(0)             # the rank's own sums
+            assert float((k['dbeta'].double() - want_db).abs().max()) < 2e-4 * max(1.0, float(want_db.abs().max())), (relu, r)
+            assert float((k['dgamma'].double() - want_dg).abs().max()) < 2e-4 * max(1.0, float(want_dg.abs().max())), (relu, r)
+    # running statistics after the two passes (global mean, unbiased global variance), equal on both ranks
+    ref = torch.nn.BatchNorm1d(C, momentum=0.1).double().train()
+    for _ in range(2):
+        ref(torch.cat(xs).double())
+    for r in range(2):
+        assert got[r]['tracked'] == 2
+        assert float((got[r]['running_mean'].double() - ref.running_mean).abs().max()) < 1e-5
+        assert float((got[r]['running_var'].double() - ref.running_var).abs().max()) < 1e-4
+    assert torch.equal(got[0]['running_mean'], got[1]['running_mean']) and torch.equal(got[0]['running_var'], got[1]['running_var'])

@@ -891,6 +891,30 @@ class BatchNormFunction(Function):
                 None, None, None, None, None, None, None, dres)
 
 
+def _gather_rows(out, row, group):
+    """out[r] = rank r's `row` (device tensors).  RCCL: one all_gather on the device.  A gloo group cannot move
+    device tensors in an all_gather: the [2C+1] floats travel through host memory (the TRANSPORT only -- this is how
+    two ranks on ONE GPU can run the device path in tests/test_gpu_sync_bn_two_ranks.py, RCCL refuses two ranks on a
+    device)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == 'gloo':
+        rows = [torch.empty(row.shape, dtype=row.dtype) for _ in range(out.shape[0])]
+        dist.all_gather(rows, row.cpu(), group=group)
+        out.copy_(torch.stack(rows), non_blocking=False)
+    else:
+        dist.all_gather_into_tensor(out, row, group=group)
+
+
+def _sum_over_ranks(t, group):
+    import torch.distributed as dist
+    if dist.get_backend(group) == 'gloo' and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 class SyncBatchNormFunction(Function):
     """SyncBatchNorm (+ fused ReLU) over the rows of [N, C] across the ranks of a process group:
     local slab statistics -> ONE all_gather of [2C+1] floats -> Chan merge in rank order ->
@@ -913,7 +937,7 @@ class SyncBatchNormFunction(Function):
         L.call('u2mkd_bn_local_stats', L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
         gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, stats, group=group)
+            _gather_rows(gathered, stats, group)
         else:
             gathered.copy_(stats.view(1, -1))
         mean = torch.empty(c, dtype=torch.float32, device=dev)
@@ -942,7 +966,7 @@ class SyncBatchNormFunction(Function):
                L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
         local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
         if ctx.world > 1:
-            dist.all_reduce(sums, group=ctx.group)
+            _sum_over_ranks(sums, ctx.group)
         dx = torch.empty_like(x)
         L.call('u2mkd_bn_backward_apply', L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
                L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.stream())
