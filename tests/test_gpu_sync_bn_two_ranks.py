@@ -113,3 +113,85 @@ def test_hip_sync_batchnorm_two_ranks_equals_batchnorm_over_all_rows(hip, tmp_pa
         assert float((got[r]['running_mean'].double() - ref.running_mean).abs().max()) < 1e-5
         assert float((got[r]['running_var'].double() - ref.running_var).abs().max()) < 1e-4
     assert torch.equal(got[0]['running_mean'], got[1]['running_mean']) and torch.equal(got[0]['running_var'], got[1]['running_var'])
+
+
+_CHILD_DDP = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+import torch
+from u2mkd_amd import distributed as D, lidar, torchsparse as ts
+from u2mkd_amd.losses import MixLovaszCrossEntropy
+from u2mkd_amd.synth import synth_batch
+D.init_from_env('gloo')
+torch.manual_seed(0)
+model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+model.dropout.p = 0.0
+net = D.wrap_model(model, sync_bn=True)
+assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+assert any(isinstance(m, lidar.SparseSyncBatchNorm) for m in net.modules())
+b = synth_batch(1500 + 300 * rank, 1, seed=D.scene_seed(100))          # unequal scenes
+feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+loss = MixLovaszCrossEntropy(ignore_index=0)(net({'lidar': ts.SparseTensor(feats, coords)})['x_vox'], labels)
+loss.backward()
+torch.cuda.synchronize()
+torch.save({'loss': float(loss), 'grads': {n: p.grad.cpu() for n, p in net.module.named_parameters()}}, out)
+D.shutdown()
+'''
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_ddp_step_equals_one_process_on_both_scenes(hip, tmp_path):
+    """DDP (gradient buckets all-reduced during the backward, the weight-gradient side stream underneath) +
+    SparseSyncBatchNorm / PointSyncBatchNorm1d on the HIP path, two ranks with their own scenes: the averaged gradients
+    equal those of ONE process holding both scenes in one batch with the loss (L_0 + L_1) / 2 -- BatchNorm over all
+    voxels of the batch is what SyncBatchNorm computes over the ranks."""
+    import numpy as np
+    from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    from u2mkd_amd.synth import synth_batch
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'U2MKD_FORCE_DDP', 'U2MKD_FORCE_SYNC_BN')}
+    outs = [str(tmp_path / f'd{r}.pt') for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_DDP, ROOT, str(r), '2', str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    got = [torch.load(o) for o in outs]
+    for n in got[0]['grads']:
+        assert torch.equal(got[0]['grads'][n], got[1]['grads'][n]), n               # all-reduced: the same on both ranks
+    # ---- one process, both scenes in one batch
+    torch.manual_seed(0)
+    model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+    model.dropout.p = 0.0
+    scenes = [synth_batch(1500 + 300 * r, 1, seed=100 + r) for r in range(2)]
+    for r, s in enumerate(scenes):
+        s['coords'][:, 3] = r
+    feats = torch.from_numpy(np.concatenate([s['feats'] for s in scenes])).cuda()
+    coords = torch.from_numpy(np.concatenate([s['coords'] for s in scenes])).cuda()
+    labels = [torch.from_numpy(s['labels']).cuda() for s in scenes]
+    out = model({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+    n0 = scenes[0]['feats'].shape[0]
+    crit = MixLovaszCrossEntropy(ignore_index=0)
+    l0, l1 = crit(out[:n0], labels[0]), crit(out[n0:], labels[1])
+    ((l0 + l1) / 2).backward()
+    l0v, l1v = float(l0.detach()), float(l1.detach())
+    assert abs(got[0]['loss'] - l0v) < 1e-4 * abs(l0v) and abs(got[1]['loss'] - l1v) < 1e-4 * abs(l1v)
+    errs = []
+    gmax = max(float(p.grad.norm()) for p in model.parameters())
+    for n, p in model.named_parameters():
+        g = got[0]['grads'][n].cuda()
+        # (the bias of a Linear in front of a BatchNorm has a gradient of exactly zero up to rounding: floor the scale)
+        errs.append(float((g - p.grad).norm() / max(float(p.grad.norm()), 1e-4 * gmax)))
+    errs = np.array(errs)
+    print('DDP-2 vs one process: L2-relative gradient distance median %.2e max %.2e' % (np.median(errs), errs.max()))
+    # fp32 summation order differs (per-rank slabs vs one batch) and ReLU inputs within rounding of zero may flip
+    assert np.median(errs) < 1e-3 and errs.max() < 3e-2, (np.median(errs), errs.max())
