@@ -19,8 +19,10 @@ gradient into memory of its own, so accumulating works as in eager mode.
 What is NOT captured (the piece then runs eagerly, as before): evaluation / no-grad passes, autocast regions,
 pieces holding a SyncBatchNorm (a collective inside a capture) and a new input signature beyond the first
 ``_MAX_SHAPES`` per piece.  ``U2MKD_CAMERA_GRAPH=0`` turns capture off."""
+import atexit
 import os
 import warnings
+import weakref
 
 import torch
 from torch import nn
@@ -34,6 +36,26 @@ _MAX_SHAPES = 2
 
 def graphs_enabled():
     return _ENABLED
+
+
+_LIVE = weakref.WeakSet()           # every StaticPiece that may hold captured graphs
+
+
+@atexit.register
+def _release_graphs():
+    """Destroy the captured graphs (and their private pools) while the HIP runtime is still up: left to interpreter
+    shutdown, a hipGraphExec can be destroyed after the runtime's own teardown has begun (seen once as an abort at
+    the exit of an otherwise green test process)."""
+    pieces = list(_LIVE)
+    if not pieces:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:                                           # noqa: BLE001 -- nothing left to protect at exit
+        pass
+    for p in pieces:
+        p._records.clear()
 
 
 class PieceCache(dict):
@@ -86,6 +108,7 @@ class StaticPiece:
     def __init__(self, name, fn, mods):
         self.name, self.fn, self.mods = name, fn, list(mods)
         self._records = {}          # input signature -> _Record, or None after a failed capture
+        _LIVE.add(self)
         self._sync_bn = any(isinstance(s, nn.SyncBatchNorm) for m in self.mods for s in m.modules())
 
     def _qualifies(self, args):
