@@ -47,6 +47,23 @@ for meth in ('item', 'tolist', 'cpu'):
         counts[key] += 1
         return r
     setattr(torch.Tensor, meth, timed)
+_orig_unique = torch.unique
+
+
+def _timed_unique(*a, **k):
+    t = time.perf_counter()
+    r = _orig_unique(*a, **k)
+    n = r[0].shape[0] if isinstance(r, tuple) else r.shape[0]       # the size is known: the stream has been synchronised
+    dt = time.perf_counter() - t
+    st = [f for f in traceback.extract_stack() if 'u2mkd_amd' in f.filename]
+    key = 'unique @ ' + ' <- '.join('%s:%d' % (f.filename.split('/')[-1], f.lineno) for f in st[-2:][::-1]) + \
+        ' [stream %s]' % ('main' if torch.cuda.current_stream() == torch.cuda.default_stream() else 'side')
+    waits[key] += dt
+    counts[key] += 1
+    return r
+
+
+torch.unique = _timed_unique
 for _ in range(6):
     run(d)
 torch.cuda.synchronize()
@@ -64,3 +81,21 @@ for k, v in marks.items():
 print('host waits by call site (ms per step):')
 for k, v in waits.most_common(12):
     print('  %7.2f ms %5.1f calls  %s' % (v / K * 1e3, counts[k] / K, k))
+
+if os.environ.get('U2MKD_PROBE_TAIL') == '1':
+    # while the tail of a step's backward is still running on the main stream: how long does a trivial kernel + sync
+    # take on (a) the teacher's stream, (b) a stream nothing has used in this step, (c) after a 2 ms pause
+    fresh = torch.cuda.Stream()
+    for name in ('teacher', 'fresh', 'teacher'):
+        torch.cuda.synchronize()
+        run(d)                                      # returns with ~30 ms of GPU work still queued
+        s = KD._SIDE[(0, 'teacher')] if name == 'teacher' else fresh
+        with torch.cuda.stream(s):
+            t = time.perf_counter()
+            x = torch.zeros(8, device='cuda'); x.add_(1); v = x.sum().item()
+            dt1 = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter()
+            y = torch.arange(80000, device='cuda') % 977; u = _orig_unique(y).shape[0]
+            dt2 = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter(); torch.cuda.synchronize(); rest = (time.perf_counter() - t) * 1e3
+        print('%-8s stream during the tail: tiny kernel + item %.2f ms, unique(80k) %.2f ms; the tail then took %.1f ms more' % (name, dt1, dt2, rest))
