@@ -86,11 +86,22 @@ if os.environ.get('U2MKD_PROBE_TAIL') == '1':
     # while the tail of a step's backward is still running on the main stream: how long does a trivial kernel + sync
     # take on (a) the teacher's stream, (b) a stream nothing has used in this step, (c) after a 2 ms pause
     fresh = torch.cuda.Stream()
+
+    class bench_pin:
+        pass
     for name in ('teacher', 'fresh', 'teacher'):
         torch.cuda.synchronize()
         run(d)                                      # returns with ~30 ms of GPU work still queued
         s = KD._SIDE[(0, 'teacher')] if name == 'teacher' else fresh
         with torch.cuda.stream(s):
+            t = time.perf_counter()
+            x = torch.zeros(8, device='cuda'); x.add_(1); ev = torch.cuda.Event(); ev.record(); ev.synchronize()
+            dt0 = (time.perf_counter() - t) * 1e3
+            t = time.perf_counter()
+            pin = torch.empty(1, dtype=torch.float32).pin_memory() if not hasattr(bench_pin, 'p') else bench_pin.p
+            bench_pin.p = pin
+            pin.copy_(x.sum().view(1), non_blocking=True); ev2 = torch.cuda.Event(); ev2.record(); ev2.synchronize()
+            dtp = (time.perf_counter() - t) * 1e3
             t = time.perf_counter()
             x = torch.zeros(8, device='cuda'); x.add_(1); v = x.sum().item()
             dt1 = (time.perf_counter() - t) * 1e3
@@ -98,4 +109,4 @@ if os.environ.get('U2MKD_PROBE_TAIL') == '1':
             y = torch.arange(80000, device='cuda') % 977; u = _orig_unique(y).shape[0]
             dt2 = (time.perf_counter() - t) * 1e3
         t = time.perf_counter(); torch.cuda.synchronize(); rest = (time.perf_counter() - t) * 1e3
-        print('%-8s stream during the tail: tiny kernel + item %.2f ms, unique(80k) %.2f ms; the tail then took %.1f ms more' % (name, dt1, dt2, rest))
+        print('%-8s stream during the tail: tiny kernel + event sync %.2f ms, + pinned copy + event %.2f ms, + .item() %.2f ms, unique(80k) %.2f ms; the tail then took %.1f ms more' % (name, dt0, dtp, dt1, dt2, rest))
