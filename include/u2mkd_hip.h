@@ -420,6 +420,71 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
                                           void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv,
                                           int64_t ld_grad, float *dtq, float *dtk, float *dtv, u2mkd_stream_t s);
 
+/* ---- the `sptr_cuda` extension, function for function (csrc/sptr_ops.hip) ----------------------------------------
+ * The ten functions third_party/SparseTransformer/src/sptr/pointops_api.cpp:9-20 exports, for a caller that keeps
+ * sptr's Python layer (sptr/functional.py) and its M = sum_w L_w^2 pair arrays: u2mkd_sptr_<name> replaces
+ * sptr_cuda.<name>_cuda with the same arguments in the same order (at::Tensor -> its data pointer, + the stream).
+ * Layouts are what the reference's launchers consume (i.e. AFTER the permutes sptr/functional.py applies), all
+ * float32 / int32, contiguous; outputs the reference pre-zeroes must be pre-zeroed (table gradients are accumulated
+ * with atomics, one per table entry and workgroup).  hdim <= 64, L <= 50 (the reference asserts L <= 50).
+ * The product path (u2mkd_sptr_attention_forward/_backward above) does not call these.                            */
+/* precompute/precompute.cpp:7-17 -- counts/offsets/sq_offsets [n](+1); index_0_offsets, index_1_offsets [N];
+ * index_0, index_1 [M]: pair m = sq_offsets[w] + i L_w + t  <->  (query offsets[w] + i, key offsets[w] + t)        */
+int u2mkd_sptr_precompute_all(int32_t N, int32_t n, uint32_t n_max, const int32_t *counts, const int32_t *offsets,
+                              const int32_t *sq_offsets, int32_t *index_0_offsets, int32_t *index_1_offsets,
+                              int32_t *index_0, int32_t *index_1, u2mkd_stream_t s);
+/* attention/attention_cuda.cpp:7-33 -- q [h,d,N_q], k [h,d,N_k] -> attn [h,M];  grad_out [M,h], q/k [N,h,d] ->
+ * grad_q, grad_k [N,h,d]                                                                                          */
+int u2mkd_sptr_attention_step1_forward(int32_t N_q, int32_t N_k, int32_t M, int32_t h, int32_t hdim, uint32_t n_max,
+                                       const float *q, const float *k, const int32_t *index0, const int32_t *index1,
+                                       float *attn, u2mkd_stream_t s);
+int u2mkd_sptr_attention_step1_backward(int32_t N, int32_t M, int32_t h, int32_t hdim, uint32_t n_max,
+                                        const float *grad_out, const int32_t *index0, const int32_t *index0_offsets,
+                                        const int32_t *index1, const int32_t *index1_offsets, const float *q,
+                                        const float *k, float *grad_q, float *grad_k, u2mkd_stream_t s);
+/* attention/attention_cuda.cpp:35-60 -- attn [M,h], v [N,h,d] -> output [N,h,d];  backward: grad_out [N,h,d],
+ * v [h,d,N] -> grad_attn [M,h], grad_v [N,h,d] (see the note on the reference's layout slip in csrc/sptr_ops.hip) */
+int u2mkd_sptr_attention_step2_forward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max, const float *attn,
+                                       const float *v, const int32_t *index0_offsets, const int32_t *index1,
+                                       float *output, u2mkd_stream_t s);
+int u2mkd_sptr_attention_step2_backward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max,
+                                        const float *grad_out, const int32_t *index0, const int32_t *index0_offsets,
+                                        const int32_t *index1, const int32_t *index1_offsets, const float *attn,
+                                        const float *v, float *grad_attn, float *grad_v, u2mkd_stream_t s);
+/* rpe/relative_pos_encoding_cuda.cpp -- forward: q, k [h,d,N], tables [h,d,3,L], rel_idx [3,M] -> output [h,M]
+ * (`_all` adds the q.k term); backward: grad_out [M,h], q, k [N,h,d], tables [L,3,h,d], rel_idx [M,3] ->
+ * grad_q, grad_k [N,h,d], grad_table_q, grad_table_k [L,3,h,d]                                                    */
+int u2mkd_sptr_dot_prod_with_idx_forward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max, int32_t L,
+                                         const float *q, const int32_t *index_q, const int32_t *index_q_offsets,
+                                         const float *k, const int32_t *index_k, const float *table_q,
+                                         const float *table_k, const int32_t *rel_idx, float *output,
+                                         u2mkd_stream_t s);
+int u2mkd_sptr_dot_prod_with_idx_all_forward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max, int32_t L,
+                                             const float *q, const int32_t *index_q, const int32_t *index_q_offsets,
+                                             const float *k, const int32_t *index_k, const float *table_q,
+                                             const float *table_k, const int32_t *rel_idx, float *output,
+                                             u2mkd_stream_t s);
+int u2mkd_sptr_dot_prod_with_idx_backward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max, int32_t L,
+                                          const float *grad_out, const float *q, const int32_t *index_q_offsets,
+                                          const float *k, const int32_t *index_k_offsets, const int32_t *index_k,
+                                          const float *table_q, const float *table_k, const int32_t *rel_idx,
+                                          float *grad_q, float *grad_k, float *grad_table_q, float *grad_table_k,
+                                          u2mkd_stream_t s);
+/* forward: attn [M,h], v [N,h,d], table [L,3,h,d], rel_idx [M,3] -> output [N,h,d];  backward: grad_out [N,h,d],
+ * attn [M,h], v [h,d,N], table [h,d,3,L], rel_idx [3,M] -> grad_attn [M,h], grad_v [N,h,d], grad_table [L,3,h,d]  */
+int u2mkd_sptr_attention_step2_with_rel_pos_value_forward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t n_max,
+                                                          const float *attn, const float *v,
+                                                          const int32_t *index0_offsets, const int32_t *index1,
+                                                          const float *table, const int32_t *rel_idx, float *output,
+                                                          u2mkd_stream_t s);
+int u2mkd_sptr_attention_step2_with_rel_pos_value_backward(int32_t N, int32_t M, int32_t h, int32_t hdim, int32_t L,
+                                                           int32_t n_max, const float *grad_out, const int32_t *index0,
+                                                           const int32_t *index0_offsets, const int32_t *index1,
+                                                           const int32_t *index1_offsets, const float *attn,
+                                                           const float *v, const float *table, const int32_t *rel_idx,
+                                                           float *grad_attn, float *grad_v, float *grad_table,
+                                                           u2mkd_stream_t s);
+
 /* ---- BatchNorm2d over NCHW maps, fused with the ReLU / residual add that follow it (csrc/bn2d.hip) -----------------
  * Replaces nn.BatchNorm2d -> nn.ReLU (and bn2(conv2(.)) + identity -> ReLU of BasicBlock) in the SwiftNet-18 camera
  * branch and the LiDAR->camera fusion convs (core/models/image_branch/swiftnet.py:20-50,114-341; the L2C blocks of

@@ -83,3 +83,24 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], capture_output=True, text=True,
                        timeout=280, env=env)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])['n_gpus'] == 1, r.stderr[-2000:]
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_stops_every_rank_when_one_dies_before_the_rendezvous():
+    """Rank 1 exits before init_process_group: rank 0 would wait in the rendezvous for ever.  The launcher must kill
+    it and exit non-zero well within the rendezvous timeout; and a run that exceeds U2MKD_BENCH_TIMEOUT likewise."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(U2MKD_BENCH_DRYRUN='1', U2MKD_BENCH_DRYRUN_FAIL_RANK='1')
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+                       timeout=280, env=env)
+    assert r.returncode != 0 and 'rank 1 exited with code 3' in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 120 and r.stdout.strip() == ''
+    # overall timeout: rank 0 dies silently late is not testable cheaply; a tiny timeout stops a healthy run too
+    env.pop('U2MKD_BENCH_DRYRUN_FAIL_RANK')
+    env['U2MKD_BENCH_TIMEOUT'] = '0.01'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+                       timeout=280, env=env)
+    assert r.returncode != 0 and 'no result after' in r.stderr

@@ -120,7 +120,7 @@ def test_kd_step_with_captured_camera_side_equals_eager_step(hip, monkeypatch):
         losses[mode] = [float(run(d)) for _ in range(3)]
         if mode:
             pieces = run.model.model_s._pieces
-            assert sorted(pieces) == sorted(['head', 'stage1', 'stage2', 'stage3', 'l2c0', 'l2c1', 'l2c2', 'l2c3', 'decoder'])
+            assert sorted(pieces) == sorted(['head', 'stage1', 'stage2', 'stage3', 'l2c0', 'l2c1', 'l2c2', 'l2c3', 'decoder_64x112'])
             for name, p in pieces.items():
                 assert p._records and all(r is not None for r in p._records.values()), name
             for n, p in run.model.model_s.named_parameters():
@@ -131,3 +131,38 @@ def test_kd_step_with_captured_camera_side_equals_eager_step(hip, monkeypatch):
     # noise the tiny scene amplifies
     assert np.isclose(losses[True][0], losses[False][0], rtol=2e-3), losses
     assert np.allclose(losses[True], losses[False], rtol=5e-2), losses
+
+
+def test_two_forwards_before_one_backward_keep_both_sets_of_activations(hip, monkeypatch):
+    """a second forward of a captured piece before the first one's backward must not overwrite the first
+    one's saved activations / outputs (two student passes summed into one loss).  The second call runs eagerly; a
+    forward whose graph is dropped without a backward does not block later replays."""
+    from u2mkd_amd import graphs
+    monkeypatch.setattr(graphs, '_ENABLED', True)
+    eager, replay, piece = _pair()
+    (x0, y0), (x1, y1) = _inputs(0), _inputs(1)
+    _loss(piece(x0, y0)).backward()                      # capture + one ordinary step
+    replay.zero_grad()
+    (xe0, ye0), (xe1, ye1) = _inputs(0), _inputs(1)
+    (xr0, yr0), (xr1, yr1) = _inputs(0), _inputs(1)
+    eager.load_state_dict(replay.state_dict())
+    out_a = piece(xr0, yr0)
+    kept = out_a[0].clone()
+    out_b = piece(xr1, yr1)                              # before out_a's backward
+    _same(out_a[0], kept, 'first output overwritten by the second forward')
+    (_loss(out_a) + _loss(out_b)).backward()
+    (_loss(eager(xe0, ye0)) + _loss(eager(xe1, ye1))).backward()
+    _same(ye0.grad, yr0.grad, 'input gradient of the first forward')
+    _same(ye1.grad, yr1.grad, 'input gradient of the second forward')
+    for (n, pe), pr in zip(eager.named_parameters(), replay.parameters()):
+        _same(pe.grad, pr.grad, n)
+    # a forward that never gets a backward: once its graph is gone the piece replays again
+    rec = next(iter(piece._records.values()))
+    out_c = piece(xr0, yr0)
+    assert rec.pending is not None
+    del out_c
+    assert rec.pending() is None
+    out_d = piece(xr0, yr0)
+    assert rec.pending is not None and rec.pending() is not None      # replayed (an eager call leaves `pending` alone)
+    _loss(out_d).backward()
+    assert rec.pending is None

@@ -1,6 +1,6 @@
 """Where the host waits during a KD step: time inside every blocking Tensor.item() / .tolist() / .cpu() / nonzero
 call by call site (ms per step), plus the host-side marks of the step (teacher issued, student forward issued,
-backward + optimizer returned, GPU drained).  Env knobs apply (e.g. U2MKD_TEACHER_AHEAD=1)."""
+backward + optimizer returned, GPU drained).  Env knobs of DESIGN.md section 7a apply."""
 import collections, os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

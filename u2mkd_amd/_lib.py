@@ -89,6 +89,17 @@ SIGNATURES = {
     'u2mkd_sptr_attention_forward_strided': (C.c_int, [_p, _p, _p, _i64, _f32] + [_p] * 8 + [_i32, _i32, _f32, _i64, _i32, _i32, _p, _i64, _p, _p]),
     'u2mkd_sptr_attention_backward_strided': (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _i64] + [_p] * 9 + [_i32, _i32, _f32, _i32, _i64, _i32, _i32]
                                               + [_p, _p, _sz] + [_p, _p, _p, _i64, _p, _p, _p, _p]),
+    # the ten sptr_cuda functions, argument for argument (csrc/sptr_ops.hip)
+    'u2mkd_sptr_precompute_all': (C.c_int, [_i32, _i32, C.c_uint32] + [_p] * 8),
+    'u2mkd_sptr_attention_step1_forward': (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_uint32] + [_p] * 6),
+    'u2mkd_sptr_attention_step1_backward': (C.c_int, [_i32, _i32, _i32, _i32, C.c_uint32] + [_p] * 10),
+    'u2mkd_sptr_attention_step2_forward': (C.c_int, [_i32] * 5 + [_p] * 6),
+    'u2mkd_sptr_attention_step2_backward': (C.c_int, [_i32] * 5 + [_p] * 10),
+    'u2mkd_sptr_dot_prod_with_idx_forward': (C.c_int, [_i32] * 6 + [_p] * 10),
+    'u2mkd_sptr_dot_prod_with_idx_all_forward': (C.c_int, [_i32] * 6 + [_p] * 10),
+    'u2mkd_sptr_dot_prod_with_idx_backward': (C.c_int, [_i32] * 6 + [_p] * 14),
+    'u2mkd_sptr_attention_step2_with_rel_pos_value_forward': (C.c_int, [_i32] * 5 + [_p] * 8),
+    'u2mkd_sptr_attention_step2_with_rel_pos_value_backward': (C.c_int, [_i32] * 6 + [_p] * 13),
     'u2mkd_count': (C.c_int, [_p, _i64, _p, _i64, _p]),
     'u2mkd_voxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_voxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),

@@ -11,6 +11,11 @@ private memory pool: the scheme of torch.cuda.make_graphed_callables), and a tra
 launches instead of ~700 kernel launches.  The captured kernels, their order and their arguments are the eager
 ones, so the results are the eager results.
 
+The OUTPUTS of a replayed piece are views of the graph's static memory: they are valid until the piece's next
+replay (the next training step).  Anything kept across steps (logged features, an exponential average of an
+activation) must be cloned by the holder.  Within a step the piece guards itself: a second forward of the same
+piece before the first one's backward runs eagerly instead of overwriting the first one's saved activations.
+
 Parameter gradients come out of a replay in static buffers, handed to autograd without a copy; ``.grad`` may
 therefore alias such a buffer until the next ``zero_grad(set_to_none=True)``.  A backward pass that finds a
 ``.grad`` still aliasing its buffer (gradient accumulation, or zero_grad(set_to_none=False)) first moves that
@@ -71,7 +76,7 @@ class PieceCache(dict):
 
 class _Record:
     """One captured (forward graph, backward graph) pair and its static tensors."""
-    __slots__ = ('fwd', 'bwd', 'sample', 'params', 'outs', 'spec', 'gouts', 'gins', 'pool')
+    __slots__ = ('fwd', 'bwd', 'sample', 'params', 'outs', 'spec', 'gouts', 'gins', 'pool', 'pending')
 
 
 class _Replay(torch.autograd.Function):
@@ -81,6 +86,8 @@ class _Replay(torch.autograd.Function):
             if s.data_ptr() != a.data_ptr():
                 s.copy_(a)
         rec.fwd.replay()
+        # the static activations now belong to THIS forward until its backward has run or its graph has been dropped
+        rec.pending = weakref.ref(ctx)
         ctx.rec = rec
         return tuple(o.detach() for o in rec.outs)
 
@@ -97,6 +104,7 @@ class _Replay(torch.autograd.Function):
             if g is not None and g.data_ptr() != grad.data_ptr():
                 g.copy_(grad)
         rec.bwd.replay()
+        rec.pending = None
         return (None,) + tuple(b.detach() if b is not None else None for b in rec.gins)
 
 
@@ -126,6 +134,12 @@ class StaticPiece:
             self._records[key] = self._capture(args) if len(self._records) < _MAX_SHAPES else None
         rec = self._records[key]
         if rec is None:
+            return self.fn(*args)
+        if rec.pending is not None and rec.pending() is not None:
+            # A second forward while an earlier one still waits for its backward (two student passes summed into one
+            # loss, gradient checkpointing): a replay would overwrite the saved activations and outputs of the first.
+            # This call runs eagerly on memory of its own.  (A forward whose backward never runs stops counting as
+            # soon as its autograd graph is released: `pending` is a weak reference to that graph's node.)
             return self.fn(*args)
         return tree_unflatten(list(_Replay.apply(rec, *args, *rec.params)), rec.spec)
 
@@ -191,4 +205,5 @@ class StaticPiece:
         gins[first:] = [k if g is not None else None for k, g in zip(keep, gins[first:])]
         gins = iter(gins)
         rec.gins = tuple(next(gins) if t.requires_grad else None for t in surface)
+        rec.pending = None
         return rec

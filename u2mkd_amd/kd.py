@@ -124,8 +124,11 @@ class StudentMSP2IFM(nn.Module):
                 blk = self.l2c_fusion_blocks[int(name[3:])]
                 fn, mods = (lambda fmap, skip: blk(fmap, skip)), [blk]
             else:
-                assert name == 'decoder', name
-                fn = lambda *feats: self.classifier_pix(pb.forward_up(list(feats), im_size=self._im_size))   # noqa: E731
+                # the up-sampling target is part of the piece's NAME: two image sizes with equal feature-map shapes
+                # (H = 359 and 360 both give H/2 = 180) must not share a captured graph
+                assert name.startswith('decoder_'), name
+                im_size = tuple(int(v) for v in name[8:].split('x'))
+                fn = lambda *feats: self.classifier_pix(pb.forward_up(list(feats), im_size=im_size))   # noqa: E731
                 mods = [pb.upsample, self.classifier_pix]
             pieces[name] = StaticPiece(name, fn, mods)
         return pieces[name]
@@ -200,10 +203,8 @@ class StudentMSP2IFM(nn.Module):
         # the pixel decoder (camera side) next to the voxel decoder (LiDAR side)
         x_pix = None
         if self.run_pix_decoder:
-            self.__dict__['_im_size'] = (ih, iw)
-
             def pix_decoder():
-                fmap = self._piece('decoder')(*img_feats)
+                fmap = self._piece('decoder_%dx%d' % (ih, iw))(*img_feats)
                 fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
                 return feature_fetch(masks, pixel_coordinates, fmap)
             x_pix = on_side(pix_decoder, *img_feats)
@@ -280,35 +281,10 @@ class TSDFull(nn.Module):
         if _CAMERA_STREAM and self.training:
             # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
             stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
-        # The teacher reads its input batch and its own frozen weights, nothing the student's optimizer step writes:
-        # with U2MKD_TEACHER_AHEAD=1 and the batch's "ready" event (train.kd_batch_to_device) its stream waits for
-        # that alone, so the teacher's forward of step k+1 -- and the host's waits for its voxel-set sizes -- run
-        # underneath the tail of step k's backward instead of behind it.  Off by default: measured 82.4-83.3 ms
-        # either way on MI355X (the step is bound by the GPU's total work, not by the host's idle 35 ms), and it
-        # obliges the caller not to touch the batch tensors after the event.
-        ready = in_mod['teacher'].get('ready') if _TEACHER_AHEAD else None
-        if ready is not None:
-            side.wait_event(ready)
-        else:
-            side.wait_stream(main)
-        calls = self.__dict__['_calls'] = self.__dict__.get('_calls', 0) + 1
-        if _TEACHER_THREAD and calls > 2:
-            # U2MKD_TEACHER_THREAD=1 (experiment, off by default).  The host is one Python thread and the teacher's forward
-            # is ~1500 launches (11 ms of host time) during which the main stream has nothing to run: a helper thread
-            # queues the teacher (its launches and its voxel-set synchronisations release the GIL) while this thread
-            # queues the student.  Streams, no_grad and autocast are per thread and set inside the job; the first two
-            # calls run in order (the camera pieces are captured into hipGraphs then).  Measured on MI355X over 40-step
-            # runs: 83.9-87.7 ms with the interpreter's 5 ms switch interval, 79.8-82.6 ms at 0.5 ms
-            # (U2MKD_SWITCH_INTERVAL_MS), against 82.5-82.8 ms without the thread: GIL hand-over noise as large as
-            # the gain.
-            amp = (torch.get_autocast_dtype('cuda'), torch.is_autocast_enabled('cuda'))
-            job = _teacher_pool().submit(_teacher_job, self.model_t, in_mod['teacher'], side, amp)
-            ret = {'stu': self.model_s(stu_in)}
-            t = job.result()
-        else:
-            with torch.cuda.stream(side), torch.no_grad():
-                t = self.model_t(in_mod['teacher'])
-            ret = {'stu': self.model_s(stu_in)}
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            t = self.model_t(in_mod['teacher'])
+        ret = {'stu': self.model_s(stu_in)}
         main.wait_stream(side)
         for v in _tensors(t):
             v.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
@@ -317,28 +293,6 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
-_TEACHER_THREAD = os.environ.get('U2MKD_TEACHER_THREAD', '0') == '1'      # measured 79.8-87.7 ms against 82.5-82.8: off
-_POOL = []
-
-
-def _teacher_pool():
-    if not _POOL:
-        import sys
-        from concurrent.futures import ThreadPoolExecutor
-        si = float(os.environ.get('U2MKD_SWITCH_INTERVAL_MS', '0'))
-        if si > 0:
-            sys.setswitchinterval(si * 1e-3)
-        _POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='u2mkd-teacher'))
-    return _POOL[0]
-
-
-def _teacher_job(model_t, in_t, side, amp):
-    torch.cuda.set_device(side.device)
-    with torch.cuda.stream(side), torch.no_grad(), torch.autocast('cuda', dtype=amp[0], enabled=amp[1]):
-        return model_t(in_t)
-
-
-_TEACHER_AHEAD = os.environ.get('U2MKD_TEACHER_AHEAD', '0') == '1'
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 _SIDE = {}
 

@@ -257,10 +257,13 @@ _RANGE_FLAGS = {}
 
 
 def _range_flag(device):
-    """Per-device int32 the key kernel raises when a coordinate cannot be packed (see u2mkd_downsample_keys_checked)."""
-    f = _RANGE_FLAGS.get(device.index)
+    """int32 the key kernel raises when a coordinate cannot be packed (see u2mkd_downsample_keys_checked).  One per
+    (device, stream), like ``_scratch``: the frozen teacher on its side stream and the student on the main stream call
+    ``spdownsample`` concurrently, and a shared flag could be read or cleared by the wrong caller."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    f = _RANGE_FLAGS.get(key)
     if f is None:
-        f = _RANGE_FLAGS[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+        f = _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return f
 
 

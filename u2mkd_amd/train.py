@@ -12,7 +12,7 @@ from . import kd as KD
 from . import torchsparse as ts
 from .losses import MixLovaszCrossEntropy
 
-__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device', 'state_dict',
+__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device', 'fresh_batch', 'state_dict',
            'load_state_dict', 'load_weights']
 
 
@@ -102,12 +102,20 @@ def kd_batch_to_device(b, device='cuda'):
         'num_pts': list(t['num_pts']), 'num_vox_t': list(t['num_vox']),
         'keyframe_mask_full': f(t['keyframe_mask_full']) if 'keyframe_mask_full' in t else None,
     }
-    if dev.type == 'cuda':
-        # "the batch is on the device": what the frozen teacher's forward of this batch has to wait for -- not for
-        # the previous step's backward and optimizer, which precede it on the main stream (kd.TSDFull.forward)
-        out['ready'] = torch.cuda.Event()
-        out['ready'].record(torch.cuda.current_stream(dev))
     return out
+
+
+def fresh_batch(d):
+    """A new device copy of a resident KD batch: every tensor a new object (``clone``), as the host-to-device copy of a
+    data loader delivers one per step (core/nusc_trainers.py:257-279).  Nothing that an earlier step cached on a batch
+    tensor (point<->pixel plans hang on ``masks[0]``) can be seen by the step that receives the copy."""
+    def cp(v):
+        if torch.is_tensor(v):
+            return v.clone()
+        if isinstance(v, (list, tuple)):
+            return type(v)(cp(x) for x in v)
+        return v
+    return {k: cp(v) for k, v in d.items()}
 
 
 class KDStep:
@@ -132,7 +140,7 @@ class KDStep:
     def __call__(self, d):
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
                'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
-        tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords']), 'ready': d.get('ready')}
+        tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
         with self.amp.autocast():
             out = self.net({'student': stu, 'teacher': tea})
             ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
