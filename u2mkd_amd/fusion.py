@@ -182,7 +182,8 @@ def c2l_gather(feature_maps, pixel_coordinates, masks):
     _lib.require_cuda(feature_maps)                      # HIP device only; there is no CPU fallback
     from .torchsparse.nn import functional as spf
     B, ncam, C, h, w = feature_maps.shape
-    idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w))
+    idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w),
+                         *masks[1:], *pixel_coordinates)
     rows = _NchwToRows.apply(feature_maps)
     if C % 4:                                   # e.g. the 17-class logit map: pad rows to whole 16-byte segments
         rows = F.pad(rows, (0, 4 - C % 4))
@@ -258,7 +259,7 @@ def _l2c_plan(pixel_coordinates, masks, ch, cw):
         key_s = torch.where(mask, row, torch.full_like(row, -1)).int()
         order_s, seg_s = spf._csr_by_destination(key_s, n_pts)
         return order_s.long(), seg_s
-    os_, seg_s = spf._plan(masks[0], 'l2c_by_source', by_source)
+    os_, seg_s = spf._plan(masks[0], 'l2c_by_source', by_source, *masks[1:])
     fwd = (row[od].int().contiguous(), w[od].contiguous(), seg_d)
     bwd = (pix[os_].int().contiguous(), w[os_].contiguous(), seg_s)
     return fwd, bwd, n_dst
@@ -281,7 +282,7 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
         ch = int(round(float(ifh) / cnt + 0.01))
         cw = int(round(float(ifw) / cnt + 0.01))
         fwd, bwd, n_dst = spf._plan(masks[0], 'l2c_%d_%d' % (ch, cw),
-                                    lambda: _l2c_plan(pixel_coordinates, masks, ch, cw))
+                                    lambda: _l2c_plan(pixel_coordinates, masks, ch, cw), *masks[1:], *pixel_coordinates)
         grid = _SegmentMap.apply(point_feats, fwd, bwd, n_dst).view(B * ncam, ch, cw, C).permute(0, 3, 1, 2)
         up = grid if (ch, cw) == (ifh, ifw) else F.interpolate(grid, (ifh, ifw), mode='bilinear', align_corners=True)
         total = up if total is None else total + up

@@ -563,19 +563,38 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
     return sch.run(feats, weight, transpose, cout, kflip, out)
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def invalidate_weight_caches(*_):
+    """Forget every cached weight re-layout.  The caches are stamped with the tensor's in-place version counter and
+    storage address, which writes through ``.data`` (``p.data.add_`` of an EMA or a hand-written optimizer,
+    ``kernel.data.uniform_`` of a re-initialisation) do not move; so the stamp also carries this epoch, bumped after
+    EVERY ``torch.optim.Optimizer.step`` (global post hook below) and by whoever writes weights behind autograd's back."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+    _reg_post(invalidate_weight_caches)
+except ImportError:                                  # pragma: no cover -- torch < 2.0 has no global hook
+    pass
+
+
 def _weight_layout(weight, transpose, fragments):
     """The layout of `kernel` [K, R, C] a conv kernel reads: rows of B_k = output columns, reduction contiguous.
     transpose: B_k[col][red] = weight[k][red][col] (else weight[k][col][red], the tensor as it is).
     fragments: MFMA operand-fragment order (u2mkd_weight_fragments) instead of row-major [K, ncol, nred].
     Fragments of BOTH orientations come from one launch (latency-bound: 5 us for one or for two) and are cached
-    on the tensor with its in-place version and storage address, so the forward's launch also serves the input
-    gradient of the same step; row-major layouts are cached for FROZEN weights only (requires_grad False: the KD
-    teacher, inference), trained weights are re-laid out per call."""
+    on the tensor with its in-place version, storage address and (trainable weights) the optimizer-step epoch of
+    ``invalidate_weight_caches``, so the forward's launch also serves the input gradient of the same step but never a
+    later step; row-major layouts are cached for FROZEN weights only (requires_grad False: the KD teacher, inference),
+    trained weights are re-laid out per call."""
     if not transpose and not fragments:
         return weight
     k, r, c = weight.shape if weight.dim() == 3 else (1,) + tuple(weight.shape)     # 2-D: nn.Linear's [out, in], one offset
     frozen = not weight.requires_grad
-    stamp = (weight._version, weight.data_ptr())
+    stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0] if not frozen else -1)
     if fragments:
         hit = weight.__dict__.get('_u2mkd_wfrag')
         if hit is None or hit[0] != stamp:
