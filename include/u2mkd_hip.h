@@ -223,6 +223,18 @@ int u2mkd_conv_forward_tiles_bf16(const void *in /*bf16 [n_in,cin]*/, int64_t n_
 int u2mkd_conv_wgrad_pairs_bf16(const void *a /*bf16 [.,ca]*/, int32_t ca, const void *b /*bf16 [.,cb]*/, int32_t cb,
                                 const int32_t *pairs, const int32_t *plan, int64_t n_rows, int32_t k, int32_t swap,
                                 void *workspace, size_t workspace_bytes, float *dw /*[k,ca,cb] fp32*/, u2mkd_stream_t s);
+/* The wide layers (cin * cout >= 8192), nn.Linear and the pair schedule's gather-sum on bf16 rows (csrc/conv_px3.hip B16):
+ * u2mkd_conv_forward_pairs_x3 / u2mkd_linear_forward_x3 / u2mkd_pairs_gather_sum with bf16 rows in and out (the scratch
+ * rows y are bf16 too), wf = the arith-3 fragments (u2mkd_weight_fragments: conv forward transpose = 1, input gradient /
+ * transposed roles transpose = 0; Linear: w [cout_l, cin_l] with k = 1, forward orientation 1 = transpose 0), bias fp32,
+ * cin and cout multiples of 32 (gather-sum: cout a multiple of 8), fp32 accumulation, ONE rounding per stored value.   */
+int u2mkd_conv_forward_pairs_bf16(const void *in /*bf16 [n_in,cin]*/, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                   const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                   int32_t k, void *y /*bf16 [capacity,cout]*/, u2mkd_stream_t s);
+int u2mkd_linear_forward_bf16(const void *x /*bf16 [n,cin]*/, int64_t n, int32_t cin, const void *wf, int32_t cout,
+                              const float *bias /*[cout] or NULL*/, void *y /*bf16 [n,cout]*/, u2mkd_stream_t s);
+int u2mkd_pairs_gather_sum_bf16(const void *y /*bf16*/, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k,
+                                int32_t cout, void *out /*bf16 [n_rows,cout]*/, u2mkd_stream_t s);
 /* The TILE SCHEDULE of a (mask-sorted) neighbour table, built on the device (csrc/schedule.hip): `mask` = the
  * rows' neighbour masks (u2mkd_kmap_rowmask), `order` = the row permutation that sorts them (NULL: identity);
  * a tile = 64 consecutive sorted rows, its weight = its 16-pair MFMA blocks (sum over offsets of ceil(pairs / 16)).
@@ -298,6 +310,17 @@ int u2mkd_devoxelize_backward(const float *grad_out /*[n,c]*/, const int32_t *id
 int u2mkd_segment_sum(const float *src /*[*,c]*/, int32_t c, const int32_t *entry_row /*[E]*/,
                       const float *entry_w /*[E] or NULL*/, const int32_t *seg_offsets /*[nv+1]*/, int64_t nv,
                       int32_t mean, float *out /*[nv,c]*/, u2mkd_stream_t s);
+/* The row movers of the point <-> voxel transfers on BF16 rows (BASELINE.json configs[4]; torchsparse's voxelize /
+ * devoxelize functions cast to half under autocast like its conv): feature rows in and out are bf16 [., c], c a multiple
+ * of 4, sums in fp32 in the same fixed order, one rounding at the store.  u2mkd_segment_sum_bf16 serves voxelize forward
+ * and devoxelize backward exactly as u2mkd_segment_sum does.                                                        */
+int u2mkd_voxelize_backward_bf16(const void *grad_out /*bf16 [nv,c]*/, const int32_t *idx, const int32_t *counts, int64_t n,
+                                 int64_t nv, int32_t c, void *grad_feats /*bf16 [n,c]*/, u2mkd_stream_t s);
+int u2mkd_devoxelize_forward_bf16(const void *feats /*bf16 [nv,c]*/, const int32_t *idx /*[n,8]*/, const float *w /*[n,8]*/,
+                                  int64_t n, int32_t c, void *out /*bf16 [n,c]*/, u2mkd_stream_t s);
+int u2mkd_segment_sum_bf16(const void *src /*bf16 [*,c]*/, int32_t c, const int32_t *entry_row /*[E]*/,
+                           const float *entry_w /*[E] or NULL*/, const int32_t *seg_offsets /*[nv+1]*/, int64_t nv,
+                           int32_t mean, void *out /*bf16 [nv,c]*/, u2mkd_stream_t s);
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 
@@ -358,6 +381,31 @@ int u2mkd_bn_backward_local(const float *dy, const float *x, int64_t n, int32_t 
 int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t c, const float *total_n /*[1] device*/,
                             const float *mean, const float *invstd, const float *gamma, const float *beta,
                             int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx, u2mkd_stream_t s);
+
+/* The BatchNorm entries above on BF16 ROWS (BASELINE.json configs[4]; under autocast the reference's nn.BatchNorm1d takes
+ * and returns half rows while its statistics stay fp32): x, res, y, dy, dx, dres are bf16 [n, c]; gamma, beta, running
+ * statistics, mean, invstd, partial, dgamma, dbeta, stats and sums are fp32 exactly as above; every value is rounded to
+ * bf16 once, at its store.  The fused ReLU mask is recomputed in the backward from the bf16 x with the forward's fp32
+ * expression, so forward and backward agree on it.                                                                  */
+int u2mkd_bn_train_forward_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *gamma,
+                                    const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                    int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd,
+                                    void *y, u2mkd_stream_t s);
+int u2mkd_bn_eval_forward_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                                   float eps, const float *running_mean, const float *running_var, int32_t relu,
+                                   float *invstd, void *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *mean,
+                               const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                               float *partial, float *dgamma, float *dbeta, void *dx, void *dres, u2mkd_stream_t s);
+int u2mkd_bn_local_stats_bf16(const void *x, int64_t n, int32_t c, float *partial, float *stats, u2mkd_stream_t s);
+int u2mkd_bn_apply_bf16(const void *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
+                        const float *beta, int32_t relu, void *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_local_bf16(const void *dy, const void *x, int64_t n, int32_t c, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, int32_t relu, float *partial, float *sums,
+                                 u2mkd_stream_t s);
+int u2mkd_bn_backward_apply_bf16(const void *dy, const void *x, int64_t n, int32_t c, const float *total_n, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, int32_t relu, const float *sums,
+                                 void *dx, u2mkd_stream_t s);
 
 /* ---- SphereFormer / sptr window attention ---------------------------------------
  * replaces the extern "C" launchers of third_party/SparseTransformer/src/sptr:

@@ -64,6 +64,9 @@ SIGNATURES = {
     'u2mkd_conv_wgrad_pairs': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
     'u2mkd_conv_forward_tiles_bf16': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_conv_wgrad_pairs_bf16': (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _sz, _p, _p]),
+    'u2mkd_conv_forward_pairs_bf16': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_linear_forward_bf16': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
+    'u2mkd_pairs_gather_sum_bf16': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_convolution_workspace_bytes': (_sz, [_i64, _i64, _i32, _i32, _p, _i32]),
     'u2mkd_convolution_forward': (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
     'u2mkd_convolution_backward': (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _sz, _p]),
@@ -80,6 +83,13 @@ SIGNATURES = {
     'u2mkd_bn_apply': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_bn_backward_local': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_apply': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_train_forward_res_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_eval_forward_res_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward_res_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_local_stats_bf16': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    'u2mkd_bn_apply_bf16': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_bn_backward_local_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward_apply_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_sptr_window_keys': (C.c_int, [_p, _p, _i64, _p, _p, _f32, _f32, _f32, _p, _p]),
     'u2mkd_sptr_window_ranges': (C.c_int, [_p, _i64, _p, _p, _p]),
     'u2mkd_sptr_quant_coords': (C.c_int, [_p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _f32, _p, _p, _p]),
@@ -106,6 +116,9 @@ SIGNATURES = {
     'u2mkd_devoxelize_forward': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_devoxelize_backward': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_segment_sum': (C.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_voxelize_backward_bf16': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    'u2mkd_devoxelize_forward_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_segment_sum_bf16': (C.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),
 }
 

@@ -21,6 +21,9 @@ namespace u2mkd {
 constexpr int kBnThreads = 256;
 constexpr int kBnSlabRows = 128;   // rows per workgroup in the partial passes (>= 600 workgroups at 80k rows)
 
+// Rows are float or bf16 (common.h: bf16row, ld4, st4).  BF16 STORAGE (BASELINE.json configs[4]): under autocast the
+// reference's BatchNorm1d takes and returns half rows with fp32 statistics; here bf16 rows, every sum, mean, invstd
+// and gradient sum in fp32, one rounding per stored element.
 // thread layout for a [rows, C4 float4] slab: j = float4 column, ry = row lane
 struct BnLayout {
     int c4, rl;
@@ -34,8 +37,9 @@ __device__ __forceinline__ BnLayout bn_layout(int c) {
 }
 
 // partial: [nslab][2][C] (mean_b, M2_b); rows of slab b = min(kBnSlabRows, n - b*kBnSlabRows)
+template <typename T>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__restrict__ partial) {
+bn_stats_partial_kernel(const T *__restrict__ x, int64_t n, int c, float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];   // [rl][c4] (c4 <= 256)
     const int c4 = c >> 2;
     const int nloop = (c4 + kBnThreads - 1) / kBnThreads;           // > 1 only for C > 1024
@@ -49,7 +53,7 @@ bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
             for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
+                float4 v = ld4(x, (r0 + rr) * c4 + j);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         if (live) red[ry * c4 + (j % c4)] = s;
@@ -67,7 +71,7 @@ bn_stats_partial_kernel(const float *__restrict__ x, int64_t n, int c, float *__
         float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
             for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
+                float4 v = ld4(x, (r0 + rr) * c4 + j);
                 float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
                 m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
             }
@@ -163,14 +167,15 @@ bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n
 
 // y = (x - mean) * invstd * gamma + beta [, relu]; gamma / beta may be null (affine=False)
 // res (may be null): the residual branch of a ResidualBlock, y = relu(bn(x) + res) in the same pass
-__global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
+template <typename T>
+__global__ void bn_apply_kernel(const T *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
                                 const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                const float *__restrict__ beta, int relu, float *__restrict__ y,
-                                const float *__restrict__ res = nullptr) {
+                                const float *__restrict__ beta, int relu, T *__restrict__ y,
+                                const T *__restrict__ res = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     int j = (int)(t % c4) * 4;
-    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 v = ld4(x, t);
     float4 m = *reinterpret_cast<const float4 *>(mean + j);
     float4 is = *reinterpret_cast<const float4 *>(invstd + j);
     float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -181,25 +186,26 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, int64_t total4, int
     o.z = (v.z - m.z) * is.z * g.z + b.z;
     o.w = (v.w - m.w) * is.w * g.w + b.w;
     if (res) {
-        const float4 rv = reinterpret_cast<const float4 *>(res)[t];
+        const float4 rv = ld4(res, t);
         o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    reinterpret_cast<float4 *>(y)[t] = o;
+    st4(y, t, o);
 }
 
 // eval mode: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta [, relu] in ONE launch (the separate
 // invstd pass was a launch per layer of the frozen KD teacher); workgroup 0 also writes invstd for a backward pass
-__global__ void bn_apply_eval_kernel(const float *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
+template <typename T>
+__global__ void bn_apply_eval_kernel(const T *__restrict__ x, int64_t total4, int c4, const float *__restrict__ mean,
                                      const float *__restrict__ var, float eps, const float *__restrict__ gamma,
                                      const float *__restrict__ beta, int relu, float *__restrict__ invstd_out,
-                                     float *__restrict__ y, const float *__restrict__ res = nullptr) {
+                                     T *__restrict__ y, const T *__restrict__ res = nullptr) {
     if (blockIdx.x == 0 && invstd_out)
         for (int ch = threadIdx.x; ch < 4 * c4; ch += blockDim.x) invstd_out[ch] = 1.f / sqrtf(var[ch] + eps);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     int j = (int)(t % c4) * 4;
-    float4 v = reinterpret_cast<const float4 *>(x)[t];
+    float4 v = ld4(x, t);
     float4 m = *reinterpret_cast<const float4 *>(mean + j);
     float4 vr = *reinterpret_cast<const float4 *>(var + j);
     float4 is = make_float4(1.f / sqrtf(vr.x + eps), 1.f / sqrtf(vr.y + eps), 1.f / sqrtf(vr.z + eps), 1.f / sqrtf(vr.w + eps));
@@ -211,19 +217,20 @@ __global__ void bn_apply_eval_kernel(const float *__restrict__ x, int64_t total4
     o.z = (v.z - m.z) * is.z * g.z + b.z;
     o.w = (v.w - m.w) * is.w * g.w + b.w;
     if (res) {
-        const float4 rv = reinterpret_cast<const float4 *>(res)[t];
+        const float4 rv = ld4(res, t);
         o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    reinterpret_cast<float4 *>(y)[t] = o;
+    st4(y, t, o);
 }
 
 // partial: [nslab][2][C] (sum dy', sum dy' * xhat)
+template <typename T>
 __global__ void __launch_bounds__(kBnThreads)
-bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t n, int c,
+bn_bwd_partial_kernel(const T *__restrict__ dy, const T *__restrict__ x, int64_t n, int c,
                       const float *__restrict__ mean, const float *__restrict__ invstd,
                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                      float *__restrict__ partial, const float *__restrict__ res = nullptr) {
+                      float *__restrict__ partial, const T *__restrict__ res = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];   // [2][rl][c4]
     const int c4 = c >> 2;
     const int nloop = (c4 + kBnThreads - 1) / kBnThreads;
@@ -243,11 +250,11 @@ bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
             float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + 4 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
             float4 b = beta ? *reinterpret_cast<const float4 *>(beta + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
             for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = *reinterpret_cast<const float4 *>(x + (r0 + rr) * c + 4 * j);
-                float4 d = *reinterpret_cast<const float4 *>(dy + (r0 + rr) * c + 4 * j);
+                float4 v = ld4(x, (r0 + rr) * c4 + j);
+                float4 d = ld4(dy, (r0 + rr) * c4 + j);
                 float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
                 if (relu) {
-                    const float4 rv = res ? *reinterpret_cast<const float4 *>(res + (r0 + rr) * c + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 rv = res ? ld4(res, (r0 + rr) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
                     if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
                     if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
                     if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
@@ -303,19 +310,20 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, floa
     dgamma[ch] = s2;
 }
 
-__global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ x, int64_t total4, int c4,
                                     float inv_n_host, const float *__restrict__ total_n,
                                     const float *__restrict__ mean, const float *__restrict__ invstd,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                     const float *__restrict__ dbeta, const float *__restrict__ dgamma,
-                                    float *__restrict__ dx, const float *__restrict__ res = nullptr,
-                                    float *__restrict__ dres = nullptr) {
+                                    T *__restrict__ dx, const T *__restrict__ res = nullptr,
+                                    T *__restrict__ dres = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     const float inv_n = total_n ? 1.f / *total_n : inv_n_host;     // SyncBatchNorm: the count of all ranks
     int j = (int)(t % c4) * 4;
-    float4 v = reinterpret_cast<const float4 *>(x)[t];
-    float4 d = reinterpret_cast<const float4 *>(dy)[t];
+    float4 v = ld4(x, t);
+    float4 d = ld4(dy, t);
     float4 m = *reinterpret_cast<const float4 *>(mean + j);
     float4 is = *reinterpret_cast<const float4 *>(invstd + j);
     float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -324,45 +332,46 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
     float4 dg = *reinterpret_cast<const float4 *>(dgamma + j);
     float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
     if (relu) {
-        const float4 rv = res ? reinterpret_cast<const float4 *>(res)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rv = res ? ld4(res, t) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
         if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
         if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
         if (hw * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
     }
-    if (dres) reinterpret_cast<float4 *>(dres)[t] = d;          // gradient of the residual branch = the masked dy
+    if (dres) st4(dres, t, d);          // gradient of the residual branch = the masked dy
     float4 o;
     o.x = g.x * is.x * (d.x - db.x * inv_n - hx * dg.x * inv_n);
     o.y = g.y * is.y * (d.y - db.y * inv_n - hy * dg.y * inv_n);
     o.z = g.z * is.z * (d.z - db.z * inv_n - hz * dg.z * inv_n);
     o.w = g.w * is.w * (d.w - db.w * inv_n - hw * dg.w * inv_n);
-    reinterpret_cast<float4 *>(dx)[t] = o;
+    st4(dx, t, o);
 }
 
 // eval-mode backward / plain affine: dx = dy' * gamma * invstd
-__global__ void bn_bwd_eval_kernel(const float *__restrict__ dy, const float *__restrict__ x, int64_t total4, int c4,
+template <typename T>
+__global__ void bn_bwd_eval_kernel(const T *__restrict__ dy, const T *__restrict__ x, int64_t total4, int c4,
                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                   float *__restrict__ dx, const float *__restrict__ res = nullptr,
-                                   float *__restrict__ dres = nullptr) {
+                                   T *__restrict__ dx, const T *__restrict__ res = nullptr,
+                                   T *__restrict__ dres = nullptr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total4) return;
     int j = (int)(t % c4) * 4;
-    float4 v = reinterpret_cast<const float4 *>(x)[t];
-    float4 d = reinterpret_cast<const float4 *>(dy)[t];
+    float4 v = ld4(x, t);
+    float4 d = ld4(dy, t);
     float4 m = *reinterpret_cast<const float4 *>(mean + j);
     float4 is = *reinterpret_cast<const float4 *>(invstd + j);
     float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + j) : make_float4(1.f, 1.f, 1.f, 1.f);
     float4 b = beta ? *reinterpret_cast<const float4 *>(beta + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (relu) {
-        const float4 rv = res ? reinterpret_cast<const float4 *>(res)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rv = res ? ld4(res, t) : make_float4(0.f, 0.f, 0.f, 0.f);
         if ((v.x - m.x) * is.x * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
         if ((v.y - m.y) * is.y * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
         if ((v.z - m.z) * is.z * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
         if ((v.w - m.w) * is.w * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
     }
-    if (dres) reinterpret_cast<float4 *>(dres)[t] = d;
-    reinterpret_cast<float4 *>(dx)[t] = make_float4(d.x * g.x * is.x, d.y * g.y * is.y, d.z * g.z * is.z, d.w * g.w * is.w);
+    if (dres) st4(dres, t, d);
+    st4(dx, t, make_float4(d.x * g.x * is.x, d.y * g.y * is.y, d.z * g.z * is.z, d.w * g.w * is.w));
 }
 
 __global__ void bn_invstd_kernel(const float *__restrict__ var, int c, float eps, float *__restrict__ invstd) {
@@ -408,9 +417,134 @@ static size_t bn_lds_bytes(int c, int arrays) {
     return (size_t)arrays * rl * cw * sizeof(float4);
 }
 
+// ---- launch sequences, shared by the fp32-row and the bf16-row entry points ------------------------------------
+template <typename T>
+static int bn_train_forward_impl(const T *x, const T *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                                 float eps, float momentum, float *running_mean, float *running_var,
+                                 int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd, T *y,
+                                 u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(n > 0, "u2mkd_bn_train_forward: empty batch (n=%lld)", (long long)n);
+    U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
+    hipStream_t st = as_stream(s);
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
+                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked);
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
+                       invstd, gamma, beta, relu, y, res);
+    return check_launch("u2mkd_bn_train_forward");
+}
+
+template <typename T>
+static int bn_eval_forward_impl(const T *x, const T *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                                float eps, const float *running_mean, const float *running_var, int32_t relu, float *invstd,
+                                T *y, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_eval_forward: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(x && running_mean && running_var && invstd && y, "u2mkd_bn_eval_forward: null pointer");
+    hipStream_t st = as_stream(s);
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_eval_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
+                       running_mean, running_var, eps, gamma, beta, relu, invstd, y, res);
+    return check_launch("u2mkd_bn_eval_forward");
+}
+
+template <typename T>
+static int bn_backward_impl(const T *dy, const T *x, const T *res, int64_t n, int32_t c, const float *mean,
+                            const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                            float *partial, float *dgamma, float *dbeta, T *dx, T *dres, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE((res == nullptr) == (dres == nullptr), "u2mkd_bn_backward_res: res and dres go together");
+    U2_REQUIRE(res == nullptr || relu, "u2mkd_bn_backward_res: a residual input is only fused with the ReLU form");
+    if (n == 0) return 0;
+    U2_REQUIRE(dy && x && mean && invstd && partial && dgamma && dbeta && dx, "u2mkd_bn_backward: null pointer");
+    hipStream_t st = as_stream(s);
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
+                       invstd, gamma, beta, relu, partial, res);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
+                       dbeta, dgamma);
+    int64_t total4 = n * (c / 4);
+    if (training)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
+                           c / 4, 1.f / (float)n, (const float *)nullptr, mean, invstd, gamma, beta, relu, dbeta, dgamma,
+                           dx, res, dres);
+    else
+        hipLaunchKernelGGL(bn_bwd_eval_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
+                           c / 4, mean, invstd, gamma, beta, relu, dx, res, dres);
+    return check_launch("u2mkd_bn_backward");
+}
+
+template <typename T>
+static int bn_local_stats_impl(const T *x, int64_t n, int32_t c, float *partial, float *stats, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_local_stats: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(stats && (n == 0 || (x && partial)), "u2mkd_bn_local_stats: null pointer");
+    hipStream_t st = as_stream(s);
+    if (n == 0) {
+        (void)hipMemsetAsync(stats, 0, (size_t)(2 * c + 1) * sizeof(float), st);
+        return check_launch("u2mkd_bn_local_stats");
+    }
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab,
+                       n, c, 0.f, 0.f, (float *)nullptr, (float *)nullptr, stats, (float *)nullptr, stats + c);
+    return check_launch("u2mkd_bn_local_stats");
+}
+
+template <typename T>
+static int bn_apply_impl(const T *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
+                         const float *beta, int32_t relu, T *y, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_apply: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(x && mean && invstd && y, "u2mkd_bn_apply: null pointer");
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), x, total4,
+                       c / 4, mean, invstd, gamma, beta, relu, y, (const T *)nullptr);
+    return check_launch("u2mkd_bn_apply");
+}
+
+template <typename T>
+static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c, const float *mean, const float *invstd,
+                                  const float *gamma, const float *beta, int32_t relu, float *partial, float *sums,
+                                  u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward_local: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(sums, "u2mkd_bn_backward_local: null pointer");
+    hipStream_t st = as_stream(s);
+    if (n == 0) {
+        (void)hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st);
+        return check_launch("u2mkd_bn_backward_local");
+    }
+    U2_REQUIRE(dy && x && mean && invstd && partial, "u2mkd_bn_backward_local: null pointer");
+    int nslab = (int)u2mkd_bn_num_slabs(n);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
+                       invstd, gamma, beta, relu, partial, (const T *)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
+                       sums, sums + c);
+    return check_launch("u2mkd_bn_backward_local");
+}
+
+template <typename T>
+static int bn_backward_apply_impl(const T *dy, const T *x, int64_t n, int32_t c, const float *total_n, const float *mean,
+                                  const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                  const float *sums, T *dx, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_backward_apply: c=%d must be a positive multiple of 4", c);
+    if (n == 0) return 0;
+    U2_REQUIRE(dy && x && total_n && mean && invstd && sums && dx, "u2mkd_bn_backward_apply: null pointer");
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), dy, x,
+                       total4, c / 4, 0.f, total_n, mean, invstd, gamma, beta, relu, sums, sums + c, dx, (const T *)nullptr,
+                       (T *)nullptr);
+    return check_launch("u2mkd_bn_backward_apply");
+}
+
 }  // namespace u2mkd
 
 using namespace u2mkd;
+
+#define BF(p) reinterpret_cast<const bf16row *>(p)
+#define BFW(p) reinterpret_cast<bf16row *>(p)
 
 extern "C" {
 
@@ -419,7 +553,10 @@ int64_t u2mkd_bn_num_slabs(int64_t n) { return n > 0 ? (n + kBnSlabRows - 1) / k
 int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
                                float eps, float momentum, float *running_mean, float *running_var,
                                int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd, float *y,
-                               u2mkd_stream_t s);
+                               u2mkd_stream_t s) {
+    return bn_train_forward_impl<float>(x, res, n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                                        num_batches_tracked, relu, partial, mean, invstd, y, s);
+}
 
 int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                                    float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
@@ -437,27 +574,11 @@ int u2mkd_bn_train_forward(const float *x, int64_t n, int32_t c, const float *ga
                                           partial, mean, invstd, y, s);
 }
 
-int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
-                               float eps, float momentum, float *running_mean, float *running_var,
-                               int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd, float *y,
-                               u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward: c=%d must be a multiple of 4 in 4..1024", c);
-    U2_REQUIRE(n > 0, "u2mkd_bn_train_forward: empty batch (n=%lld)", (long long)n);
-    U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
-    hipStream_t st = as_stream(s);
-    int nslab = (int)u2mkd_bn_num_slabs(n);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
-                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked);
-    int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
-                       invstd, gamma, beta, relu, y, res);
-    return check_launch("u2mkd_bn_train_forward");
-}
-
 int u2mkd_bn_eval_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
                               float eps, const float *running_mean, const float *running_var, int32_t relu,
-                              float *invstd /*[c]*/, float *y, u2mkd_stream_t s);
+                              float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
+    return bn_eval_forward_impl<float>(x, res, n, c, gamma, beta, eps, running_mean, running_var, relu, invstd, y, s);
+}
 
 int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,
                           const float *running_mean, const float *running_var, int32_t relu, float *invstd /*[c]*/,
@@ -465,22 +586,12 @@ int u2mkd_bn_eval_forward(const float *x, int64_t n, int32_t c, const float *gam
     return u2mkd_bn_eval_forward_res(x, nullptr, n, c, gamma, beta, eps, running_mean, running_var, relu, invstd, y, s);
 }
 
-int u2mkd_bn_eval_forward_res(const float *x, const float *res, int64_t n, int32_t c, const float *gamma, const float *beta,
-                              float eps, const float *running_mean, const float *running_var, int32_t relu,
-                              float *invstd /*[c]*/, float *y, u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_eval_forward: c=%d must be a positive multiple of 4", c);
-    if (n == 0) return 0;
-    U2_REQUIRE(x && running_mean && running_var && invstd && y, "u2mkd_bn_eval_forward: null pointer");
-    hipStream_t st = as_stream(s);
-    int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_apply_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4,
-                       running_mean, running_var, eps, gamma, beta, relu, invstd, y, res);
-    return check_launch("u2mkd_bn_eval_forward");
-}
-
 int u2mkd_bn_backward_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
                           const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
-                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s);
+                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s) {
+    return bn_backward_impl<float>(dy, x, res, n, c, mean, invstd, gamma, beta, relu, training, partial, dgamma, dbeta, dx,
+                                   dres, s);
+}
 
 int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int32_t relu, int32_t training, float *partial,
@@ -489,47 +600,11 @@ int u2mkd_bn_backward(const float *dy, const float *x, int64_t n, int32_t c, con
                                  nullptr, s);
 }
 
-int u2mkd_bn_backward_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
-                          const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
-                          float *partial, float *dgamma, float *dbeta, float *dx, float *dres, u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward: c=%d must be a multiple of 4 in 4..1024", c);
-    U2_REQUIRE((res == nullptr) == (dres == nullptr), "u2mkd_bn_backward_res: res and dres go together");
-    U2_REQUIRE(res == nullptr || relu, "u2mkd_bn_backward_res: a residual input is only fused with the ReLU form");
-    if (n == 0) return 0;
-    U2_REQUIRE(dy && x && mean && invstd && partial && dgamma && dbeta && dx, "u2mkd_bn_backward: null pointer");
-    hipStream_t st = as_stream(s);
-    int nslab = (int)u2mkd_bn_num_slabs(n);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
-                       invstd, gamma, beta, relu, partial, res);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
-                       dbeta, dgamma);
-    int64_t total4 = n * (c / 4);
-    if (training)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
-                           c / 4, 1.f / (float)n, (const float *)nullptr, mean, invstd, gamma, beta, relu, dbeta, dgamma,
-                           dx, res, dres);
-    else
-        hipLaunchKernelGGL(bn_bwd_eval_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, total4,
-                           c / 4, mean, invstd, gamma, beta, relu, dx, res, dres);
-    return check_launch("u2mkd_bn_backward");
-}
-
 /* ---- SyncBatchNorm pieces: local statistics | (all_gather by the caller) | merge | apply, and
  * local sums | (all_reduce by the caller) | apply in the backward ---- */
 int u2mkd_bn_local_stats(const float *x, int64_t n, int32_t c, float *partial, float *stats /*[2c+1]*/,
                          u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_local_stats: c=%d must be a multiple of 4 in 4..1024", c);
-    U2_REQUIRE(stats && (n == 0 || (x && partial)), "u2mkd_bn_local_stats: null pointer");
-    hipStream_t st = as_stream(s);
-    if (n == 0) {
-        (void)hipMemsetAsync(stats, 0, (size_t)(2 * c + 1) * sizeof(float), st);
-        return check_launch("u2mkd_bn_local_stats");
-    }
-    int nslab = (int)u2mkd_bn_num_slabs(n);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab,
-                       n, c, 0.f, 0.f, (float *)nullptr, (float *)nullptr, stats, (float *)nullptr, stats + c);
-    return check_launch("u2mkd_bn_local_stats");
+    return bn_local_stats_impl<float>(x, n, c, partial, stats, s);
 }
 
 int u2mkd_bn_merge_stats(const float *gathered /*[world,2c+1]*/, int32_t world, int32_t c, float eps, float momentum,
@@ -543,44 +618,63 @@ int u2mkd_bn_merge_stats(const float *gathered /*[world,2c+1]*/, int32_t world, 
 
 int u2mkd_bn_apply(const float *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
                    const float *beta, int32_t relu, float *y, u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_apply: c=%d must be a positive multiple of 4", c);
-    if (n == 0) return 0;
-    U2_REQUIRE(x && mean && invstd && y, "u2mkd_bn_apply: null pointer");
-    int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), x, total4,
-                       c / 4, mean, invstd, gamma, beta, relu, y);
-    return check_launch("u2mkd_bn_apply");
+    return bn_apply_impl<float>(x, n, c, mean, invstd, gamma, beta, relu, y, s);
 }
 
 int u2mkd_bn_backward_local(const float *dy, const float *x, int64_t n, int32_t c, const float *mean,
                             const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
                             float *sums /*[2c]: dbeta, dgamma of this rank*/, u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward_local: c=%d must be a multiple of 4 in 4..1024", c);
-    U2_REQUIRE(sums, "u2mkd_bn_backward_local: null pointer");
-    hipStream_t st = as_stream(s);
-    if (n == 0) {
-        (void)hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st);
-        return check_launch("u2mkd_bn_backward_local");
-    }
-    U2_REQUIRE(dy && x && mean && invstd && partial, "u2mkd_bn_backward_local: null pointer");
-    int nslab = (int)u2mkd_bn_num_slabs(n);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
-                       invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
-                       sums, sums + c);
-    return check_launch("u2mkd_bn_backward_local");
+    return bn_backward_local_impl<float>(dy, x, n, c, mean, invstd, gamma, beta, relu, partial, sums, s);
 }
 
 int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t c, const float *total_n,
                             const float *mean, const float *invstd, const float *gamma, const float *beta,
                             int32_t relu, const float *sums /*[2c] summed over ranks*/, float *dx, u2mkd_stream_t s) {
-    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_backward_apply: c=%d must be a positive multiple of 4", c);
-    if (n == 0) return 0;
-    U2_REQUIRE(dy && x && total_n && mean && invstd && sums && dx, "u2mkd_bn_backward_apply: null pointer");
-    int64_t total4 = n * (c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), dy, x,
-                       total4, c / 4, 0.f, total_n, mean, invstd, gamma, beta, relu, sums, sums + c, dx);
-    return check_launch("u2mkd_bn_backward_apply");
+    return bn_backward_apply_impl<float>(dy, x, n, c, total_n, mean, invstd, gamma, beta, relu, sums, dx, s);
+}
+
+/* ---- the same on BF16 rows (x, res, y, dy, dx, dres are bf16 [n, c]; every statistic, parameter and sum fp32) ---- */
+int u2mkd_bn_train_forward_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *gamma,
+                                    const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                    int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean, float *invstd,
+                                    void *y, u2mkd_stream_t s) {
+    return bn_train_forward_impl<bf16row>(BF(x), BF(res), n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                                          num_batches_tracked, relu, partial, mean, invstd, BFW(y), s);
+}
+
+int u2mkd_bn_eval_forward_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *gamma, const float *beta,
+                                   float eps, const float *running_mean, const float *running_var, int32_t relu,
+                                   float *invstd, void *y, u2mkd_stream_t s) {
+    return bn_eval_forward_impl<bf16row>(BF(x), BF(res), n, c, gamma, beta, eps, running_mean, running_var, relu, invstd,
+                                         BFW(y), s);
+}
+
+int u2mkd_bn_backward_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *mean,
+                               const float *invstd, const float *gamma, const float *beta, int32_t relu, int32_t training,
+                               float *partial, float *dgamma, float *dbeta, void *dx, void *dres, u2mkd_stream_t s) {
+    return bn_backward_impl<bf16row>(BF(dy), BF(x), BF(res), n, c, mean, invstd, gamma, beta, relu, training, partial, dgamma,
+                                     dbeta, BFW(dx), BFW(dres), s);
+}
+
+int u2mkd_bn_local_stats_bf16(const void *x, int64_t n, int32_t c, float *partial, float *stats, u2mkd_stream_t s) {
+    return bn_local_stats_impl<bf16row>(BF(x), n, c, partial, stats, s);
+}
+
+int u2mkd_bn_apply_bf16(const void *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
+                        const float *beta, int32_t relu, void *y, u2mkd_stream_t s) {
+    return bn_apply_impl<bf16row>(BF(x), n, c, mean, invstd, gamma, beta, relu, BFW(y), s);
+}
+
+int u2mkd_bn_backward_local_bf16(const void *dy, const void *x, int64_t n, int32_t c, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, int32_t relu, float *partial, float *sums,
+                                 u2mkd_stream_t s) {
+    return bn_backward_local_impl<bf16row>(BF(dy), BF(x), n, c, mean, invstd, gamma, beta, relu, partial, sums, s);
+}
+
+int u2mkd_bn_backward_apply_bf16(const void *dy, const void *x, int64_t n, int32_t c, const float *total_n, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, int32_t relu, const float *sums,
+                                 void *dx, u2mkd_stream_t s) {
+    return bn_backward_apply_impl<bf16row>(BF(dy), BF(x), n, c, total_n, mean, invstd, gamma, beta, relu, sums, BFW(dx), s);
 }
 
 }  // extern "C"

@@ -44,6 +44,28 @@ __device__ __forceinline__ int64_t fnv_hash4(int x, int y, int z, int b) {
     return (int64_t)h;
 }
 
+// ---- feature-row element types: float, or bf16 (BF16 STORAGE, BASELINE.json configs[4]) --------------------------
+// ld4 / st4 move 4 consecutive channels of a row (index in units of 4 elements); bf16 values are widened exactly on
+// load and rounded to nearest-even once at the store, arithmetic in between is fp32.
+struct bf16row { unsigned short v; };
+template <typename T> __device__ __forceinline__ float4 ld4(const T *p, int64_t i4);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p, int64_t i4) { return reinterpret_cast<const float4 *>(p)[i4]; }
+template <> __device__ __forceinline__ float4 ld4<bf16row>(const bf16row *p, int64_t i4) {
+    const uint2 w = reinterpret_cast<const uint2 *>(p)[i4];     // a bf16 is the upper half of the fp32 with the same value
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T *p, int64_t i4, const float4 &v);
+template <> __device__ __forceinline__ void st4<float>(float *p, int64_t i4, const float4 &v) { reinterpret_cast<float4 *>(p)[i4] = v; }
+template <> __device__ __forceinline__ void st4<bf16row>(bf16row *p, int64_t i4, const float4 &v) {
+    const __bf16 a = (__bf16)v.x, b = (__bf16)v.y, c = (__bf16)v.z, d = (__bf16)v.w;      // round to nearest even, NaN stays NaN
+    uint2 w;
+    w.x = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+    w.y = (uint32_t)__builtin_bit_cast(unsigned short, c) | ((uint32_t)__builtin_bit_cast(unsigned short, d) << 16);
+    reinterpret_cast<uint2 *>(p)[i4] = w;
+}
+
+
 // ---- hash table view (keys then values in one caller-owned buffer) --------
 struct TableView {
     int64_t *keys;   // cap entries, -1 = empty

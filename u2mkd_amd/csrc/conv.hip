@@ -889,6 +889,45 @@ pairs_gather_sum_kernel(const float *__restrict__ y, const int32_t *__restrict__
     reinterpret_cast<float4 *>(out)[r * c4 + c] = acc;
 }
 
+// the same over bf16 rows (bf16 storage, BASELINE.json configs[4]): 8 channels = 16 bytes per thread, fp32 sum in ascending
+// offset order, one rounding to bf16 at the store
+__global__ void __launch_bounds__(256)
+pairs_gather_sum_bf16_kernel(const uint4 *__restrict__ y, const int32_t *__restrict__ pos, int64_t n_rows, int K, int c8,
+                             uint4 *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rows * c8) return;
+    int64_t r = t / c8;
+    int c = (int)(t - r * c8);
+    const int32_t *pr = pos + r * K;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int p[8];
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = k0 + i < K ? pr[k0 + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i] >= 0 ? y[(int64_t)p[i] * c8 + c] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {      // a bf16 is the upper half of the fp32 with the same value
+                acc[2 * j] += __uint_as_float(w[j] << 16);
+                acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+            }
+        }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 lo = (__bf16)acc[2 * j], hi = (__bf16)acc[2 * j + 1];
+        o[j] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    out[r * c8 + c] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 template <int WAVES, int KC>
 static int launch_conv_os2(int nb, dim3 grid, int K, hipStream_t st, const float *in, int cin, const float *wt,
                            int cout, const int32_t *nbr, const int32_t *order, RowRange n_out, int kflip, float *out) {
@@ -1151,6 +1190,42 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, i
     hipLaunchKernelGGL(pairs_gather_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), y, pos,
                        n_rows, k, c4, out);
     return check_launch("u2mkd_pairs_gather_sum");
+}
+
+int u2mkd_conv_forward_pairs_bf16(const void *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                   const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                   int32_t k, void *y, u2mkd_stream_t s) {
+    if (capacity == 0) return 0;
+    U2_REQUIRE(in && wf && pair_idx && tile_k && meta && y, "u2mkd_conv_forward_pairs_bf16: null pointer");
+    U2_REQUIRE(k > 0 && n_in > 0 && capacity % 64 == 0, "u2mkd_conv_forward_pairs_bf16: the capacity must be a multiple of 64");
+    int rc = launch_conv_px3("u2mkd_conv_forward_pairs_bf16", reinterpret_cast<const float *>(in), cin,
+                             reinterpret_cast<const float *>(wf), cout, pair_idx, tile_k, meta + 1, capacity,
+                             reinterpret_cast<float *>(y), as_stream(s), true);
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_pairs_bf16: cin=%d and cout=%d must be multiples of 32", cin, cout);
+    return rc;
+}
+
+int u2mkd_linear_forward_bf16(const void *x, int64_t n, int32_t cin, const void *wf, int32_t cout, const float *bias,
+                              void *y, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(x && wf && y, "u2mkd_linear_forward_bf16: null pointer");
+    U2_REQUIRE(n > 0 && n < ((int64_t)1 << 31) - 64, "u2mkd_linear_forward_bf16: %lld rows out of range", (long long)n);
+    int rc = launch_linear_px3("u2mkd_linear_forward_bf16", reinterpret_cast<const float *>(x), n, cin,
+                               reinterpret_cast<const float *>(wf), cout, bias, reinterpret_cast<float *>(y), as_stream(s), true);
+    U2_REQUIRE(rc >= 0, "u2mkd_linear_forward_bf16: cin=%d and cout=%d must be multiples of 32", cin, cout);
+    return rc;
+}
+
+int u2mkd_pairs_gather_sum_bf16(const void *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, void *out,
+                                u2mkd_stream_t s) {
+    if (n_rows == 0) return 0;
+    U2_REQUIRE(y && pos && out, "u2mkd_pairs_gather_sum_bf16: null pointer");
+    U2_REQUIRE(cout > 0 && cout % 8 == 0 && k > 0, "u2mkd_pairs_gather_sum_bf16: cout=%d must be a positive multiple of 8", cout);
+    const int c8 = cout / 8;
+    const int64_t total = n_rows * c8;
+    hipLaunchKernelGGL(pairs_gather_sum_bf16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const uint4 *>(y), pos, n_rows, k, c8, reinterpret_cast<uint4 *>(out));
+    return check_launch("u2mkd_pairs_gather_sum_bf16");
 }
 
 int u2mkd_debug_wgrad_stamps(const float *a, const float *b, const int32_t *pairs, const int32_t *plan, int64_t n_rows,

@@ -26,10 +26,10 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
 // Global pair schedule in bf16x3 arithmetic (conv_px3.hip); wf = arith-2 fragments.  -1 = shape not supported.
 bool conv_px3_supported(int cin, int cout);
 int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
-                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st);
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16 = false);
 // the same kernel with the identity pair list: y[n_rows, cout] = in x B (+ bias), one offset (nn.Linear)
 int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
-                      const float *bias, float *y, hipStream_t st);
+                      const float *bias, float *y, hipStream_t st, bool b16 = false);
 
 // Weight gradient in bf16x3 arithmetic (conv_wgrad_x3.hip): 64 x 64-channel tiles, slabs as the f32 kernel.
 bool conv_wgrad_x3_supported(int ca, int cb, int k);

@@ -26,6 +26,12 @@
 //     stored into the other LDS image, one LDS-only barrier per step; all loads in the loop are unconditional
 //     so the compiler's s_waitcnt counters stay exact.
 // Results differ from the f32-MFMA kernel by fp32 rounding only (tests hold both to the same gates).
+//
+// BF16 STORAGE (B16; BASELINE.json configs[4]: torchsparse runs its conv in half precision under autocast,
+// custom_fwd(cast_inputs=half)): the same pipeline on bf16 rows -- one plane in the LDS
+// image, no split, ONE v_mfma_f32_16x16x32_bf16 per 32 channels, fp32 accumulators -- with 64-channel steps where
+// cin allows (a row's step is again one full 128-byte line), weights = the one-plane fragments of
+// u2mkd_weight_fragments(arith 3), scratch rows y / outputs in bf16 (rounded once from the fp32 accumulator).
 #include <type_traits>
 
 #include "conv_internal.h"
@@ -51,15 +57,21 @@ __device__ __forceinline__ px_bf16x8 px_bf8(const float4 &x) {
 // DENSE (nn.Linear over point features, the learner / point_transforms MLPs of spvcnn.py:58-74 and tsd_full.py): the
 // "pair list" is the identity -- tile t = rows 64 t .. 64 t + 63 of `in`, one offset -- the bias is added at the
 // store and rows past n_rows are not written (y = the [n_rows, cout] output itself, no scratch rows).
-template <int NW, int NBW, bool DENSE = false>
+// B16: bf16 rows in / out (see the header); SC = channels per pipeline step (fp32 rows: 32; bf16 rows: 64 or 32)
+template <int NW, int NBW, bool DENSE = false, bool B16 = false, int SC = 32>
 __global__ void __launch_bounds__(64 * NW)
 conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wf, int cout,
                 const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
                 const int32_t *__restrict__ n_tiles, float *__restrict__ y, const float *__restrict__ bias = nullptr,
                 int n_rows = 0) {
+    static_assert(B16 ? (SC == 32 || SC == 64) : SC == 32, "step width");
     constexpr int NT = 64 * NW, TN = 16 * NW * NBW;
-    constexpr int RS = 208;                       // bytes per row of the LDS image: 3 planes x 32 bf16 + 16 pad
-    constexpr int LPT = (512 + NT - 1) / NT;      // 16-byte chunks a thread gathers per step (64 rows x 8)
+    constexpr int RS = 208;                       // bytes per row of the LDS image: 3 planes x 32 bf16 (or 64 bf16) + pad
+    constexpr int CH = B16 ? SC / 8 : 8;          // 16-byte chunks of a row's step (fp32: 4 channels each, bf16: 8)
+    constexpr int NCH = 64 * CH;                  // chunks per step
+    constexpr int LPT = (NCH + NT - 1) / NT;      // 16-byte chunks a thread gathers per step
+    constexpr int NWF = B16 ? SC / 32 : 3;        // weight / row fragments per (column block, step): k-steps or planes
+    const int esz = B16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -67,18 +79,18 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntile);
     if (t0 >= t1) return;
-    const int ns = cin / 32;
+    const int ns = cin / SC;
     const int nsteps = (t1 - t0) * ns;
     const int ncb = cout / 16;
     const int cbw = blockIdx.y * (TN / 16) + NBW * wave;      // this wave's first column block
 
-    // chunk e of a step: row e >> 3 of the tile, 16-byte chunk e & 7 of the row's 128-byte line
+    // chunk e of a step: row e / CH of the tile, 16-byte chunk e % CH of the row's step bytes
     int crow[LPT], cch[LPT];
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
-        const int e = min(tid + l * NT, 511);
-        crow[l] = e >> 3;
-        cch[l] = e & 7;
+        const int e = min(tid + l * NT, NCH - 1);
+        crow[l] = e / CH;
+        cch[l] = e % CH;
     }
 
     f32x4 acc[4][NBW];
@@ -86,7 +98,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int n = 0; n < NBW; ++n) acc[b][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bw[2][3 * NBW];
+    float4 bw[2][NWF * NBW];
     f32x4 g[2][LPT];
     int gix[LPT];        // pair entries of the tile the NEXT gather reads
     int kw;              // offset of the tile the NEXT weight issue reads
@@ -107,22 +119,28 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             const int row = ix[l] >= 0 ? ix[l] : 0;       // padding entries multiply row 0; their y rows are never read
-            gg[l] = *reinterpret_cast<const f32x4 *>(in + (size_t)row * cin + 32 * s + 4 * cch[l]);
+            gg[l] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(in) +
+                                                     ((size_t)row * cin + SC * s) * esz + 16 * cch[l]);
         }
     };
-    auto issue_B = [&](int k, int s, float4 (&bb)[3 * NBW]) __attribute__((always_inline)) {
+    auto issue_B = [&](int k, int s, float4 (&bb)[NWF * NBW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
             const int cb = min(cbw + n, ncb - 1);         // column blocks past cout: computed, never stored
-            const float *pb = wf + ((((size_t)k * ncb + cb) * ns + s) * 3 * 64 + lane) * 4;
+            // fragments of one (offset, column block): [32-channel step][plane][lane][16 B]; a step of this kernel reads
+            // NWF consecutive ones (x3: the 3 planes of its 32 channels; bf16: SC / 32 one-plane k-steps)
+            const float *pb = wf + ((((size_t)k * ncb + cb) * ns + s) * NWF * 64 + lane) * 4;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bb[3 * n + p] = *reinterpret_cast<const float4 *>(pb + p * 256);
+            for (int p = 0; p < NWF; ++p) bb[NWF * n + p] = *reinterpret_cast<const float4 *>(pb + p * 256);
         }
     };
     auto store_G = [&](const f32x4 (&gg)[LPT], int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
-            if (tid + l * NT < 512) {
+            if (B16) {
+                if (tid + l * NT < NCH)
+                    *reinterpret_cast<f32x4 *>(smem + (slot * 64 + crow[l]) * RS + 16 * cch[l]) = gg[l];
+            } else if (tid + l * NT < NCH) {
                 // split by truncation (x & 0xffff0000; exact residuals), two bf16 packed per dword by a byte permute
                 uint32_t hb[4], mb[4], lb[4];
 #pragma unroll
@@ -140,10 +158,10 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
             }
         }
     };
-    auto read_frag = [&](int slot, int rb, float4 (&aa)[3]) __attribute__((always_inline)) {
+    auto read_frag = [&](int slot, int rb, float4 (&aa)[NWF]) __attribute__((always_inline)) {
         const char *row = smem + (slot * 64 + 16 * rb + r) * RS + 16 * q;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
+        for (int p = 0; p < NWF; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[min(t, t1 - 1)]; };
@@ -184,15 +202,26 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         kw = tile_offset(tw);                      // step i+2's tile
         load_idx(tg, gix);                         // step i+3's tile
         // -- multiply step i from LDS image u
-        float4 a[2][3];
+        float4 a[2][NWF];
         read_frag(u, 0, a[0]);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             if (rb < 3) read_frag(u, rb + 1, a[(rb + 1) & 1]);
-            const px_bf16x8 xh = px_bf8(a[rb & 1][0]), xm = px_bf8(a[rb & 1][1]), xl = px_bf8(a[rb & 1][2]);
+            if (B16) {      // one plane: one MFMA per 32 channels; weights = A operand: D[col][pair]
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    f32x4 c = acc[rb][n];
+#pragma unroll
+                    for (int p = 0; p < NWF; ++p)
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(px_bf8(bw[u][NWF * n + p]), px_bf8(a[rb & 1][p]), c, 0, 0, 0);
+                    acc[rb][n] = c;
+                }
+                continue;
+            }
+            const px_bf16x8 xh = px_bf8(a[rb & 1][0]), xm = px_bf8(a[rb & 1][NWF / 2]), xl = px_bf8(a[rb & 1][NWF - 1]);
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                const px_bf16x8 wh = px_bf8(bw[u][3 * n]), wm = px_bf8(bw[u][3 * n + 1]), wl = px_bf8(bw[u][3 * n + 2]);
+                const px_bf16x8 wh = px_bf8(bw[u][NWF * n]), wm = px_bf8(bw[u][NWF * n + NWF / 2]), wl = px_bf8(bw[u][NWF * n + NWF - 1]);
                 // the six partial products, low order first; weights = A operand: D[col][pair]
                 f32x4 c = acc[rb][n];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
@@ -211,15 +240,17 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const int col = 16 * (cbw + n) + 4 * q;
-                    if (DENSE) {
-                        const int row = tc * 64 + 16 * rb + r;
-                        if (cbw + n < ncb && row < n_rows) {
-                            f32x4 o = acc[rb][n];
-                            if (bias) o += *reinterpret_cast<const f32x4 *>(bias + col);
+                    const int row = tc * 64 + 16 * rb + r;
+                    if (cbw + n < ncb && (!DENSE || row < n_rows)) {
+                        f32x4 o = acc[rb][n];
+                        if (DENSE && bias) o += *reinterpret_cast<const f32x4 *>(bias + col);
+                        if (B16) {
+                            px_bf16x4 ob;
+                            ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3];
+                            *reinterpret_cast<px_bf16x4 *>(reinterpret_cast<char *>(y) + ((size_t)row * cout + col) * 2) = ob;
+                        } else {
                             *reinterpret_cast<f32x4 *>(y + (size_t)row * cout + col) = o;
                         }
-                    } else if (cbw + n < ncb) {
-                        *reinterpret_cast<f32x4 *>(y + ((size_t)tc * 64 + 16 * rb + r) * cout + col) = acc[rb][n];
                     }
                     acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
@@ -240,8 +271,22 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 // (cin, cout) the kernel takes: whole 32-channel steps and fragment-layout weights (multiples of 32)
 bool conv_px3_supported(int cin, int cout) { return cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0; }
 
+template <bool DENSE, bool B16, int SC>
+static void px3_launch(bool w3, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
+                       const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y, const float *bias,
+                       int n_rows) {
+    const size_t lds = (size_t)2 * 64 * 208;
+    if (w3)
+        hipLaunchKernelGGL((conv_px3_kernel<3, 2, DENSE, B16, SC>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k,
+                           n_tiles, y, bias, n_rows);
+    else
+        hipLaunchKernelGGL((conv_px3_kernel<4, 2, DENSE, B16, SC>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k,
+                           n_tiles, y, bias, n_rows);
+}
+
+// b16: `in` and `y` are bf16 rows, wf = the arith-3 (one bf16 plane) fragments
 int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
-                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st) {
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
     // column tiles: 128 (4 waves x 2 blocks) or 96 (3 waves x 2 blocks: 96- and 192-column layers exactly)
     const bool w3 = cout % 96 == 0 && cout % 128 != 0;
@@ -251,18 +296,16 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
     const int gy = (int)ceil_div(cout, tn);
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
     if (gx < 1) gx = 1;
-    const size_t lds = (size_t)2 * 64 * 208;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (w3)
-        hipLaunchKernelGGL((conv_px3_kernel<3, 2>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
-    else
-        hipLaunchKernelGGL((conv_px3_kernel<4, 2>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y);
+    if (!b16) px3_launch<false, false, 32>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    else if (cin % 64 == 0) px3_launch<false, true, 64>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    else px3_launch<false, true, 32>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     return check_launch(who);
 }
 
-// y[n_rows, cout] = in[n_rows, cin] x B (+ bias), B in the arith-2 fragment order of ONE offset
+// y[n_rows, cout] = in[n_rows, cin] x B (+ bias), B in the arith-2 (b16: arith-3) fragment order of ONE offset
 int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
-                      const float *bias, float *y, hipStream_t st) {
+                      const float *bias, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
     const bool w3 = cout % 96 == 0 && cout % 128 != 0;
     const int tn = w3 ? 96 : 128;
@@ -270,14 +313,10 @@ int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin,
     int64_t gx = ceil_div(n_rows, 64);
     const int64_t cap_x = 3 * 256;
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
-    const size_t lds = (size_t)2 * 64 * 208;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (w3)
-        hipLaunchKernelGGL((conv_px3_kernel<3, 2, true>), grid, dim3(192), lds, st, in, cin, wf, cout, nullptr, nullptr, nullptr,
-                           y, bias, (int)n_rows);
-    else
-        hipLaunchKernelGGL((conv_px3_kernel<4, 2, true>), grid, dim3(256), lds, st, in, cin, wf, cout, nullptr, nullptr, nullptr,
-                           y, bias, (int)n_rows);
+    if (!b16) px3_launch<true, false, 32>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    else if (cin % 64 == 0) px3_launch<true, true, 64>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    else px3_launch<true, true, 32>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     return check_launch(who);
 }
 

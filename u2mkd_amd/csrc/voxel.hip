@@ -190,6 +190,86 @@ __global__ void segment_sum_kernel(const float *__restrict__ src, int c4, const 
     reinterpret_cast<float4 *>(out)[t] = acc;
 }
 
+// ---- the row movers on float OR bf16 rows (common.h ld4 / st4), 4 channels per thread; the fp32 entries keep the
+// kernels above (bit-for-bit the round-2 arithmetic), the bf16-storage entries use these with T = bf16row: sums in fp32
+// in the same fixed order, one rounding at the store
+template <typename T>
+__global__ void voxelize_bwd_rows_kernel(const T *__restrict__ gout, const int32_t *__restrict__ idx,
+                                         const int32_t *__restrict__ counts, int64_t n, int64_t nv, int c4,
+                                         T *__restrict__ gin) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / c4;
+    int j = (int)(t - i * c4);
+    if (i >= n) return;
+    int p = idx[i];
+    bool ok = p >= 0 && p < nv;
+    int cnt = ok ? counts[p] : 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt > 0) {
+        float4 g = ld4(gout, (int64_t)p * c4 + j);
+        float inv = (float)cnt;
+        v = make_float4(g.x / inv, g.y / inv, g.z / inv, g.w / inv);
+    }
+    st4(gin, t, v);
+}
+
+template <typename T>
+__global__ void devoxelize_fwd_rows_kernel(const T *__restrict__ feats, const int32_t *__restrict__ idx,
+                                           const float *__restrict__ w, int64_t n, int c4, T *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = t / c4;
+    int j = (int)(t - i * c4);
+    if (i >= n) return;
+    const int32_t *ii = idx + i * 8;
+    const float *ww = w + i * 8;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int p = ii[k];
+        float wk = ww[k];
+        if (p >= 0) {
+            float4 f = ld4(feats, (int64_t)p * c4 + j);
+            acc.x += wk * f.x; acc.y += wk * f.y; acc.z += wk * f.z; acc.w += wk * f.w;
+        }
+    }
+    st4(out, t, acc);
+}
+
+template <typename T>
+__global__ void segment_sum_rows_kernel(const T *__restrict__ src, int c4, const int32_t *__restrict__ erow,
+                                        const float *__restrict__ ew, const int32_t *__restrict__ seg, int64_t nv,
+                                        int mean, T *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t v = t / c4;
+    if (v >= nv) return;
+    int j = (int)(t - v * c4);
+    const int e0 = seg[v], e1 = seg[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = e0;
+    const float cnt = (float)(e1 - e0);
+    for (; e + 4 <= e1; e += 4) {
+        int r[4];
+        float w[4];
+        float4 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { r[u] = erow[e + u]; w[u] = ew ? ew[e + u] : 1.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = ld4(src, (int64_t)r[u] * c4 + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (mean) { acc.x += f[u].x / cnt; acc.y += f[u].y / cnt; acc.z += f[u].z / cnt; acc.w += f[u].w / cnt; }
+            else { acc.x += w[u] * f[u].x; acc.y += w[u] * f[u].y; acc.z += w[u] * f[u].z; acc.w += w[u] * f[u].w; }
+        }
+    }
+    for (; e < e1; ++e) {
+        float w = ew ? ew[e] : 1.f;
+        float4 f = ld4(src, (int64_t)erow[e] * c4 + j);
+        if (mean) { acc.x += f.x / cnt; acc.y += f.y / cnt; acc.z += f.z / cnt; acc.w += f.w / cnt; }
+        else { acc.x += w * f.x; acc.y += w * f.y; acc.z += w * f.z; acc.w += w * f.w; }
+    }
+    st4(out, t, acc);
+}
+
 // F.calc_ti_weights fused with the [8,N] -> [N,8] transposes of
 // core/models/utils.py:94-95.  Same operation order as the reference:
 // products of differences, / scale^3, zero where idx == -1, / (sum + 1e-8).
@@ -300,6 +380,42 @@ int u2mkd_segment_sum(const float *src, int32_t c, const int32_t *entry_row, con
     hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), src, c / 4,
                        entry_row, entry_w, seg_offsets, nv, mean, out);
     return check_launch("u2mkd_segment_sum");
+}
+
+/* ---- bf16 rows (feature rows in and out are bf16 [., c], c a multiple of 4; indices, weights, counts as above) ---- */
+int u2mkd_voxelize_backward_bf16(const void *grad_out, const int32_t *idx, const int32_t *counts, int64_t n, int64_t nv,
+                                 int32_t c, void *grad_feats, u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(grad_out && idx && counts && grad_feats, "u2mkd_voxelize_backward_bf16: null pointer");
+    U2_REQUIRE(c % 4 == 0, "u2mkd_voxelize_backward_bf16: c=%d must be a multiple of 4", c);
+    int64_t total = n * (c / 4);
+    hipLaunchKernelGGL(voxelize_bwd_rows_kernel<bf16row>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const bf16row *>(grad_out), idx, counts, n, nv, c / 4,
+                       reinterpret_cast<bf16row *>(grad_feats));
+    return check_launch("u2mkd_voxelize_backward_bf16");
+}
+
+int u2mkd_devoxelize_forward_bf16(const void *feats, const int32_t *idx, const float *w, int64_t n, int32_t c, void *out,
+                                  u2mkd_stream_t s) {
+    if (n == 0 || c == 0) return 0;
+    U2_REQUIRE(feats && idx && w && out, "u2mkd_devoxelize_forward_bf16: null pointer");
+    U2_REQUIRE(c % 4 == 0, "u2mkd_devoxelize_forward_bf16: c=%d must be a multiple of 4", c);
+    int64_t total = n * (c / 4);
+    hipLaunchKernelGGL(devoxelize_fwd_rows_kernel<bf16row>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const bf16row *>(feats), idx, w, n, c / 4, reinterpret_cast<bf16row *>(out));
+    return check_launch("u2mkd_devoxelize_forward_bf16");
+}
+
+int u2mkd_segment_sum_bf16(const void *src, int32_t c, const int32_t *entry_row, const float *entry_w,
+                           const int32_t *seg_offsets, int64_t nv, int32_t mean, void *out, u2mkd_stream_t s) {
+    if (nv == 0 || c == 0) return 0;
+    U2_REQUIRE(src && entry_row && seg_offsets && out, "u2mkd_segment_sum_bf16: null pointer");
+    U2_REQUIRE(c % 4 == 0, "u2mkd_segment_sum_bf16: c=%d must be a multiple of 4", c);
+    int64_t total = nv * (c / 4);
+    hipLaunchKernelGGL(segment_sum_rows_kernel<bf16row>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const bf16row *>(src), c / 4, entry_row, entry_w, seg_offsets, nv, mean,
+                       reinterpret_cast<bf16row *>(out));
+    return check_launch("u2mkd_segment_sum_bf16");
 }
 
 int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, float scale, float *w_n8,

@@ -214,15 +214,17 @@ class _SegmentMap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, fwd, bwd, n_dst):
         from .torchsparse.nn import functional as spf
-        ctx.bwd, ctx.n_src = bwd, src.shape[0]
+        ctx.bwd, ctx.n_src, ctx.in_dtype = bwd, src.shape[0], src.dtype
         erow, ew, seg = fwd
-        return spf._segment_sum(src.contiguous().float(), erow, ew, seg, n_dst, False)
+        # bf16 rows stay bf16 (bf16 storage under autocast); anything else is moved as fp32
+        return spf._segment_sum(spf._rows(src, src.dtype == torch.bfloat16), erow, ew, seg, n_dst, False)
 
     @staticmethod
     def backward(ctx, g):
         from .torchsparse.nn import functional as spf
         erow, ew, seg = ctx.bwd
-        return spf._segment_sum(g.contiguous().float(), erow, ew, seg, ctx.n_src, False), None, None, None
+        gs = spf._segment_sum(spf._rows(g, g.dtype == torch.bfloat16), erow, ew, seg, ctx.n_src, False)
+        return (gs if gs.dtype == ctx.in_dtype else gs.to(ctx.in_dtype)), None, None, None
 
 
 def _flat_entries(pixel_coordinates, masks):

@@ -85,6 +85,24 @@ def spcount(coords: torch.Tensor, num: int) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------ bf16 storage
+_BF16_ROWS = os.environ.get('U2MKD_BF16_ROWS', '1') != '0'      # 0: autocast keeps fp32 rows between the sparse operators
+
+
+def bf16_rows() -> bool:
+    """True when the sparse operators keep their feature rows in bf16: under ``torch.autocast('cuda', bfloat16)``.
+    torchsparse v1.4.0 decorates its conv / voxelize / devoxelize functions ``custom_fwd(cast_inputs=torch.half)``
+    (SURVEY.md Appendix A-6), so under the reference's amp (core/nusc_trainers.py:285) rows travel in half between
+    them and nn.BatchNorm1d passes half through; here the reduced type is bf16 (BASELINE.json configs[4]), every
+    accumulation, statistic and weight gradient stays fp32.  fp16 autocast keeps fp32 rows (no fp16 kernels)."""
+    return _BF16_ROWS and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def _rows(t, b16):
+    """contiguous rows in the storage type of the call"""
+    return t.contiguous().to(torch.bfloat16 if b16 else torch.float32)
+
+
 # ------------------------------------------------- destination-sorted scatter plans
 def _csr_by_destination(keys: torch.Tensor, nv: int):
     """(entry order int32 [E'], segment offsets int32 [nv+1]) of the entries with key >= 0, sorted
@@ -112,10 +130,11 @@ def _plan(t: torch.Tensor, name: str, build, *deps):
 
 
 def _segment_sum(src, erow, ew, seg, nv, mean):
+    """rows of src (fp32 or bf16: the output has the same type) summed per destination segment"""
     c = src.shape[1]
-    out = torch.empty(nv, c, dtype=torch.float32, device=src.device)
-    L.call('u2mkd_segment_sum', L.ptr(src), c, L.ptr(erow), L.ptr(ew), L.ptr(seg), nv, int(mean), L.ptr(out),
-           L.stream())
+    out = torch.empty(nv, c, dtype=src.dtype, device=src.device)
+    L.call('u2mkd_segment_sum_bf16' if src.dtype == torch.bfloat16 else 'u2mkd_segment_sum', L.ptr(src), c, L.ptr(erow),
+           L.ptr(ew), L.ptr(seg), nv, int(mean), L.ptr(out), L.stream())
     return out
 
 
@@ -124,14 +143,15 @@ class VoxelizeFunction(Function):
     @staticmethod
     def forward(ctx, feats, coords, counts):
         L.require_cuda(feats, coords, counts)
-        feats = feats.contiguous().float()
+        b16 = bf16_rows() and feats.shape[1] % 4 == 0 and feats.shape[1] >= 16    # (coordinate means stay fp32: c = 4)
+        feats = _rows(feats, b16)
         coords = _i32(coords).contiguous()
         counts = _i32(counts).contiguous()
         n, c = feats.shape
         nv = counts.shape[0]
         if n == 0:
             ctx.for_backwards = (coords, counts, n)
-            return torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
+            return torch.zeros(nv, c, dtype=feats.dtype, device=feats.device)
         if c % 4 == 0:
             # deterministic scatter-mean: points grouped by voxel once per map, then a gather-sum
             order, seg = _plan(coords, 'vox_csr_%d' % nv, lambda: _csr_by_destination(coords, nv))
@@ -146,10 +166,12 @@ class VoxelizeFunction(Function):
     @staticmethod
     def backward(ctx, grad_output):
         coords, counts, n = ctx.for_backwards
-        g = grad_output.contiguous().float()
+        b16 = grad_output.dtype == torch.bfloat16 and grad_output.shape[1] % 4 == 0
+        g = _rows(grad_output, b16)
         nv, c = g.shape
-        gi = torch.empty(n, c, dtype=torch.float32, device=g.device)
-        L.call('u2mkd_voxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(counts), n, nv, c, L.ptr(gi), L.stream())
+        gi = torch.empty(n, c, dtype=g.dtype, device=g.device)
+        L.call('u2mkd_voxelize_backward_bf16' if b16 else 'u2mkd_voxelize_backward', L.ptr(g), L.ptr(coords),
+               L.ptr(counts), n, nv, c, L.ptr(gi), L.stream())
         return gi, None, None
 
 
@@ -166,24 +188,26 @@ class DevoxelizeFunction(Function):
     @staticmethod
     def forward(ctx, feats, coords, weights):
         L.require_cuda(feats, coords, weights)
-        feats = feats.contiguous().float()
+        b16 = bf16_rows() and feats.shape[1] % 4 == 0 and feats.shape[1] >= 16
+        feats = _rows(feats, b16)
         coords = _i32(coords).contiguous()
         weights = weights.contiguous().float()
         nv, c = feats.shape
         n = coords.shape[0]
         assert coords.shape == (n, 8) and weights.shape == (n, 8), (coords.shape, weights.shape)
-        out = torch.empty(n, c, dtype=torch.float32, device=feats.device)
-        L.call('u2mkd_devoxelize_forward', L.ptr(feats), L.ptr(coords), L.ptr(weights), n, c, L.ptr(out), L.stream())
+        out = torch.empty(n, c, dtype=feats.dtype, device=feats.device)
+        L.call('u2mkd_devoxelize_forward_bf16' if b16 else 'u2mkd_devoxelize_forward', L.ptr(feats), L.ptr(coords),
+               L.ptr(weights), n, c, L.ptr(out), L.stream())
         ctx.for_backwards = (coords, weights, nv)
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         coords, weights, nv = ctx.for_backwards
-        g = grad_output.contiguous().float()
+        g = _rows(grad_output, grad_output.dtype == torch.bfloat16 and grad_output.shape[1] % 4 == 0)
         n, c = g.shape
         if n == 0:
-            return torch.zeros(nv, c, dtype=torch.float32, device=g.device), None, None
+            return torch.zeros(nv, c, dtype=g.dtype, device=g.device), None, None
         if c % 4 == 0:
             def build():
                 keys = torch.where(weights != 0, coords, -1).view(-1)          # [n*8], zero-weight corners dropped
@@ -192,6 +216,7 @@ class DevoxelizeFunction(Function):
             erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build, weights)
             gi = _segment_sum(g, erow, ew, seg, nv, False)
         else:
+            g = g.float()
             gi = torch.zeros(nv, c, dtype=torch.float32, device=g.device)
             L.call('u2mkd_devoxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(weights), n, nv, c, L.ptr(gi),
                    L.stream())
@@ -343,7 +368,12 @@ class TileSchedule:
         """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k[col][ci] = weight[kk][ci][col] (transpose, the forward) or
         weight[kk][col][ci] (the input gradient), kk = K-1-k if kflip else k; weight = `kernel` [K, cin, cout]."""
         n_in, cin = feats.shape
-        if L.load().u2mkd_conv_tiles_supported(cin, cout, self.k):
+        if feats.dtype == torch.bfloat16:        # bf16 storage: rows in and out bf16, one bf16 weight plane
+            wf = _weight_layout(weight, transpose, True, arith=3)
+            L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), L.ptr(out),
+                   L.stream())
+        elif L.load().u2mkd_conv_tiles_supported(cin, cout, self.k):
             wf = _weight_layout(weight, transpose, True)
             L.call('u2mkd_conv_forward_tiles', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
                    L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), 0, L.ptr(out),
@@ -398,6 +428,11 @@ class PairSchedule:
         if n_rows == 0:
             return out
         y = _scratch(self.cap * cout * 4, feats.device)
+        if feats.dtype == torch.bfloat16:        # bf16 storage (wt = the arith-3 fragments): scratch rows y in bf16 too
+            L.call('u2mkd_conv_forward_pairs_bf16', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
+                   L.ptr(self.meta), self.cap, self.k, L.ptr(y), st)
+            L.call('u2mkd_pairs_gather_sum_bf16', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
+            return out
         if fragments:
             L.call('u2mkd_conv_forward_pairs_x3', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
                    L.ptr(self.meta), self.cap, self.k, L.ptr(y), st)
@@ -551,8 +586,12 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
     weight[kk][col][ci] (False: the input gradient), kk = K-1-k if kflip else k.  kflip = 1 is the input
     gradient of a symmetric (submanifold) map computed on the forward table with mirrored offsets -- in the
     pair schedule that is simply the swapped-role walk."""
-    out = torch.empty(n_rows, cout, dtype=torch.float32, device=feats.device)
-    if _pairs_mode(feats.shape[1], cout):
+    out = torch.empty(n_rows, cout, dtype=feats.dtype, device=feats.device)
+    if feats.dtype == torch.bfloat16 and not L.load().u2mkd_conv_tiles_supported(feats.shape[1], cout, kmap.k):
+        # bf16 storage, every shape the tile kernel has no instantiation for (_conv_bf16_ok: multiples of 32)
+        wt = _weight_layout(weight, transpose, True, arith=3)
+        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
+    if feats.dtype != torch.bfloat16 and _pairs_mode(feats.shape[1], cout):
         x3 = _PAIRS_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(feats.shape[1], cout))
         wt = _weight_layout(weight, transpose, x3)
         return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3)
@@ -581,7 +620,12 @@ except ImportError:                                  # pragma: no cover -- torch
     pass
 
 
-def _weight_layout(weight, transpose, fragments):
+def _conv_bf16_ok(cin, cout):
+    """channel counts the bf16-storage conv kernels take (tile kernel: 32..128; pair kernel: multiples of 32)"""
+    return cin >= 32 and cin % 32 == 0 and cout >= 32 and cout % 32 == 0
+
+
+def _weight_layout(weight, transpose, fragments, arith=0):
     """The layout of `kernel` [K, R, C] a conv kernel reads: rows of B_k = output columns, reduction contiguous.
     transpose: B_k[col][red] = weight[k][red][col] (else weight[k][col][red], the tensor as it is).
     fragments: MFMA operand-fragment order (u2mkd_weight_fragments) instead of row-major [K, ncol, nred].
@@ -596,13 +640,15 @@ def _weight_layout(weight, transpose, fragments):
     frozen = not weight.requires_grad
     stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0] if not frozen else -1)
     if fragments:
-        hit = weight.__dict__.get('_u2mkd_wfrag')
+        # arith 0 = the library's fp32-row arithmetic (bf16x3 / f32), 3 = ONE bf16 plane (bf16 storage)
+        slot = '_u2mkd_wfrag3' if arith == 3 else '_u2mkd_wfrag'
+        hit = weight.__dict__.get(slot)
         if hit is None or hit[0] != stamp:
-            nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, 0)
+            nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, arith)
             both = torch.empty(2, nbytes, dtype=torch.uint8, device=weight.device)
-            L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, 2, 0, L.ptr(both), L.stream())
+            L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, 2, arith, L.ptr(both), L.stream())
             hit = (stamp, both)
-            weight.__dict__['_u2mkd_wfrag'] = hit
+            weight.__dict__[slot] = hit
         return hit[1][0 if transpose else 1]
     key = '_u2mkd_wt'
     if frozen:
@@ -650,12 +696,15 @@ def _dense_x3_ok(cin, cout):
 
 def _dense_x3(x, weight, forward, bias=None):
     """x @ weight.T (+ bias) (forward) or x @ weight (the input gradient) for nn.Linear's weight [out, in] on the
-    bf16x3 pair kernel's dense mode; the fragment-order weights of both orientations come from one cached launch."""
+    bf16x3 pair kernel's dense mode; the fragment-order weights of both orientations come from one cached launch.
+    bf16 rows (bf16 storage): the same kernel's one-plane form, bf16 in and out, fp32 bias and accumulation."""
     n = x.shape[0]
     cout = weight.shape[0] if forward else weight.shape[1]
-    wf = _weight_layout(weight, not forward, True)
-    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
-    L.call('u2mkd_linear_forward_x3', L.ptr(x), n, x.shape[1], L.ptr(wf), cout, L.ptr(bias), L.ptr(y), L.stream())
+    b16 = x.dtype == torch.bfloat16
+    wf = _weight_layout(weight, not forward, True, arith=3 if b16 else 0)
+    y = torch.empty(n, cout, dtype=x.dtype, device=x.device)
+    L.call('u2mkd_linear_forward_bf16' if b16 else 'u2mkd_linear_forward_x3', L.ptr(x), n, x.shape[1], L.ptr(wf), cout,
+           L.ptr(bias), L.ptr(y), L.stream())
     return y
 
 
@@ -675,8 +724,11 @@ class LinearFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         L.require_cuda(x, weight)
-        x = x.contiguous().float()
         weight = weight.contiguous().float()
+        want16 = bf16_rows()
+        b16 = want16 and _conv_bf16_ok(weight.shape[1], weight.shape[0])
+        ctx.in_dtype = x.dtype
+        x = _rows(x, b16)
         if x.dim() != 2 or x.shape[1] != weight.shape[1]:
             raise RuntimeError(f'linear: input {tuple(x.shape)} does not match weight {tuple(weight.shape)}')
         if weight.shape[1] % 4 != 0 or weight.shape[0] % 4 != 0:
@@ -686,13 +738,15 @@ class LinearFunction(Function):
         if x.shape[0] == 0:
             return x.new_zeros(0, weight.shape[0])
         b = bias.contiguous().float() if bias is not None else None
-        ctx.x3 = _dense_x3_ok(weight.shape[1], weight.shape[0])
-        return _dense_x3(x, weight, True, b) if ctx.x3 else _dense(x, weight, b)
+        ctx.x3 = b16 or _dense_x3_ok(weight.shape[1], weight.shape[0])
+        y = _dense_x3(x, weight, True, b) if ctx.x3 else _dense(x, weight, b)
+        return y.to(torch.bfloat16) if (want16 and not b16) else y
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        g = g.contiguous().float()
+        b16 = x.dtype == torch.bfloat16
+        g = _rows(g, b16)
         n = x.shape[0]
         cout, cin = weight.shape
         gx = gw = gb = None
@@ -710,10 +764,12 @@ class LinearFunction(Function):
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cout, cin, 1)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             gw = torch.empty_like(weight)
-            L.call('u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin, L.ptr(pairs), L.ptr(plan), n, 1, 0,
-                   L.ptr(ws), nbytes, L.ptr(gw), L.stream())
+            L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin,
+                   L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), L.stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+            gb = g.sum(0, dtype=torch.float32)
+        if gx is not None and gx.dtype != ctx.in_dtype:
+            gx = gx.to(ctx.in_dtype)
         return gx, gw, gb
 
 
@@ -741,9 +797,14 @@ class ConvolutionFunction(Function):
     @staticmethod
     def forward(ctx, input, weight, kmap, transposed=False):
         L.require_cuda(input, weight)
-        input = input.contiguous().float()
         weight = weight.contiguous().float()
         k, cin, cout = weight.shape
+        # bf16 storage (autocast to bfloat16): bf16 rows in and out, as torchsparse's custom_fwd(cast_inputs=half);
+        # shapes without a bf16 kernel (the 4-channel stem) compute on fp32 rows and round the result once
+        want16 = bf16_rows()
+        b16 = want16 and _conv_bf16_ok(cin, cout)
+        ctx.in_dtype = input.dtype
+        input = _rows(input, b16)
         if input.shape[1] != cin:
             raise RuntimeError(f'conv3d: input has {input.shape[1]} channels, kernel expects {cin}')
         if cin % 4 != 0:
@@ -760,13 +821,14 @@ class ConvolutionFunction(Function):
         ctx.save_for_backward(input, weight)
         ctx.kmap = kmap
         ctx.transposed = transposed
-        return out
+        return out.to(torch.bfloat16) if (want16 and not b16) else out
 
     @staticmethod
     def backward(ctx, grad_output):
         input, weight = ctx.saved_tensors
         kmap, transposed = ctx.kmap, ctx.transposed
-        g = grad_output.contiguous().float()
+        b16 = input.dtype == torch.bfloat16
+        g = _rows(grad_output, b16)
         k, cin, cout = weight.shape
         grad_input = grad_weight = None
         # The two gradients are independent: the weight gradient runs on a side stream next to
@@ -788,8 +850,8 @@ class ConvolutionFunction(Function):
                 st = side.cuda_stream
             else:
                 st = L.stream()
-            L.call('u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout, L.ptr(pairs), L.ptr(plan), kmap.n_out,
-                   k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), st)
+            L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout,
+                   L.ptr(pairs), L.ptr(plan), kmap.n_out, k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), st)
         if do_x:
             # dX[i] = sum_k dY[out_k(i)] @ W[k]^T : same kernel on the swapped-role table,
             # B_k = W[k] read as [cin][cout] (reduction over cout contiguous).
@@ -802,6 +864,8 @@ class ConvolutionFunction(Function):
             grad_input = _conv_os(g, weight, False, cin, kmap, inverse, input.shape[0], kflip)
         if side is not None:
             torch.cuda.current_stream(g.device).wait_stream(side)
+        if grad_input is not None and grad_input.dtype != ctx.in_dtype:
+            grad_input = grad_input.to(ctx.in_dtype)
         return grad_input, grad_weight, None, None
 
 
@@ -871,24 +935,29 @@ class BatchNormFunction(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None, res=None):
         L.require_cuda(x)
-        x = x.contiguous().float()
+        # bf16 storage: rows stay bf16 through the BatchNorm (as nn.BatchNorm1d passes half through under the
+        # reference's amp), statistics / parameters / gradient sums fp32
+        b16 = bf16_rows() or (x.dtype == torch.bfloat16 and _BF16_ROWS)
+        sfx = '_bf16' if b16 else ''
+        ctx.in_dtype, ctx.res_dtype = x.dtype, (res.dtype if res is not None else None)
+        x = _rows(x, b16)
         n, c = x.shape
         dev = x.device
         if res is not None:      # y = relu(bn(x) + res): the tail of a ResidualBlock in the same pass
             assert relu and res.shape == x.shape, (relu, res.shape, x.shape)
-            res = res.contiguous().float()
+            res = _rows(res, b16)
         y = torch.empty_like(x)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
         if training:
             slabs = L.load().u2mkd_bn_num_slabs(n)
             partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
-            L.call('u2mkd_bn_train_forward_res', L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+            L.call('u2mkd_bn_train_forward_res' + sfx, L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
                    float(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(counter), int(relu), L.ptr(partial),
                    L.ptr(mean), L.ptr(invstd), L.ptr(y), L.stream())
         else:
             mean = running_mean
-            L.call('u2mkd_bn_eval_forward_res', L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+            L.call('u2mkd_bn_eval_forward_res' + sfx, L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
                    L.ptr(running_mean), L.ptr(running_var), int(relu), L.ptr(invstd), L.ptr(y), L.stream())
         ctx.save_for_backward(x, gamma, beta, mean, invstd, res)
         ctx.relu, ctx.training = bool(relu), bool(training)
@@ -897,7 +966,8 @@ class BatchNormFunction(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd, res = ctx.saved_tensors
-        dy = dy.contiguous().float()
+        b16 = x.dtype == torch.bfloat16
+        dy = _rows(dy, b16)
         n, c = x.shape
         dev = x.device
         slabs = L.load().u2mkd_bn_num_slabs(n)
@@ -906,9 +976,13 @@ class BatchNormFunction(Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if res is not None else None
-        L.call('u2mkd_bn_backward_res', L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-               L.ptr(beta), int(ctx.relu), int(ctx.training), L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx),
-               L.ptr(dres), L.stream())
+        L.call('u2mkd_bn_backward_res_bf16' if b16 else 'u2mkd_bn_backward_res', L.ptr(dy), L.ptr(x), L.ptr(res), n, c,
+               L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(ctx.relu), int(ctx.training), L.ptr(partial),
+               L.ptr(dgamma), L.ptr(dbeta), L.ptr(dx), L.ptr(dres), L.stream())
+        if dx.dtype != ctx.in_dtype:
+            dx = dx.to(ctx.in_dtype)
+        if dres is not None and dres.dtype != ctx.res_dtype:
+            dres = dres.to(ctx.res_dtype)
         return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None,
                 None, None, None, None, None, None, None, dres)
 
@@ -949,14 +1023,17 @@ class SyncBatchNormFunction(Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world):
         import torch.distributed as dist
         L.require_cuda(x)
-        x = x.contiguous().float()
+        b16 = bf16_rows() or (x.dtype == torch.bfloat16 and _BF16_ROWS)
+        sfx = '_bf16' if b16 else ''
+        ctx.in_dtype = x.dtype
+        x = _rows(x, b16)
         n, c = x.shape
         dev = x.device
         st = L.stream()
         slabs = L.load().u2mkd_bn_num_slabs(n)
         partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
         stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
-        L.call('u2mkd_bn_local_stats', L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
+        L.call('u2mkd_bn_local_stats' + sfx, L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
         gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
         if world > 1:
             _gather_rows(gathered, stats, group)
@@ -968,7 +1045,7 @@ class SyncBatchNormFunction(Function):
         L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(eps), float(momentum), L.ptr(running_mean),
                L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.ptr(total), L.stream())
         y = torch.empty_like(x)
-        L.call('u2mkd_bn_apply', L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
+        L.call('u2mkd_bn_apply' + sfx, L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
                L.ptr(y), L.stream())
         ctx.save_for_backward(x, gamma, beta, mean, invstd, total)
         ctx.relu, ctx.group, ctx.world = bool(relu), group, world
@@ -978,20 +1055,24 @@ class SyncBatchNormFunction(Function):
     def backward(ctx, dy):
         import torch.distributed as dist
         x, gamma, beta, mean, invstd, total = ctx.saved_tensors
-        dy = dy.contiguous().float()
+        b16 = x.dtype == torch.bfloat16
+        sfx = '_bf16' if b16 else ''
+        dy = _rows(dy, b16)
         n, c = x.shape
         dev = x.device
         slabs = L.load().u2mkd_bn_num_slabs(n)
         partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        L.call('u2mkd_bn_backward_local', L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+        L.call('u2mkd_bn_backward_local' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
                L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
         local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
         dx = torch.empty_like(x)
-        L.call('u2mkd_bn_backward_apply', L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
+        L.call('u2mkd_bn_backward_apply' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
                L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.stream())
+        if dx.dtype != ctx.in_dtype:
+            dx = dx.to(ctx.in_dtype)
         return (dx, local[c:] if gamma is not None else None, local[:c] if beta is not None else None,
                 None, None, None, None, None, None, None)
 
