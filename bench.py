@@ -409,9 +409,10 @@ _T0 = time.perf_counter()
 
 
 # --------------------------------------------------------------------------------- workloads
-def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=None):
-    """(step closure, points per step on this rank, description).  sweeps / dtype / voxels: the configs[4] variant
-    (multi-sweep teacher scene of `voxels` voxels, bf16 autocast)."""
+def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=None, cr=None, cr_t=None):
+    """(step closure, points per step on this rank, description).  sweeps / dtype / voxels / cr / cr_t: the configs[4]
+    variant (multi-sweep teacher scene of `voxels` points, bf16 autocast with bf16 storage, the `_B` widths cr 2.0 /
+    cr_t 2.0 of configs/nuscenes/train/spformer_tsd_full_ours_star_B.yaml:34-36)."""
     import torch
     from u2mkd_amd import lidar, train as T
     from u2mkd_amd.synth import synth_batch, synth_kd_batch
@@ -435,7 +436,8 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
         return step, res[0][0].shape[0], desc
     from u2mkd_amd import kd as KD
     sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
-    model = KD.TSDFull(cr=args.cr, cr_t=args.cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+    cr, cr_t = cr or args.cr, cr_t or args.cr_t
+    model = KD.TSDFull(cr=cr, cr_t=cr_t, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
     runner = T.KDStep(model, num_epochs=50, batch_size=1, amp=amp)
     runner.train_mode()
     n_batches = max(1, args.batches)
@@ -446,14 +448,16 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
     resident = [T.kd_batch_to_device(b) for b in nbs]
     desc = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t %g, frozen) + SwiftNet18/SPVCNN+SphereFormer student '
             '(cr %g) + KD losses train step, one %d-point scene + 6 cameras %dx%d per GPU'
-            % (args.cr_t, args.cr, n_pts, image_hw[0], image_hw[1]))
+            % (cr_t, cr, n_pts, image_hw[0], image_hw[1]))
     if sweeps:
         n_agg = n_pts
         kf = [int(b['teacher']['keyframe_mask_full'].sum()) for b in nbs]
         n_pts = sum(kf) / len(kf)       # the metric counts raw KEY-FRAME points; mean over the rotated scenes
-        desc = ('BASELINE.json configs[4] on ONE GPU: the same KD step with a multi-sweep teacher scene (%d aggregated points, '
-                '%d teacher voxels, key frame %d student voxels), %s autocast, 6 cameras %dx%d'
-                % (n_agg, int(sum(nb['teacher']['num_vox'])), int(sum(nb['student']['num_vox'])), amp or 'f32', image_hw[0], image_hw[1]))
+        desc = ('BASELINE.json configs[4] on ONE GPU: the KD step at the `_B` widths (student cr %g, teacher cr_t %g) with a '
+                'multi-sweep teacher scene (%d aggregated points, %d teacher voxels, key frame %d student voxels), %s autocast '
+                'with bf16 rows between the sparse operators, 6 cameras %dx%d'
+                % (cr, cr_t, n_agg, int(sum(nb['teacher']['num_vox'])), int(sum(nb['student']['num_vox'])), amp or 'f32',
+                   image_hw[0], image_hw[1]))
     counter = [0]
 
     def step():
@@ -533,7 +537,7 @@ def run_rank(args):
             torch.cuda.empty_cache()
             for name, wl, hw, w_, k_, extra in (('lidar_only_configs1', 'spvcnn', args.image_hw, 3, 10, {}),
                                                 ('configs4_multisweep_bf16_1gpu', 'kd', args.image_hw, 2, 6,
-                                                 {'sweeps': 9, 'dtype': 'bf16', 'voxels': 300000})):
+                                                 {'sweeps': 9, 'dtype': 'bf16', 'voxels': 300000, 'cr': 2.0, 'cr_t': 2.0})):
                 if wl == args.workload and tuple(hw) == tuple(args.image_hw) and not extra:
                     continue
                 try:

@@ -208,6 +208,38 @@ def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write
     print(tag, 'kd golden losses', [float(x) for x in (ce_vox, ce_pix, kl, feat, total)])
 
 
+def make_teacher_multisweep_golden():
+    """Stage-1 (teacher-only) training step of the reference on a MULTI-SWEEP scene (BASELINE.json configs[4]'s
+    teacher input): the reference's own SPVCNN_SPFORMER (core/models/nuscenes/spvcnn_spformer.py)
+    over the oracle operators on three aggregated sweeps, and the loss of core/spformer_trainer.py:80-83 --
+    criterion(outputs['x_vox'][keyframe_mask], targets[keyframe_mask]): only key-frame voxels carry labels."""
+    from oracle.spformer_ref import default_spformer_kwargs
+    _, MixLovaszCrossEntropy = import_reference()
+    cr = 1.0
+    SPF = import_reference_spformer(cr)
+    crit = MixLovaszCrossEntropy(ignore_index=0)
+    kw = default_spformer_kwargs(cr=cr, drop_path_rate=0.0)
+    for k in ('cr', 'in_channel', 'num_classes'):
+        kw.pop(k)
+    b = synth_batch(3000, 2, seed=55, sweeps=3)
+    feats, coords, labels, kf = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels', 'keyframe'))
+    assert 0 < int(kf.sum()) < len(kf)
+    torch.manual_seed(0)
+    ref = O.fill_state_by_name(SPF(**kw)).train()
+    ref.dropout.p = 0.0
+    out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
+    loss = crit(out[kf], labels[kf])
+    loss.backward()
+    grads = {n: p.grad for n, p in ref.named_parameters()}
+    blk = 'transformer_blocks.0.attn.'
+    np.savez_compressed(
+        os.path.join(HERE, 'teacher_multisweep_cr10_6000.npz'),
+        logits=out.detach().numpy().astype(np.float32), loss=np.float32(loss.item()), n_keyframe=np.int64(kf.sum()),
+        grad_stem=grads['stem.3.kernel'].numpy(), grad_cls=grads['classifier_vox.0.weight'].numpy(),
+        grad_tk=grads[blk + 'relative_pos_key_table'].numpy(), grad_up3=grads['vox_ups.3.1.1.net.3.kernel'].numpy()[13])
+    print('teacher multi-sweep golden: loss', float(loss), 'key-frame voxels', int(kf.sum()), 'of', len(kf))
+
+
 def main_kd_widths():
     """Only the KD fixtures at the shipped widths (`python tests/golden/make_golden.py kd`)."""
     _, MixLovaszCrossEntropy = import_reference()
@@ -220,6 +252,9 @@ def main_kd_widths():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'kd':
         main_kd_widths()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'teacher_ms':
+        make_teacher_multisweep_golden()
     else:
         main()
         main_kd_widths()
+        make_teacher_multisweep_golden()
