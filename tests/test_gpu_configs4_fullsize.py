@@ -5,7 +5,10 @@ configs/nuscenes/train/spformer_tsd_full_ours_star_B.yaml:34-36, six 360x640 cam
 BF16 STORAGE between the sparse operators.  The CPU oracle cannot run this size, so the test holds size-independent
 properties (the per-operator and small-scene parity against the oracle / the reference goldens is in
 test_gpu_bf16_rows.py, test_golden_teacher_multisweep.py, test_kd_path.py):
-  * run-to-run determinism of the bf16 step from one state (teacher logits and every loss term bit for bit);
+  * run-to-run reproducibility of the bf16 step from one state: the frozen teacher (this package's kernels + rocBLAS with
+    its atomic split-K kernels switched off, u2mkd_amd/__init__.py) bit for bit; the student, whose camera branch runs
+    MIOpen convolutions that are not run-to-run reproducible (measured: the first module whose output differs between two
+    identical forwards is pix_branch.layer2.0.conv1, DESIGN.md section 7b), within rounding noise;
   * every student parameter receives a finite fp32 gradient, the frozen teacher none;
   * the bf16 step stays within a stated bound of the fp32 step from the same state (logits and losses);
   * the teacher -> student re-index with key-frame masking (core/nusc_trainers.py:288-324) selects exactly the rows the
@@ -55,19 +58,24 @@ def test_scene_is_configs4_sized(world):
     assert 15000 < int(kf.sum()) < 40000 and s['num_vox'][0] < int(kf.sum()) + 1      # the student sees the key frame only
 
 
-def test_bf16_step_is_deterministic_and_trains_every_student_parameter(world):
+def test_bf16_step_is_reproducible_and_trains_every_student_parameter(world):
     nb, d, run, state = world
     res = []
-    for _ in range(2):
+    for _ in range(3):            # (the first pass also settles MIOpen's solver choice)
         run.model.load_state_dict(state)
         out, ld = _step(run, d, True)
-        res.append((out['t']['x_vox'].clone(), out['stu']['x_vox'].detach().clone(),
-                    {k: (torch.stack(list(v)) if isinstance(v, (list, tuple)) else v).detach().clone() for k, v in ld.items()}))
+        res.append((out['t']['x_vox'].clone(), out['stu']['x_vox'].detach().float().clone(),
+                    {k: (torch.stack(list(v)) if isinstance(v, (list, tuple)) else v).detach().float().clone() for k, v in ld.items()}))
     assert res[0][0].shape[0] == nb['teacher']['num_vox'][0]
-    assert torch.equal(res[0][0], res[1][0]), 'teacher logits differ between two runs'
-    assert torch.equal(res[0][1], res[1][1]), 'student logits differ between two runs'
-    for k in res[0][2]:
-        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    assert torch.equal(res[1][0], res[2][0]) and torch.equal(res[0][0], res[1][0]), 'teacher logits differ between runs'
+    # student: bf16 logits of two runs agree to within two bf16 steps on all but a sliver of the rows (a last-place
+    # difference upstream of a rounding edge moves a value by one bf16 step), the loss terms to 2e-4 relative
+    a, b = res[1][1], res[2][1]
+    step = 2.0 ** -7 * float(b.abs().max())
+    far = ((a - b).abs().max(1).values > 2 * step).float().mean()
+    assert float(far) < 0.005, float(far)
+    for k in res[1][2]:
+        assert torch.allclose(res[1][2][k], res[2][2][k], rtol=2e-4, atol=1e-6), (k, res[1][2][k], res[2][2][k])
     assert all(bool(torch.isfinite(v).all()) for v in res[0][2].values())
     for n, p in run.model.model_s.named_parameters():
         assert p.dtype == torch.float32 and p.grad is not None and p.grad.dtype == torch.float32, n
