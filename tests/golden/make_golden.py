@@ -221,13 +221,47 @@ def make_teacher_multisweep_golden():
     kw = default_spformer_kwargs(cr=cr, drop_path_rate=0.0)
     for k in ('cr', 'in_channel', 'num_classes'):
         kw.pop(k)
-    b = synth_batch(3000, 2, seed=55, sweeps=3)
-    feats, coords, labels, kf = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels', 'keyframe'))
+    import core.models.sphereformer.spherical_transformer as ST
+    real_c2s = ST.cart2sphere
+
+    def shifted(k):
+        """cart2sphere with its two atan2-derived angles moved k units in the last place (the CPU and GPU libm differ
+        there): a scene whose logits survive +-4 holds no token within 4 ulp of an edge of SphereFormer's hard window /
+        relative-position quantisers, so the fixture can be held to the north-star 1e-3 without exception"""
+        def f(xyz):
+            o = real_c2s(xyz)
+            ang = o[:, :2]
+            for _ in range(abs(k)):
+                ang = torch.nextafter(ang, torch.full_like(ang, float('inf') if k > 0 else -float('inf')))
+            return torch.cat([ang, o[:, 2:]], 1)
+        return f
+
+    def forward(seed, k=0):
+        import gc
+        gc.collect()
+        b = synth_batch(3000, 2, seed=seed, sweeps=3)
+        feats, coords, labels, kf = (torch.from_numpy(b[x]) for x in ('feats', 'coords', 'labels', 'keyframe'))
+        torch.manual_seed(0)
+        ref = O.fill_state_by_name(SPF(**kw)).train()
+        ref.dropout.p = 0.0
+        ST.cart2sphere = shifted(k) if k else real_c2s
+        try:
+            out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
+        finally:
+            ST.cart2sphere = real_c2s
+        return ref, out, labels, kf
+
+    for seed in range(55, 75):
+        with torch.no_grad():
+            base = forward(seed)[1].clone()
+            worst = max(float((forward(seed, k)[1] - base).abs().max()) for k in (4, -4))
+        print('seed', seed, 'logit change under +-4 ulp of the angles: %.3g' % worst, flush=True)
+        if worst < 1e-4:
+            break
+    else:
+        raise SystemExit('no seed keeps every token 4 ulp away from the quantiser edges')
+    ref, out, labels, kf = forward(seed)
     assert 0 < int(kf.sum()) < len(kf)
-    torch.manual_seed(0)
-    ref = O.fill_state_by_name(SPF(**kw)).train()
-    ref.dropout.p = 0.0
-    out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
     loss = crit(out[kf], labels[kf])
     loss.backward()
     grads = {n: p.grad for n, p in ref.named_parameters()}
@@ -235,7 +269,7 @@ def make_teacher_multisweep_golden():
     np.savez_compressed(
         os.path.join(HERE, 'teacher_multisweep_cr10_6000.npz'),
         logits=out.detach().numpy().astype(np.float32), loss=np.float32(loss.item()), n_keyframe=np.int64(kf.sum()),
-        grad_stem=grads['stem.3.kernel'].numpy(), grad_cls=grads['classifier_vox.0.weight'].numpy(),
+        seed=np.int64(seed), grad_stem=grads['stem.3.kernel'].numpy(), grad_cls=grads['classifier_vox.0.weight'].numpy(),
         grad_tk=grads[blk + 'relative_pos_key_table'].numpy(), grad_up3=grads['vox_ups.3.1.1.net.3.kernel'].numpy()[13])
     print('teacher multi-sweep golden: loss', float(loss), 'key-frame voxels', int(kf.sum()), 'of', len(kf))
 

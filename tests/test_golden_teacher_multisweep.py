@@ -19,7 +19,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def _inputs():
-    b = synth_batch(3000, 2, seed=55, sweeps=3)
+    # the seed make_golden.py settled on: the first one whose logits do not move when SphereFormer's atan2-derived
+    # angles are shifted by +-4 units in the last place (CPU and GPU libm differ there), i.e. no token sits within 4 ulp
+    # of an edge of the hard window / relative-position quantisers -- the fixture is held to 1e-3 without exception
+    b = synth_batch(3000, 2, seed=int(_gold()['seed']), sweeps=3)
     return tuple(torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels', 'keyframe'))
 
 
