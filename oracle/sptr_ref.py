@@ -85,13 +85,18 @@ def cart2sphere(xyz):  # core/models/sphereformer/spherical_transformer.py:31-36
     return torch.stack([theta, beta, r], -1)
 
 
-def exponential_split(xyz, index_0, index_1, relative_position_index, a=0.05 * 0.25):
-    """spherical_transformer.py:39-64."""
+def exponential_split(xyz, index_0, index_1, relative_position_index, a=0.05 * 0.25, _log_ulps=0):
+    """spherical_transformer.py:39-64.  ``_log_ulps`` (fixture generation only): move the logarithm by that many units
+    in the last place before the floor -- the CPU and GPU libm differ there; tests/golden/make_golden.py uses it to pick
+    scenes without a pair on a radial bin edge."""
     r = xyz[:, 2]
     rel_pos = r[index_0.long()] - r[index_1.long()]
     rel_pos_abs = rel_pos.abs()
     flag_float = (rel_pos >= 0).float()
-    idx = 2 * torch.floor(torch.log((rel_pos_abs + 2 * a) / a) / np.log(2)) - 2
+    lg = torch.log((rel_pos_abs + 2 * a) / a)
+    for _ in range(abs(_log_ulps)):
+        lg = torch.nextafter(lg, torch.full_like(lg, float('inf') if _log_ulps > 0 else -float('inf')))
+    idx = 2 * torch.floor(lg / np.log(2)) - 2
     idx = idx + ((3 * (2 ** (idx // 2)) - 2) * a <= rel_pos_abs).float()
     idx = idx * (2 * flag_float - 1) + (flag_float - 1)
     relative_position_index[:, 2] = idx.long() + 24

@@ -5,8 +5,8 @@ configs/nuscenes/train/spformer_tsd_full_ours_star_B.yaml:34-36, six 360x640 cam
 BF16 STORAGE between the sparse operators.  The CPU oracle cannot run this size, so the test holds size-independent
 properties (the per-operator and small-scene parity against the oracle / the reference goldens is in
 test_gpu_bf16_rows.py, test_golden_teacher_multisweep.py, test_kd_path.py):
-  * run-to-run reproducibility of the bf16 step from one state: the frozen teacher (this package's kernels + rocBLAS with
-    its atomic split-K kernels switched off, u2mkd_amd/__init__.py) bit for bit; the student, whose camera branch runs
+  * run-to-run reproducibility of the bf16 step from one state: the frozen teacher (this package's order-deterministic
+    kernels throughout, SphereFormer's Linear layers included) bit for bit; the student, whose camera branch runs
     MIOpen convolutions that are not run-to-run reproducible (measured: the first module whose output differs between two
     identical forwards is pix_branch.layer2.0.conv1, DESIGN.md section 7b), within rounding noise;
   * every student parameter receives a finite fp32 gradient, the frozen teacher none;

@@ -5,17 +5,7 @@ the reference's ``core/models`` code calls; every operator
 runs as a hand-written HIP kernel behind the C ABI in ``include/u2mkd_hip.h``.
 There is no CPU / PyTorch fallback: operators raise on CPU tensors.
 """
-import os as _os
-
 __version__ = '0.1.0'
-
-# rocBLAS may pick split-K GEMM kernels that combine their partial sums with float atomics: the SphereFormer
-# qkv / proj / MLP products of the frozen teacher then differ in the last place from run to run (measured on MI355X,
-# tools/dbg_determinism_kd.py: 12..734 of 276 000 teacher rows, only while other streams keep the chip busy), and a
-# last-place difference upstream of SphereFormer's hard window / relative-position quantisers moves whole tokens.
-# Everything this package computes itself is order-deterministic, so the library default is to ask rocBLAS for its
-# non-atomic kernels as well (read when rocBLAS creates its handle; set the variable to 1 beforehand to opt out).
-_os.environ.setdefault('ROCBLAS_DEFAULT_ATOMICS_MODE', '0')
 
 
 def install_as_torchsparse():

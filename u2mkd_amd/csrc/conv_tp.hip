@@ -659,12 +659,15 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
     const int ar = conv_tp_arith(arith);
     if (ar == 2 || ar == 3) {
         const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
-        const dim3 grid((unsigned)ceil_div(total, 256), transpose == 2 ? 2 : 1);
+        // one-wave workgroups: the kernel is a single round of loads and stores per thread (latency-bound), and 27 x 64 x 64
+        // weights are only 432 waves -- as 256-thread workgroups they sat on 108 of the 256 CUs
+        static const int bt = getenv("U2MKD_FRAG_BLOCK") ? atoi(getenv("U2MKD_FRAG_BLOCK")) : 64;
+        const dim3 grid((unsigned)ceil_div(total, bt), transpose == 2 ? 2 : 1);
         if (ar == 2)
-            hipLaunchKernelGGL(weight_fragments_x3_kernel<3>, grid, dim3(256), 0, st, w, rows, cols, transpose,
+            hipLaunchKernelGGL(weight_fragments_x3_kernel<3>, grid, dim3(bt), 0, st, w, rows, cols, transpose,
                                reinterpret_cast<bf16x8 *>(wf), total);
         else
-            hipLaunchKernelGGL(weight_fragments_x3_kernel<1>, grid, dim3(256), 0, st, w, rows, cols, transpose,
+            hipLaunchKernelGGL(weight_fragments_x3_kernel<1>, grid, dim3(bt), 0, st, w, rows, cols, transpose,
                                reinterpret_cast<bf16x8 *>(wf), total);
     } else {
         hipLaunchKernelGGL(weight_fragments_kernel, dim3((unsigned)ceil_div(elems, 256), transpose == 2 ? 2 : 1), dim3(256), 0, st, w, rows, cols,

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .. import sptr
+from .blocks import PointLinear
 
 _PACKED = os.environ.get('U2MKD_SPTR_PACKED', '1') != '0'     # 0: slice / scale / concatenate around the contiguous kernels
 
@@ -47,9 +48,14 @@ class DropPath(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        # nn.Linear of the reference (same parameters and state-dict keys) on this package's MFMA pipeline: forward /
+        # input gradient on the pair kernel's dense mode, the weight gradient (a [out, N] x [N, in] product whose
+        # reduction runs over all N tokens) on the pair-list kernel with its fixed-order slab sum -- rocBLAS answers
+        # that shape with an atomic split-K kernel (not reproducible from run to run) or, atomics off, ONE serial tile
+        # (14 ms per product at N = 80 000, measured)
+        self.fc1 = PointLinear(in_features, hidden_features)
         self.act = nn.GELU()
-        self.fc2 = nn.Linear(hidden_features, in_features)
+        self.fc2 = PointLinear(hidden_features, in_features)
 
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
@@ -89,8 +95,8 @@ class SparseMultiheadSASphereConcat(nn.Module):
         self.relative_pos_query_table_sphere = table(2 * qgs, h2)
         self.relative_pos_key_table_sphere = table(2 * qgs, h2)
         self.relative_pos_value_table_sphere = table(2 * qgs, h2)
-        self.qkv = nn.Linear(embed_dim, embed_dim * 3, bias=True)
-        self.proj = nn.Linear(embed_dim, embed_dim)
+        self.qkv = PointLinear(embed_dim, embed_dim * 3, bias=True)
+        self.proj = PointLinear(embed_dim, embed_dim)
 
     def forward(self, feats, xyz, batch):
         N, C = feats.shape
