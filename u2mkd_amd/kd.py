@@ -89,7 +89,7 @@ class StudentMSP2IFM(nn.Module):
                     ResidualBlock(cs[i + 1] + cs[len(cs) - 2 - i], cs[i + 1], ks=3, stride=1, dilation=1),
                     ResidualBlock(cs[i + 1], cs[i + 1], ks=3, stride=1, dilation=1))])
             for i in range(4, len(cs) - 1)])
-        self.classifier_vox = nn.Sequential(nn.Linear(cs[8], num_classes))
+        self.classifier_vox = nn.Sequential(PointLinear(cs[8], num_classes))
         self.classifier_pix = BNReluConv(self.pix_branch.num_features, num_classes, k=1)
         self.point_transforms = nn.ModuleList([
             FusedSequential(PointLinear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))

@@ -49,7 +49,7 @@ class SPVCNN(nn.Module):
                     ResidualBlock(cs[i + 1], cs[i + 1], ks=3, stride=1, dilation=1))])
             for i in range(4, len(cs) - 1)])
 
-        self.classifier_vox = nn.Sequential(nn.Linear(cs[8], self.num_classes))
+        self.classifier_vox = nn.Sequential(PointLinear(cs[8], self.num_classes))
 
         self.point_transforms = nn.ModuleList([
             FusedSequential(PointLinear(cs[a], cs[b]), PointBatchNorm1d(cs[b]), nn.ReLU(True))

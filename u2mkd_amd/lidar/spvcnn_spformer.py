@@ -81,7 +81,7 @@ class SPVCNN_SPFORMER(nn.Module):
                     ResidualBlock(cs[i + 1] + cs[len(cs) - 2 - i], cs[i + 1], ks=3, stride=1, dilation=1),
                     ResidualBlock(cs[i + 1], cs[i + 1], ks=3, stride=1, dilation=1))])
             for i in range(4, len(cs) - 1)])
-        self.classifier_vox = nn.Sequential(nn.Linear(cs[8], num_classes))
+        self.classifier_vox = nn.Sequential(PointLinear(cs[8], num_classes))
         self.point_transforms = nn.ModuleList([
             FusedSequential(PointLinear(cs[a_], cs[b_]), PointBatchNorm1d(cs[b_]), nn.ReLU(True))
             for a_, b_ in ((0, 4), (4, 6), (6, 8))])

@@ -774,9 +774,21 @@ class LinearFunction(Function):
 
 
 def linear(x, weight, bias=None):
-    """nn.functional.linear for [N, C] feature matrices on the HIP path (in / out features must be
-    multiples of 4; CPU tensors raise)."""
-    return LinearFunction.apply(x, weight, bias)
+    """nn.functional.linear for [N, C] feature matrices on the HIP path (CPU tensors raise).  in / out features that
+    are not multiples of 4 (the 17-class heads) are zero-padded to the next multiple of 32 / 4 -- rows of `weight` and
+    entries of `bias` for the outputs, columns of `weight` and of `x` for the inputs; differentiable, the padding
+    receives zero gradient and the extra output columns are dropped (as conv3d does for odd channel counts)."""
+    cout, cin = weight.shape
+    pin = (-cin) % 4
+    pout = 0 if cout % 4 == 0 else ((-cout) % 32 if cin % 32 == 0 else (-cout) % 4)
+    if pin == 0 and pout == 0:
+        return LinearFunction.apply(x, weight, bias)
+    if pin:
+        x = torch.nn.functional.pad(x, (0, pin))
+    weight = torch.nn.functional.pad(weight, (0, pin, 0, pout))
+    if bias is not None and pout:
+        bias = torch.nn.functional.pad(bias, (0, pout))
+    return LinearFunction.apply(x, weight, bias)[:, :cout]
 
 
 _OVERLAP_WGRAD = os.environ.get('U2MKD_OVERLAP_WGRAD', '1') != '0'
