@@ -321,6 +321,13 @@ int u2mkd_devoxelize_forward_bf16(const void *feats /*bf16 [nv,c]*/, const int32
 int u2mkd_segment_sum_bf16(const void *src /*bf16 [*,c]*/, int32_t c, const int32_t *entry_row /*[E]*/,
                            const float *entry_w /*[E] or NULL*/, const int32_t *seg_offsets /*[nv+1]*/, int64_t nv,
                            int32_t mean, void *out /*bf16 [nv,c]*/, u2mkd_stream_t s);
+/* The entry lists u2mkd_segment_sum walks, built in one call (csrc/csr.hip): entries e with key[e] in [0, nv) grouped by
+ * key, ascending e inside a group -- bit-identical to a stable argsort by key, by a counting sort (histogram, scan,
+ * placement, per-segment sort of the entry ids).  order [n_entries] (the first seg[nv] entries are live, the rest 0),
+ * seg [nv + 1]; keys outside [0, nv) are dropped.  workspace: u2mkd_csr_workspace_bytes(n_entries, nv) bytes.      */
+size_t u2mkd_csr_workspace_bytes(int64_t n_entries, int64_t nv);
+int u2mkd_csr_build(const int32_t *keys /*[n_entries]*/, int64_t n_entries, int64_t nv, void *workspace,
+                    int32_t *order /*[n_entries]*/, int32_t *seg /*[nv+1]*/, u2mkd_stream_t s);
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 

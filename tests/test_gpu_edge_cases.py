@@ -152,3 +152,27 @@ def test_floor_coords_kernel_equals_the_torch_formula(F):
     for s in (1, 2, 8, 16):
         want = torch.cat([torch.floor(pc[:, :3] / s).int() * s, pc[:, -1].int().view(-1, 1)], 1)
         assert torch.equal(_floor_coords(pc.cuda(), s).cpu(), want)
+
+
+@pytest.mark.parametrize('e,nv,drop', [(200000, 60000, 0.1), (480000, 5000, 0.5), (1000, 1, 0.0), (70000, 300000, 0.0), (5, 3, 0.4),
+                                       (20000, 4, 0.0), (0, 7, 0.0)])
+def test_csr_build_equals_a_stable_argsort(hip, e, nv, drop):
+    """u2mkd_csr_build (counting sort + per-segment sort of the entry ids, csrc/csr.hip) groups the entries exactly as
+    the stable argsort it replaces: bit-identical live entries and segment offsets, dropped keys (negative or >= nv)
+    left out; short (<= 24), long (LDS-ranked) and very long (> 2048: global-memory ranked) segments all occur."""
+    from u2mkd_amd.torchsparse.nn import functional as F
+    g = torch.Generator().manual_seed(e + nv)
+    keys = torch.randint(0, max(nv, 1), (e,), generator=g, dtype=torch.int32)
+    if e > 1000:
+        keys[: e // 8] = keys[: e // 8] % max(nv // 50, 1)          # a few heavy destinations
+    dropped = torch.rand(e, generator=g) < drop
+    keys[dropped] = torch.where(torch.rand(int(dropped.sum()), generator=g) < 0.5, -1, nv + 3).int()
+    order, seg = F._csr_by_destination(keys.cuda(), nv)
+    valid = (keys >= 0) & (keys < nv)
+    want_seg = torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(keys[valid].long(), minlength=nv).cumsum(0)])
+    assert torch.equal(seg.cpu().long(), want_seg)
+    ids = torch.arange(e)[valid]
+    want = ids[torch.argsort(keys[valid].long(), stable=True)]
+    n_live = int(want_seg[-1])
+    assert torch.equal(order.cpu().long()[:n_live], want)
+    assert bool((order.cpu()[n_live:] == 0).all())

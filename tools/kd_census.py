@@ -5,10 +5,11 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from tools.kd_host import build
 run, d = build(80000)
-for _ in range(4): run(d)
+from u2mkd_amd import train as T
+for _ in range(4): run(T.fresh_batch(d))
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    run(d)
+    run(T.fresh_batch(d))
     torch.cuda.synchronize()
 ev = prof.events()
 # map: every CPU op with device kernels -> (count, device time), keyed by innermost repo frame + op name

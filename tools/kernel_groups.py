@@ -23,19 +23,20 @@ def grp(n):
     return 'other'
 
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-steps = int(sys.argv[2])
-top = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-tot = sum(float(r['TotalDurationNs']) for r in rows)
-calls = sum(int(r['Calls']) for r in rows)
-print('kernel time %.1f ms/step, %d launches/step (%d steps)' % (tot / 1e6 / steps, calls / steps, steps))
-acc = collections.defaultdict(lambda: [0.0, 0])
-for r in rows:
-    g = grp(r['Name'])
-    acc[g][0] += float(r['TotalDurationNs'])
-    acc[g][1] += int(r['Calls'])
-for g, (t, c) in sorted(acc.items(), key=lambda x: -x[1][0]):
-    print('%-20s %7.2f ms/step %6d launches/step' % (g, t / 1e6 / steps, c / steps))
-print()
-for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:top]:
-    print('%8.2f ms/step %6.1f  %s' % (float(r['TotalDurationNs']) / 1e6 / steps, int(r['Calls']) / steps, r['Name'][:120]))
+if __name__ == '__main__':
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    steps = int(sys.argv[2])
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    calls = sum(int(r['Calls']) for r in rows)
+    print('kernel time %.1f ms/step, %d launches/step (%d steps)' % (tot / 1e6 / steps, calls / steps, steps))
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in rows:
+        g = grp(r['Name'])
+        acc[g][0] += float(r['TotalDurationNs'])
+        acc[g][1] += int(r['Calls'])
+    for g, (t, c) in sorted(acc.items(), key=lambda x: -x[1][0]):
+        print('%-20s %7.2f ms/step %6d launches/step' % (g, t / 1e6 / steps, c / steps))
+    print()
+    for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:top]:
+        print('%8.2f ms/step %6.1f  %s' % (float(r['TotalDurationNs']) / 1e6 / steps, int(r['Calls']) / steps, r['Name'][:120]))

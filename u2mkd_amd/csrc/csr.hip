@@ -1,0 +1,212 @@
+// Destination-grouped entry lists (CSR) for the deterministic scatter replacements: voxelise forward, devoxelise
+// backward, LiDAR -> camera pixel means, camera -> LiDAR backward (u2mkd_segment_sum walks them).  torchsparse v1.4.0
+// scatters with float atomics (voxelize_forward_cuda / devoxelize_backward_cuda); here every
+// destination row sums its entries in ascending entry order, which needs the entries grouped by destination.
+//
+// Round 2 built the grouping with torch: count + zeros + cumsum + where + a stable argsort (rocPRIM's merge sort below
+// its radix threshold: ~13 launches) + a cast -- ~20 launches and 6 Python-level ops per list, ~40 lists per KD step, on
+// a step that is bound by the host's launch rate.  The keys are small integers (destination ids < nv), so a counting
+// sort does it in ONE call: histogram (integer atomics: exact), exclusive scan, placement with an atomic cursor (the
+// order inside a segment is then arbitrary), and a sort of every segment's entry ids (segments are short: a few to a
+// few hundred entries) that restores the ascending-entry order -- the result is bit-identical to the stable argsort.
+#include "common.h"
+
+namespace u2mkd {
+
+constexpr int kCsrThreads = 256;
+constexpr int kScanBlock = 2048;            // elements per scan block (256 threads x 8)
+
+__global__ void __launch_bounds__(kCsrThreads)
+csr_count_kernel(const int32_t *__restrict__ keys, int64_t e, int64_t nv, int32_t *__restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const int k = keys[i];
+    if (k >= 0 && k < nv) atomicAdd(&counts[k], 1);
+}
+
+// exclusive scan, three small launches: per-block sums, one block scans them, per-block scan with its offset
+__global__ void __launch_bounds__(kCsrThreads)
+csr_block_sums_kernel(const int32_t *__restrict__ counts, int64_t nv, int32_t *__restrict__ block_sums) {
+    __shared__ int s[kCsrThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock;
+    int t = 0;
+#pragma unroll
+    for (int j = 0; j < kScanBlock / kCsrThreads; ++j) {
+        const int64_t i = base + threadIdx.x + j * kCsrThreads;
+        t += i < nv ? counts[i] : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void __launch_bounds__(kCsrThreads)
+csr_scan_sums_kernel(int32_t *__restrict__ block_sums, int nb, int32_t *__restrict__ total) {
+    // one workgroup: serial chunks of 256 with a running carry (nb <= a few hundred)
+    __shared__ int s[kCsrThreads];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += kCsrThreads) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? block_sums[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kCsrThreads; off <<= 1) {      // Hillis-Steele inclusive scan
+            const int add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int c = carry;
+        if (i < nb) block_sums[i] = c + s[threadIdx.x] - v;     // exclusive
+        __syncthreads();
+        if (threadIdx.x == kCsrThreads - 1) carry = c + s[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kCsrThreads)
+csr_scan_blocks_kernel(const int32_t *__restrict__ counts, int64_t nv, const int32_t *__restrict__ block_sums,
+                       const int32_t *__restrict__ total, int32_t *__restrict__ seg /*[nv+1]*/, int32_t *__restrict__ cursor) {
+    // thread t owns 8 consecutive elements: local prefix, wave scan, workgroup scan
+    __shared__ int s[kCsrThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * 8;
+    int v[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = base + j < nv ? counts[base + j] : 0;
+        sum += v[j];
+    }
+    int incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s[w];
+    int run = block_sums[blockIdx.x] + woff + incl - sum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < nv) {
+            seg[base + j] = run;
+            cursor[base + j] = run;          // the placement kernel bumps this copy
+        }
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) seg[nv] = *total;
+}
+
+__global__ void __launch_bounds__(kCsrThreads)
+csr_place_kernel(const int32_t *__restrict__ keys, int64_t e, int64_t nv, int32_t *__restrict__ cursor,
+                 int32_t *__restrict__ order) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const int k = keys[i];
+    if (k >= 0 && k < nv) order[atomicAdd(&cursor[k], 1)] = (int32_t)i;
+}
+
+// ascending entry ids inside every segment.  One thread per segment for short segments (insertion sort in
+// place), one wave per long segment (rank by counting into LDS / a scratch copy).
+constexpr int kShortSeg = 24;
+
+__global__ void __launch_bounds__(kCsrThreads)
+csr_sort_short_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int b = seg[v], n = seg[v + 1] - b;
+    if (n < 2 || n > kShortSeg) return;
+    int32_t *o = order + b;
+    for (int i = 1; i < n; ++i) {
+        const int x = o[i];
+        int j = i - 1;
+        while (j >= 0 && o[j] > x) { o[j + 1] = o[j]; --j; }
+        o[j + 1] = x;
+    }
+}
+
+// long segments: wave w scans the segment list for segments longer than kShortSeg (grid-stride over segments, one
+// wave per candidate); entries are ranked by counting (ids are distinct) and rewritten through LDS in chunks
+constexpr int kLongChunk = 2048;
+__global__ void __launch_bounds__(64)
+csr_sort_long_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order, int32_t *__restrict__ scratch) {
+    __shared__ int s_in[kLongChunk];
+    const int lane = threadIdx.x;
+    for (int64_t v = blockIdx.x; v < nv; v += gridDim.x) {
+        const int b = seg[v], n = seg[v + 1] - b;
+        if (n <= kShortSeg) continue;
+        int32_t *o = order + b;
+        if (n <= kLongChunk) {
+            for (int i = lane; i < n; i += 64) s_in[i] = o[i];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const int x = s_in[i];
+                int r = 0;
+                for (int j = 0; j < n; ++j) r += s_in[j] < x;
+                o[r] = x;
+            }
+            __syncthreads();
+        } else {      // (never on the U2MKD scenes: thousands of entries on one destination) rank against global memory
+            int32_t *tmp = scratch + b;
+            for (int i = lane; i < n; i += 64) tmp[i] = o[i];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const int x = tmp[i];
+                int r = 0;
+                for (int j = 0; j < n; ++j) r += tmp[j] < x;
+                o[r] = x;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace u2mkd
+
+using namespace u2mkd;
+
+extern "C" {
+
+size_t u2mkd_csr_workspace_bytes(int64_t n_entries, int64_t nv) {
+    const int64_t nb = ceil_div(nv > 0 ? nv : 1, kScanBlock);
+    return (size_t)(2 * (nv + 1) + nb + 2 + n_entries) * sizeof(int32_t);
+}
+
+int u2mkd_csr_build(const int32_t *keys, int64_t n_entries, int64_t nv, void *workspace, int32_t *order, int32_t *seg,
+                    u2mkd_stream_t s) {
+    U2_REQUIRE(nv >= 0 && n_entries >= 0, "u2mkd_csr_build: negative sizes");
+    U2_REQUIRE(seg && workspace && (n_entries == 0 || (keys && order)), "u2mkd_csr_build: null pointer");
+    U2_REQUIRE(nv < ((int64_t)1 << 31) - kScanBlock && n_entries < ((int64_t)1 << 31), "u2mkd_csr_build: sizes beyond int32");
+    hipStream_t st = as_stream(s);
+    if (nv == 0 || n_entries == 0) {
+        (void)hipMemsetAsync(seg, 0, (size_t)(nv + 1) * sizeof(int32_t), st);
+        return check_launch("u2mkd_csr_build");
+    }
+    const int nb = (int)ceil_div(nv, kScanBlock);
+    int32_t *counts = reinterpret_cast<int32_t *>(workspace);
+    int32_t *cursor = counts + (nv + 1);
+    int32_t *block_sums = cursor + (nv + 1);
+    int32_t *total = block_sums + nb;
+    int32_t *scratch = total + 2;
+    (void)hipMemsetAsync(counts, 0, (size_t)nv * sizeof(int32_t), st);
+    (void)hipMemsetAsync(order, 0, (size_t)n_entries * sizeof(int32_t), st);      // entries past seg[nv] stay a valid index (0)
+    const unsigned ge = (unsigned)ceil_div(n_entries, kCsrThreads);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(ge), dim3(kCsrThreads), 0, st, keys, n_entries, nv, counts);
+    hipLaunchKernelGGL(csr_block_sums_kernel, dim3(nb), dim3(kCsrThreads), 0, st, counts, nv, block_sums);
+    hipLaunchKernelGGL(csr_scan_sums_kernel, dim3(1), dim3(kCsrThreads), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(nb), dim3(kCsrThreads), 0, st, counts, nv, block_sums, total, seg, cursor);
+    hipLaunchKernelGGL(csr_place_kernel, dim3(ge), dim3(kCsrThreads), 0, st, keys, n_entries, nv, cursor, order);
+    hipLaunchKernelGGL(csr_sort_short_kernel, dim3((unsigned)ceil_div(nv, kCsrThreads)), dim3(kCsrThreads), 0, st, seg, nv, order);
+    const unsigned gl = (unsigned)std::min<int64_t>(nv, 2048);
+    hipLaunchKernelGGL(csr_sort_long_kernel, dim3(gl), dim3(64), 0, st, seg, nv, order, scratch);
+    return check_launch("u2mkd_csr_build");
+}
+
+}  // extern "C"

@@ -105,13 +105,15 @@ def _rows(t, b16):
 
 # ------------------------------------------------- destination-sorted scatter plans
 def _csr_by_destination(keys: torch.Tensor, nv: int):
-    """(entry order int32 [E'], segment offsets int32 [nv+1]) of the entries with key >= 0, sorted
-    by key (stable).  No host sync: dropped entries sort to the end and are never addressed."""
+    """(entry order int32 [E], segment offsets int32 [nv+1]) of the entries with 0 <= key < nv, grouped by key, ascending
+    entry id inside a group (what a stable argsort by key gives; the entries past seg[nv] are 0 and never addressed).
+    One call, no host sync (csrc/csr.hip: counting sort)."""
     k32 = _i32(keys).contiguous().view(-1)
-    counts = spcount(k32, nv)
-    seg = torch.zeros(nv + 1, dtype=torch.int32, device=keys.device)
-    torch.cumsum(counts, 0, out=seg[1:])
-    order = torch.argsort(torch.where(k32 >= 0, k32, nv), stable=True).int()
+    e = k32.numel()
+    order = torch.empty(e, dtype=torch.int32, device=keys.device)
+    seg = torch.empty(nv + 1, dtype=torch.int32, device=keys.device)
+    ws = torch.empty(max(L.load().u2mkd_csr_workspace_bytes(e, nv), 16), dtype=torch.uint8, device=keys.device)
+    L.call('u2mkd_csr_build', L.ptr(k32), e, nv, L.ptr(ws), L.ptr(order), L.ptr(seg), L.stream())
     return order, seg
 
 
