@@ -82,3 +82,33 @@ def test_configs4_multisweep_teacher_under_bf16_autocast(hip):
     assert all(np.isfinite(losses)) and max(losses) < 10 * losses[0]
     for n, p in run.model.model_s.named_parameters():
         assert p.dtype == torch.float32 and p.grad is not None and p.grad.dtype == torch.float32, n
+
+
+def test_prefetched_geometry_makes_the_forward_sync_free_and_changes_nothing(hip):
+    """train.KDStep(prefetch=next batch): the voxel sets and kernel maps of batch k+1 are built between the forward and
+    the backward of step k (kd.TSDFull.prepare).  (1) same losses as the plain loop, step for step; (2) a forward that
+    is handed the prepared geometry contains NO host synchronisation (torch's sync debug mode raises on one)."""
+    from u2mkd_amd import train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    batches = [T.kd_batch_to_device(synth_kd_batch(2500, 1, seed=40 + i, image_hw=(64, 112))) for i in range(3)]
+    plain = _runner(1.0, 1.0)
+    want = [float(plain(T.fresh_batch(b))) for b in batches]
+    del plain
+    torch.cuda.empty_cache()
+    run = _runner(1.0, 1.0)
+    got, cur = [], T.fresh_batch(batches[0])
+    for i in range(3):
+        nxt = T.fresh_batch(batches[i + 1]) if i + 1 < 3 else None
+        got.append(float(run(cur, prefetch=nxt)))
+        cur = nxt
+    assert np.allclose(got, want, rtol=2e-3), (got, want)          # (MIOpen's camera branch is not bit-reproducible)
+    # sync-free forward on prepared geometry
+    d = T.fresh_batch(batches[1])
+    in_mod = run.model.prepare(run._in_mod(d))
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        out = run.net(in_mod)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert bool(torch.isfinite(out['stu']['x_vox']).all())

@@ -20,7 +20,7 @@ from .graphs import PieceCache, StaticPiece
 from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c_scatter
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
-from .lidar.point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .lidar.point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, voxel_to_point
 from .torchsparse.nn import functional as spf
 from .lidar.sphereformer import SphereFormer
 from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
@@ -163,10 +163,9 @@ class StudentMSP2IFM(nn.Module):
         cam = in_mod.get('_camera_head')          # queued already by TSDFull (ahead of the teacher's forward)
         if cam is None:
             cam = self.camera_head(in_mod)
-        z = PointTensor(x.F, x.C.float())
-        x0 = initial_voxelize(z, self.pres, self.vres)
+        # points -> stride-1 voxels + all kernel maps (every down-sample sync), prepared ahead by the trainer or here
+        z, x0 = in_mod.get('_geometry') or prepare_geometry(x, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())
-        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)     # all down-sample syncs up front
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
         vox_feats = [point_to_voxel(x0, z0)]
@@ -261,6 +260,21 @@ class TSDFull(nn.Module):
         self.debug_val = debug_val
         self.model_s.adapt_layer = FusedSequential(
             PointLinear(self.model_s.cs[4], self.model_t.cs[4]), PointBatchNorm1d(self.model_t.cs[4]), nn.ReLU(True))
+
+    def prepare(self, in_mod: dict):
+        """Geometry of a batch for both networks (point_voxel.prepare_geometry), on the current stream: everything in a
+        training step that makes the host wait for the GPU.  ``forward`` of a batch that carries the result as
+        ``in_mod['student']['_geometry']`` / ``in_mod['teacher']['_geometry']`` is pure launch issue.  Called by
+        train.KDStep for batch k+1 between the forward and the backward of step k: the GPU queue is short there (the
+        forward is bound by the host's launch rate), so the waits are short, and the host then issues the next
+        forward while step k's backward -- ~30 ms of queued kernels -- drains, instead of sitting in the next
+        forward's first synchronisation for as long."""
+        with torch.no_grad():
+            g_s = prepare_geometry(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres)
+            g_t = prepare_geometry(in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)
+        in_mod['student']['_geometry'] = g_s
+        in_mod['teacher']['_geometry'] = g_t
+        return in_mod
 
     def forward(self, in_mod: dict):
         """tsd_full.py:582-596.  The frozen teacher's forward is independent of the student's until the KD losses,

@@ -4,7 +4,8 @@ Mirrors the reference's operator-level wiring on top
 of ``u2mkd_amd.torchsparse``; module / parameter names match the reference so
 its checkpoints load unchanged.
 """
-from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point, fetch_idx, SparseSyncBatchNorm
+from .point_voxel import (initial_voxelize, point_to_voxel, voxel_to_point, fetch_idx, prepare_geometry,
+                          SparseSyncBatchNorm)
 from .blocks import BasicConvolutionBlock, BasicDeconvolutionBlock, ResidualBlock
 from .spvcnn import SPVCNN
 from .sphereformer import SphereFormer

@@ -53,6 +53,22 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     return new_tensor
 
 
+KMAP_SPECS = [(3, 1)] + [(2, 2), (3, 1)] * 4       # the maps an SPVCNN-shaped encoder creates, in forward order
+
+
+def prepare_geometry(x: SparseTensor, pres, vres):
+    """The part of a forward pass that depends on the INPUT BATCH only and needs the host: points -> stride-1 voxels
+    (``initial_voxelize``: a ``torch.unique`` sizes the voxel set) and the kernel maps of the whole encoder
+    (``prefetch_kmaps``: one ``torch.unique`` per down-sampling) -- every host synchronisation of a training step is
+    in here.  Returns ``(z, x0)`` exactly as the first lines of the model's forward leave them; a forward that is
+    handed the pair (``in_mod['_geometry']``) queues its launches without ever waiting for the GPU, so a trainer can
+    prepare batch k+1 while step k's backward drains (train.KDStep ``prefetch=``)."""
+    z = PointTensor(x.F, x.C.float())
+    x0 = initial_voxelize(z, pres, vres)
+    spf.prefetch_kmaps(x0, KMAP_SPECS)
+    return z, x0
+
+
 def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     """Scatter-mean point features into the voxels of ``x`` (utils.py:40-65)."""
     cache = z.additional_features

@@ -11,7 +11,7 @@ from ..torchsparse import nn as spnn
 from ..torchsparse.nn import functional as spf
 from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                      ResidualBlock)
-from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, voxel_to_point
 
 __all__ = ['SPVCNN']
 
@@ -66,10 +66,9 @@ class SPVCNN(nn.Module):
 
     def forward(self, in_mod):
         x = in_mod['lidar']
-        z = PointTensor(x.F, x.C.float())
-        x0 = initial_voxelize(z, self.pres, self.vres)
-        # all kernel maps up front: stem k3 at stride 1, then (k2 s2 down, k3) per encoder stage
-        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)
+        # points -> stride-1 voxels and all kernel maps up front (stem k3 at stride 1, then (k2 s2 down, k3) per encoder
+        # stage): the host synchronisations of the forward; a trainer may hand them over prepared (in_mod['_geometry'])
+        z, x0 = in_mod.get('_geometry') or prepare_geometry(x, self.pres, self.vres)
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
 

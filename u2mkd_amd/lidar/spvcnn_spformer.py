@@ -16,7 +16,7 @@ from ..torchsparse import nn as spnn
 from ..torchsparse.nn import functional as spf
 from .blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                      ResidualBlock)
-from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, voxel_to_point
 from .sphereformer import SphereFormer
 
 __all__ = ['SPVCNN_SPFORMER', 'spformer_kwargs']
@@ -93,10 +93,10 @@ class SPVCNN_SPFORMER(nn.Module):
 
     def forward(self, in_mod):
         x = in_mod['lidar']
-        z = PointTensor(x.F, x.C.float())
-        x0 = initial_voxelize(z, self.pres, self.vres)
+        # (z, x0): points -> stride-1 voxels + every kernel map of the encoder; prepared ahead by the trainer
+        # (in_mod['_geometry'], point_voxel.prepare_geometry) or here -- the only host synchronisations of the forward
+        z, x0 = in_mod.get('_geometry') or prepare_geometry(x, self.pres, self.vres)
         zz = PointTensor(x0.F, x0.C.float())          # carries the metric xyz of every stride-1 voxel
-        spf.prefetch_kmaps(x0, [(3, 1)] + [(2, 2), (3, 1)] * 4)
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
 

@@ -137,14 +137,28 @@ class KDStep:
         self.model.train()
         self.model.model_t.eval()          # core/nusc_trainers.py:203-208
 
-    def __call__(self, d):
+    @staticmethod
+    def _in_mod(d):
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
                'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
         tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
+        return {'student': stu, 'teacher': tea}
+
+    def __call__(self, d, prefetch=None):
+        """One training step on batch ``d``.  ``prefetch`` = the NEXT batch (the dict the next call will receive): its
+        geometry (voxel sets, kernel maps: every host synchronisation of a step, kd.TSDFull.prepare) is built between
+        this step's forward and backward, where the GPU queue is short; the next call then issues its whole forward
+        without waiting for the GPU while this step's backward drains.  The work per batch is the same, it only moves
+        one step ahead, as a data loader's prefetch does."""
+        queued = self.__dict__.pop('_queued', None)
+        in_mod = queued[1] if (queued is not None and queued[0] is d) else self._in_mod(d)
         with self.amp.autocast():
-            out = self.net({'student': stu, 'teacher': tea})
+            out = self.net(in_mod)
             ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
                               self.crit, d['keyframe_mask_full'])
+        if prefetch is not None:
+            with self.amp.autocast():
+                self._queued = (prefetch, self.model.prepare(self._in_mod(prefetch)))
         self.amp.backward_and_step(ld['total'], self.opt)
         self.sched.step()
         return ld['total'].detach()
