@@ -515,8 +515,6 @@ def run_rank(args):
         return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    if os.environ.get('U2MKD_MIOPEN_BENCHMARK') == '1':      # A/B: let MIOpen time its solvers per convolution shape
-        torch.backends.cudnn.benchmark = True
     from u2mkd_amd import distributed as D
     rank, world, local_rank = D.init_from_env('nccl')
     if world != args.gpus:

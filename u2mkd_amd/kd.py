@@ -283,18 +283,7 @@ class TSDFull(nn.Module):
         queued so far (the teacher's inputs) and the main stream waits for it before the outputs are used;
         U2MKD_TEACHER_STREAM=0 runs the reference's sequential order."""
         want_t = self.training or self.debug_val
-        ahead = in_mod['teacher'].get('_out') if want_t else None
         side = _side_stream(in_mod['teacher']['lidar'].F, 'teacher') if want_t and _TEACHER_STREAM else None
-        if ahead is not None:
-            # the frozen teacher's outputs for this batch were computed one step ahead (teacher_ahead): join its stream
-            ret = {'stu': self.model_s(self._with_camera_head(in_mod['student']))}
-            if side is not None:
-                main = torch.cuda.current_stream()
-                main.wait_stream(side)
-                for v in _tensors(ahead):
-                    v.record_stream(main)
-            ret['t'] = ahead
-            return ret
         if side is None:
             ret = {'stu': self.model_s(in_mod['student'])}
             if want_t:
@@ -302,8 +291,10 @@ class TSDFull(nn.Module):
                     ret['t'] = self.model_t(in_mod['teacher'])
             return ret
         main = torch.cuda.current_stream()
-        # the camera head first: its large kernels run while the host queues the teacher's ~800 small ones
-        stu_in = self._with_camera_head(in_mod['student'])
+        stu_in = in_mod['student']
+        if _CAMERA_STREAM and self.training:
+            # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
+            stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             t = self.model_t(in_mod['teacher'])
@@ -313,28 +304,6 @@ class TSDFull(nn.Module):
             v.record_stream(main)      # allocated on the side stream, consumed (and freed) on the main one
         ret['t'] = t
         return ret
-
-    def _with_camera_head(self, stu_in):
-        if _CAMERA_STREAM and self.training and stu_in['lidar'].F.is_cuda:
-            return dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
-        return stu_in
-
-    def teacher_ahead(self, in_mod: dict):
-        """The frozen teacher's forward of a PREPARED batch (``prepare``), queued on the teacher's stream behind what the
-        main stream holds right now, results left in ``in_mod['teacher']['_out']`` for the ``forward`` of that batch.
-        The teacher reads its batch and its frozen weights only, so train.KDStep runs it for batch k+1 between the
-        forward and the backward of step k: on the GPU it executes next to step k's backward (another stream) instead
-        of in front of step k+1's student forward, and the host issues it without a wait (the geometry is prepared)."""
-        tea = in_mod['teacher']
-        side = _side_stream(tea['lidar'].F, 'teacher') if _TEACHER_STREAM else None
-        with torch.no_grad():
-            if side is None:
-                tea['_out'] = self.model_t(tea)
-            else:
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    tea['_out'] = self.model_t(tea)
-        return in_mod
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'

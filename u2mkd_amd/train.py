@@ -118,9 +118,6 @@ def fresh_batch(d):
     return {k: cp(v) for k, v in d.items()}
 
 
-_TEACHER_AHEAD = os.environ.get('U2MKD_TEACHER_AHEAD', '1') != '0'     # A/B: 0 keeps the teacher inside its own step
-
-
 class KDStep:
     """Uni-to-multi-modal KD training step: frozen teacher forward (no grad, eval-mode BN),
     student forward/backward, the five loss terms."""
@@ -152,9 +149,7 @@ class KDStep:
         geometry (voxel sets, kernel maps: every host synchronisation of a step, kd.TSDFull.prepare) is built between
         this step's forward and backward, where the GPU queue is short; the next call then issues its whole forward
         without waiting for the GPU while this step's backward drains.  The work per batch is the same, it only moves
-        one step ahead, as a data loader's prefetch does.  The frozen teacher's forward of the next batch goes with it
-        (kd.TSDFull.teacher_ahead): it depends on the batch and on frozen weights only, and next to this step's backward
-        it runs on an otherwise under-used GPU."""
+        one step ahead, as a data loader's prefetch does."""
         queued = self.__dict__.pop('_queued', None)
         in_mod = queued[1] if (queued is not None and queued[0] is d) else self._in_mod(d)
         with self.amp.autocast():
@@ -163,10 +158,7 @@ class KDStep:
                               self.crit, d['keyframe_mask_full'])
         if prefetch is not None:
             with self.amp.autocast():
-                nxt = self.model.prepare(self._in_mod(prefetch))
-                if self.model.training and _TEACHER_AHEAD:
-                    self.model.teacher_ahead(nxt)          # next to this step's backward, on the teacher's stream
-                self._queued = (prefetch, nxt)
+                self._queued = (prefetch, self.model.prepare(self._in_mod(prefetch)))
         self.amp.backward_and_step(ld['total'], self.opt)
         self.sched.step()
         return ld['total'].detach()
