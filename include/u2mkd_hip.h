@@ -562,6 +562,23 @@ int u2mkd_bn2d_backward(const float *dy, const float *x, const float *res, int64
                         int32_t batch_stats, void *workspace, float *dgamma, float *dbeta, float *dx,
                         float *dres /*or NULL*/, u2mkd_stream_t s);
 
+/* SyncBatchNorm2d in pieces (SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s), train_lc_nusc_tsd_full.py:80, turns
+ * the camera branch's BatchNorm2d layers into torch.nn.SyncBatchNorm): the caller puts ONE small collective between
+ * them, exactly as for the feature-row pieces above -- local (mean, M2, count) -> all_gather [2c+1] ->
+ * u2mkd_bn_merge_stats -> u2mkd_bn2d_apply (+ residual, ReLU fused); backward: local sums [2c] -> all_reduce ->
+ * u2mkd_bn2d_backward_apply with the global element count (device float).  workspace: u2mkd_bn2d_workspace_bytes.   */
+int u2mkd_bn2d_local_stats(const float *x, int64_t b, int32_t c, int64_t hw, void *workspace, float *stats /*[2c+1]*/,
+                           u2mkd_stream_t s);
+int u2mkd_bn2d_apply(const float *x, const float *res, int64_t b, int32_t c, int64_t hw, const float *mean,
+                     const float *invstd, const float *gamma, const float *beta, int32_t relu, float *y, u2mkd_stream_t s);
+int u2mkd_bn2d_backward_local(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                              const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                              void *workspace, float *sums /*[2c]*/, u2mkd_stream_t s);
+int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                              const float *total_n /*[1] device*/, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx,
+                              float *dres /*or NULL*/, u2mkd_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

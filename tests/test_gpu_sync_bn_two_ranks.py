@@ -195,3 +195,101 @@ def test_two_rank_ddp_step_equals_one_process_on_both_scenes(hip, tmp_path):
     print('DDP-2 vs one process: L2-relative gradient distance median %.2e max %.2e' % (np.median(errs), errs.max()))
     # fp32 summation order differs (per-rank slabs vs one batch) and ReLU inputs within rounding of zero may flip
     assert np.median(errs) < 1e-3 and errs.max() < 3e-2, (np.median(errs), errs.max())
+
+
+_CHILD_2D = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+import torch, torch.distributed as dist
+from u2mkd_amd.camera import BatchNorm2d, SyncBatchNorm2d, bn_act
+from u2mkd_amd.lidar.point_voxel import SparseSyncBatchNorm
+from u2mkd_amd.torchsparse.nn import functional as F
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+torch.cuda.set_device(0)
+C, shapes = 24, ((3, 20, 36), (2, 20, 36))            # UNEQUAL images per rank
+g = torch.Generator().manual_seed(11)
+xs = [torch.randn(b, C, h, w, generator=g) * 1.5 + 0.7 for b, h, w in shapes]
+rs = [torch.randn(b, C, h, w, generator=g) for b, h, w in shapes]
+ws = [torch.randn(b, C, h, w, generator=g) for b, h, w in shapes]
+bn = BatchNorm2d(C, momentum=0.1)
+with torch.no_grad():
+    bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+bn = SparseSyncBatchNorm.convert_sync_batchnorm(bn).cuda().train()
+assert isinstance(bn, SyncBatchNorm2d) and F._sync_group(bn)[1] == 2
+res = {}
+for mode in ('plain', 'relu', 'res'):
+    x = xs[rank].cuda().requires_grad_(True)
+    r = rs[rank].cuda().requires_grad_(True) if mode == 'res' else None
+    bn.zero_grad(set_to_none=True)
+    y = bn_act(bn, x, relu=mode != 'plain', residual=r)
+    (y * ws[rank].cuda()).sum().backward()
+    res[mode] = {'y': y.detach().cpu(), 'dx': x.grad.cpu(), 'dgamma': bn.weight.grad.cpu(), 'dbeta': bn.bias.grad.cpu(),
+                 'dres': r.grad.cpu() if r is not None else None}
+res['running_mean'], res['running_var'], res['tracked'] = bn.running_mean.cpu(), bn.running_var.cpu(), int(bn.num_batches_tracked)
+torch.save(res, out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_hip_sync_batchnorm2d_two_ranks_equals_batchnorm2d_over_all_images(hip, tmp_path):
+    """The camera branch's BatchNorm2d under DDP (SyncBatchNorm2d on the csrc/bn2d.hip pieces, ReLU / residual fused):
+    two processes with 3 and 2 images against ONE fp64 nn.BatchNorm2d over all 5 -- y, dx, the residual gradient, the
+    per-rank dgamma / dbeta, the running statistics with the global count."""
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    outs = [str(tmp_path / f'q{r}.pt') for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_2D, ROOT, str(r), '2', str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    got = [torch.load(o) for o in outs]
+    C, shapes = 24, ((3, 20, 36), (2, 20, 36))
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(b, C, h, w, generator=g) * 1.5 + 0.7 for b, h, w in shapes]
+    rs = [torch.randn(b, C, h, w, generator=g) for b, h, w in shapes]
+    ws = [torch.randn(b, C, h, w, generator=g) for b, h, w in shapes]
+    gamma = (torch.rand(C, generator=g) + 0.5).double()
+    beta = (torch.randn(C, generator=g) * 0.2).double()
+    nb = [s[0] for s in shapes]
+    for mode in ('plain', 'relu', 'res'):
+        x = torch.cat(xs).double().requires_grad_(True)
+        r = torch.cat(rs).double().requires_grad_(True) if mode == 'res' else None
+        bn = torch.nn.BatchNorm2d(C, momentum=0.1).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        pre = bn(x) + (r if r is not None else 0.0)
+        y = torch.relu(pre) if mode != 'plain' else pre
+        w_all = torch.cat(ws).double()
+        (y * w_all).sum().backward()
+        clear = (pre.detach().abs() > 1e-4) if mode != 'plain' else torch.ones_like(pre, dtype=torch.bool)
+        xd = x.detach()
+        xhat = (xd - xd.mean((0, 2, 3), keepdim=True)) / torch.sqrt(xd.var((0, 2, 3), unbiased=False, keepdim=True) + bn.eps)
+        dyp = w_all * ((pre.detach() > 0) if mode != 'plain' else 1.0)
+        lo = 0
+        for rk, n in enumerate(nb):
+            sl = slice(lo, lo + n)
+            lo += n
+            k = got[rk][mode]
+            assert float((k['y'].double() - y.detach()[sl]).abs().max()) < 2e-5 * float(y.detach().abs().max()), (mode, rk)
+            assert float(((k['dx'].double() - x.grad[sl]) * clear[sl]).abs().max()) < 2e-4 * max(1.0, float(x.grad.abs().max())), (mode, rk)
+            if r is not None:
+                assert float(((k['dres'].double() - r.grad[sl]) * clear[sl]).abs().max()) < 2e-5 * max(1.0, float(r.grad.abs().max()))
+            want_db, want_dg = dyp[sl].sum((0, 2, 3)), (dyp[sl] * xhat[sl]).sum((0, 2, 3))
+            assert float((k['dbeta'].double() - want_db).abs().max()) < 2e-4 * max(1.0, float(want_db.abs().max())), (mode, rk)
+            assert float((k['dgamma'].double() - want_dg).abs().max()) < 2e-4 * max(1.0, float(want_dg.abs().max())), (mode, rk)
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).double().train()
+    for _ in range(3):
+        ref(torch.cat(xs).double())
+    for rk in range(2):
+        assert got[rk]['tracked'] == 3
+        assert float((got[rk]['running_mean'].double() - ref.running_mean).abs().max()) < 1e-5
+        assert float((got[rk]['running_var'].double() - ref.running_var).abs().max()) < 1e-4

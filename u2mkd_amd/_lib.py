@@ -51,6 +51,10 @@ SIGNATURES = {
     'u2mkd_bn2d_train_forward': (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, C.c_float, C.c_float, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_bn2d_eval_forward': (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, C.c_float, _i32, _p, _p, _p, _p]),
     'u2mkd_bn2d_backward': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    'u2mkd_bn2d_local_stats': (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p]),
+    'u2mkd_bn2d_apply': (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_bn2d_backward_local': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn2d_backward_apply': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_linear_forward_x3': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-__all__ = ['SwiftNetRes18', 'SwiftNetResNet', 'BNReluConv', 'BatchNorm2d', 'bn_act']
+__all__ = ['SwiftNetRes18', 'SwiftNetResNet', 'BNReluConv', 'BatchNorm2d', 'SyncBatchNorm2d', 'bn_act']
 
 _HIP_BN2D = os.environ.get('U2MKD_BN2D', '1') != '0'
 
@@ -87,10 +87,92 @@ class BatchNorm2d(nn.BatchNorm2d):
         return F.relu(y) if relu else y
 
 
+class _SyncBatchNorm2dFunction(torch.autograd.Function):
+    """relu?(sync_batch_norm(x) [+ res]) over the ranks of a process group on the csrc/bn2d.hip pieces: local
+    (mean, M2, count) -> ONE all_gather of [2C+1] floats -> Chan merge in rank order -> normalise (+ residual, ReLU);
+    backward: local sums -> ONE all_reduce of [2C] floats -> dx with the global count.  The same statistics as
+    torch.nn.SyncBatchNorm (what the reference's convert_sync_batchnorm(model.model_s) makes of every BatchNorm2d of the
+    camera branch, train_lc_nusc_tsd_full.py:80), with the ReLU / residual add still fused under DDP."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, bn, relu, group, world):
+        from . import _lib as L
+        from .torchsparse.nn.functional import _gather_rows
+        b, c, h, w = x.shape
+        hw = h * w
+        dev, st = x.device, L.stream()
+        ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=dev)
+        stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+        L.call('u2mkd_bn2d_local_stats', L.ptr(x), b, c, hw, L.ptr(ws), L.ptr(stats), st)
+        gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
+        if world > 1:
+            _gather_rows(gathered, stats, group)
+        else:
+            gathered.copy_(stats.view(1, -1))
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        total = torch.empty(1, dtype=torch.float32, device=dev)
+        track = bn.running_mean is not None
+        L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(bn.eps), float(bn.momentum if track else 0.0),
+               L.ptr(bn.running_mean if track else None), L.ptr(bn.running_var if track else None), L.ptr(mean),
+               L.ptr(invstd), L.ptr(total), L.stream())
+        y = torch.empty_like(x)
+        L.call('u2mkd_bn2d_apply', L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd), L.ptr(weight), L.ptr(bias),
+               int(relu), L.ptr(y), L.stream())
+        ctx.save_for_backward(x, weight, bias, res, mean, invstd, total)
+        ctx.relu, ctx.group, ctx.world = bool(relu), group, world
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib as L
+        from .torchsparse.nn.functional import _sum_over_ranks
+        x, weight, bias, res, mean, invstd, total = ctx.saved_tensors
+        b, c, h, w = x.shape
+        hw = h * w
+        dy = dy.contiguous()
+        dev = x.device
+        ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=dev)
+        sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        L.call('u2mkd_bn2d_backward_local', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd),
+               L.ptr(weight), L.ptr(bias), int(ctx.relu), L.ptr(ws), L.ptr(sums), L.stream())
+        local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        if ctx.world > 1:
+            _sum_over_ranks(sums, ctx.group)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if res is not None else None
+        L.call('u2mkd_bn2d_backward_apply', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(total), L.ptr(mean),
+               L.ptr(invstd), L.ptr(weight), L.ptr(bias), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.ptr(dres), L.stream())
+        return (dx, local[c:] if weight is not None else None, local[:c] if bias is not None else None, dres,
+                None, None, None, None)
+
+
+class SyncBatchNorm2d(nn.SyncBatchNorm):
+    """What ``SparseSyncBatchNorm.convert_sync_batchnorm`` makes of this file's BatchNorm2d: torch.nn.SyncBatchNorm
+    (same parameters, buffers, keys) whose forward takes the ReLU / residual add that follow it and runs on the HIP
+    pieces with one small collective per pass; anything they do not cover (CPU, autocast, evaluation) takes torch's."""
+
+    def forward(self, x, relu=False, residual=None):
+        from .torchsparse.nn.functional import _sync_group
+        sync = _sync_group(self) if self.training else None
+        if (sync is not None and _HIP_BN2D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+                and x.numel() > 0 and not torch.is_autocast_enabled() and self.momentum is not None
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape))):
+            if residual is not None:
+                residual = residual.contiguous()
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _SyncBatchNorm2dFunction.apply(x, self.weight, self.bias, residual, self, relu, sync[0], sync[1])
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
 def bn_act(bn, x, relu=False, residual=None):
     """relu?(bn(x) [+ residual]) for any BatchNorm flavour (this file's fused one, or what convert_sync_batchnorm
     made of it)."""
-    if isinstance(bn, BatchNorm2d):
+    if isinstance(bn, (BatchNorm2d, SyncBatchNorm2d)):
         return bn(x, relu, residual)
     y = bn(x)
     if residual is not None:

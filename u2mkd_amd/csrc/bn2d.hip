@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64)
 bn2d_stats_finalize_kernel(const float *__restrict__ partial, int np, int hw, int splits, float eps, float momentum,
                            float *__restrict__ running_mean, float *__restrict__ running_var,
                            int64_t *__restrict__ num_batches_tracked, float *__restrict__ mean_out,
-                           float *__restrict__ invstd_out) {
+                           float *__restrict__ invstd_out, float *__restrict__ m2_out = nullptr) {
     const int c = blockIdx.x, lane = threadIdx.x;
     if (num_batches_tracked && c == 0 && lane == 0) *num_batches_tracked += 1;
     float na = 0.f, mean = 0.f, m2 = 0.f;
@@ -104,6 +104,11 @@ bn2d_stats_finalize_kernel(const float *__restrict__ partial, int np, int hw, in
     if (lane != 0) return;
     const float var = m2 / na;
     mean_out[c] = mean;
+    if (m2_out) {          // local statistics only (the cross-rank merge follows): stats row = mean[C], M2[C], count
+        m2_out[c] = m2;
+        if (c == 0) m2_out[gridDim.x] = na;
+        return;
+    }
     invstd_out[c] = 1.f / sqrtf(var + eps);
     if (running_mean) {
         const float unbiased = na > 1.f ? m2 / (na - 1.f) : var;
@@ -198,7 +203,8 @@ bn2d_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                       int hw, int asplits, float inv_n, const float *__restrict__ mean, const float *__restrict__ invstd,
                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                       const float *__restrict__ dbeta, const float *__restrict__ dgamma, float *__restrict__ dx,
-                      float *__restrict__ dres) {
+                      float *__restrict__ dres, const float *__restrict__ total_n = nullptr) {
+    if (total_n) inv_n = 1.f / *total_n;          // SyncBatchNorm: the element count of all ranks (device side)
     const int c = blockIdx.y, b = blockIdx.x / asplits, s = blockIdx.x - b * asplits;
     const int lo = s * kB2ApplyChunk, cnt = min(kB2ApplyChunk, hw - lo);
     const size_t base = ((size_t)b * C + c) * hw + lo;
@@ -291,6 +297,59 @@ int u2mkd_bn2d_backward(const float *dy, const float *x, const float *res, int64
                        res, c, (int)hw, asplits, 1.f / (float)(b * hw), mean, invstd, gamma, beta, relu, batch_stats ? dbeta : nullptr,
                        batch_stats ? dgamma : nullptr, dx, dres);
     return check_launch("u2mkd_bn2d_backward");
+}
+
+/* ---- SyncBatchNorm2d in pieces (as u2mkd_bn_local_stats / _merge_stats / _apply / _backward_local / _backward_apply for
+ * feature rows): local (mean, M2, count) per channel -> the caller's all_gather -> u2mkd_bn_merge_stats -> normalise
+ * (+ residual, ReLU); backward: local (sum dy', sum dy' xhat) -> all_reduce -> dx with the global count. ---- */
+int u2mkd_bn2d_local_stats(const float *x, int64_t b, int32_t c, int64_t hw, void *workspace, float *stats /*[2c+1]*/,
+                           u2mkd_stream_t s) {
+    U2_REQUIRE(x && workspace && stats, "u2mkd_bn2d_local_stats: null pointer");
+    U2_REQUIRE(b2_shape_ok(b, c, hw), "u2mkd_bn2d_local_stats: shape [%lld, %d, %lld] out of range", (long long)b, c, (long long)hw);
+    const int splits = b2_splits((int)hw, kB2Chunk);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(bn2d_stats_partial_kernel, dim3((unsigned)(splits * b), (unsigned)c), dim3(kB2Threads), 0, as_stream(s), x,
+                       c, (int)hw, splits, partial);
+    hipLaunchKernelGGL(bn2d_stats_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), partial, (int)(splits * b),
+                       (int)hw, splits, 0.f, 0.f, (float *)nullptr, (float *)nullptr, (int64_t *)nullptr, stats, (float *)nullptr,
+                       stats + c);
+    return check_launch("u2mkd_bn2d_local_stats");
+}
+
+int u2mkd_bn2d_apply(const float *x, const float *res, int64_t b, int32_t c, int64_t hw, const float *mean,
+                     const float *invstd, const float *gamma, const float *beta, int32_t relu, float *y, u2mkd_stream_t s) {
+    U2_REQUIRE(x && mean && invstd && y, "u2mkd_bn2d_apply: null pointer");
+    U2_REQUIRE(b2_shape_ok(b, c, hw), "u2mkd_bn2d_apply: shape [%lld, %d, %lld] out of range", (long long)b, c, (long long)hw);
+    const int asplits = b2_splits((int)hw, kB2ApplyChunk);
+    hipLaunchKernelGGL(bn2d_apply_kernel, dim3((unsigned)(asplits * b), (unsigned)c), dim3(kB2Threads), 0, as_stream(s), x, res, c,
+                       (int)hw, asplits, mean, invstd, nullptr, 0.f, gamma, beta, relu, y);
+    return check_launch("u2mkd_bn2d_apply");
+}
+
+int u2mkd_bn2d_backward_local(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                              const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                              void *workspace, float *sums /*[2c]: dbeta, dgamma of this rank*/, u2mkd_stream_t s) {
+    U2_REQUIRE(dy && x && mean && invstd && workspace && sums, "u2mkd_bn2d_backward_local: null pointer");
+    U2_REQUIRE(b2_shape_ok(b, c, hw), "u2mkd_bn2d_backward_local: shape [%lld, %d, %lld] out of range", (long long)b, c, (long long)hw);
+    const int splits = b2_splits((int)hw, kB2Chunk);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(bn2d_bwd_partial_kernel, dim3((unsigned)(splits * b), (unsigned)c), dim3(kB2Threads), 0, as_stream(s), dy, x,
+                       res, c, (int)hw, splits, mean, invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), partial, (int)(splits * b), sums,
+                       sums + c);
+    return check_launch("u2mkd_bn2d_backward_local");
+}
+
+int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                              const float *total_n, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx,
+                              float *dres, u2mkd_stream_t s) {
+    U2_REQUIRE(dy && x && total_n && mean && invstd && sums && dx, "u2mkd_bn2d_backward_apply: null pointer");
+    U2_REQUIRE(b2_shape_ok(b, c, hw), "u2mkd_bn2d_backward_apply: shape [%lld, %d, %lld] out of range", (long long)b, c, (long long)hw);
+    const int asplits = b2_splits((int)hw, kB2ApplyChunk);
+    hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3((unsigned)(asplits * b), (unsigned)c), dim3(kB2Threads), 0, as_stream(s), dy, x,
+                       res, c, (int)hw, asplits, 0.f, mean, invstd, gamma, beta, relu, sums, sums + c, dx, dres, total_n);
+    return check_launch("u2mkd_bn2d_backward_apply");
 }
 
 }  // extern "C"

@@ -144,7 +144,9 @@ class SparseSyncBatchNorm(nn.SyncBatchNorm):
     def convert_sync_batchnorm(cls, module, process_group=None):
         out = module
         if isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
-            klass = SparseSyncBatchNorm if isinstance(module, spnn.BatchNorm) else PointSyncBatchNorm1d
+            from ..camera import BatchNorm2d as _CamBN, SyncBatchNorm2d
+            klass = (SparseSyncBatchNorm if isinstance(module, spnn.BatchNorm)
+                     else SyncBatchNorm2d if isinstance(module, (_CamBN, nn.BatchNorm2d)) else PointSyncBatchNorm1d)
             out = klass(module.num_features, module.eps, module.momentum, module.affine,
                         module.track_running_stats, process_group)
             if module.affine:
