@@ -331,6 +331,27 @@ int u2mkd_csr_build(const int32_t *keys /*[n_entries]*/, int64_t n_entries, int6
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 
+/* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
+ * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
+ * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and
+ * the multi-scale pixel mean (tsd_full.py:448-478).  One sample per call (pixel_coords [ncam, n, 2] f32 in [-1, 1],
+ * mask [ncam, n] bytes); the outputs feed u2mkd_devoxelize_forward (4 weighted corners per point) and u2mkd_csr_build /
+ * u2mkd_segment_sum (entries grouped by pixel and by point).
+ *   u2mkd_c2l_plan   idx8 / w8 [n, 8]: the bilinear corners (align_corners, zero padding) of every point in the [h, w]
+ *                    map of the LAST camera that sees it, as rows (sample * ncam + cam) * h * w + y * w + x; -1 / 0 else
+ *   u2mkd_l2c_keys   entry e0 + cam * n + i: pix = its pixel of a [ch, cw] grid, key_d = pix or -1 (not seen),
+ *                    key_s = row0 + i or -1 (may be NULL), row = row0 + i (may be NULL)
+ *   u2mkd_l2c_finish the forward list (by pixel: source row, 1 / points in the pixel) and the backward list (by point:
+ *                    pixel, the same weight) from the two grouped orders of u2mkd_csr_build                          */
+int u2mkd_c2l_plan(const float *pixel_coords, const uint8_t *mask, int32_t ncam, int64_t n, int32_t sample, int32_t h,
+                   int32_t w, int32_t *idx8 /*[n,8]*/, float *w8 /*[n,8]*/, u2mkd_stream_t s);
+int u2mkd_l2c_keys(const float *pixel_coords, const uint8_t *mask, int32_t ncam, int64_t n, int32_t sample, int64_t row0,
+                   int64_t e0, int32_t ch, int32_t cw, int32_t *pix, int32_t *key_d, int32_t *key_s, int32_t *row,
+                   u2mkd_stream_t s);
+int u2mkd_l2c_finish(const int32_t *order_d, const int32_t *seg_d, const int32_t *order_s, const int32_t *pix,
+                     const int32_t *row, int64_t n_entries, int32_t *fwd_row, float *fwd_w, int32_t *bwd_pix, float *bwd_w,
+                     u2mkd_stream_t s);
+
 /* ---- BatchNorm over feature rows (+ fused ReLU) ------------------------------
  * replaces spnn.BatchNorm + spnn.ReLU (nn.BatchNorm1d / nn.ReLU over SparseTensor.feats,
  * core/models/build_blocks.py:30-31,48-49,64-65,71,77).  Same statistics as

@@ -1,0 +1,49 @@
+"""The point <-> pixel index plans of csrc/fusion.hip (u2mkd_c2l_plan, u2mkd_l2c_keys / u2mkd_csr_build /
+u2mkd_l2c_finish) against the torch formulation they replace (fusion._c2l_plan_torch / _l2c_plan_torch, which the
+host-side tests pin against the reference's Python loops, spvcnn_swiftnet18_spformer_tsd_full.py:448-495): indices
+bit-exact, weights bit-exact (the kernels repeat the fp32 operations one for one), for one and two samples, every grid
+size the four fusion stages use, incl. points no camera sees and coordinates on / outside the image border."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(n_list, ncam=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pcs, masks = [], []
+    for n in n_list:
+        pc = torch.rand(ncam, n, 2, generator=g) * 2.4 - 1.2           # some outside (-1, 1)
+        pc[0, :7] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0], [1.0, -1.0], [0.999999, 0.5], [-1.0, 0.25], [0.3, 1.0]])
+        m = (pc.abs().max(-1).values < 1.0) & (torch.rand(ncam, n, generator=g) < 0.35)
+        m[:, -5:] = False                                               # points no camera sees
+        pcs.append(pc.cuda())
+        masks.append(m.cuda())
+    return pcs, masks
+
+
+@pytest.mark.parametrize('n_list', [[4000], [3000, 1777]])
+@pytest.mark.parametrize('hw', [(180, 320), (90, 160), (45, 80), (23, 40), (360, 640)])
+def test_c2l_plan_equals_the_torch_formulation(hip, n_list, hw):
+    from u2mkd_amd import fusion
+    pcs, masks = _batch(n_list, seed=hw[0])
+    i_t, w_t = fusion._c2l_plan_torch(pcs, masks, *hw)
+    i_h, w_h = fusion._c2l_plan(pcs, masks, *hw)
+    assert torch.equal(i_h, i_t)
+    assert torch.equal(w_h, w_t)
+
+
+@pytest.mark.parametrize('n_list', [[4000], [3000, 1777]])
+@pytest.mark.parametrize('hw', [(180, 320), (90, 160), (45, 80), (23, 40), (12, 20)])
+def test_l2c_plan_equals_the_torch_formulation(hip, n_list, hw):
+    from u2mkd_amd import fusion
+    pcs, masks = _batch(n_list, seed=hw[1])
+    (fr_t, fw_t, sd_t), (bp_t, bw_t, ss_t), nd_t = fusion._l2c_plan_torch(pcs, masks, *hw)
+    pcs2, masks2 = [p.clone() for p in pcs], [m.clone() for m in masks]          # (plans are cached on masks[0])
+    for _ in range(2):                                                            # second call: the cached by-source grouping
+        (fr_h, fw_h, sd_h), (bp_h, bw_h, ss_h), nd_h = fusion._l2c_plan(pcs2, masks2, *hw)
+        assert nd_h == nd_t and torch.equal(sd_h, sd_t) and torch.equal(ss_h, ss_t)
+        live_d, live_s = int(sd_t[-1]), int(ss_t[-1])
+        assert live_d == live_s == int(sum(int(m.sum()) for m in masks))
+        assert torch.equal(fr_h[:live_d], fr_t[:live_d]) and torch.equal(fw_h[:live_d], fw_t[:live_d])
+        assert torch.equal(bp_h[:live_s], bp_t[:live_s]) and torch.equal(bw_h[:live_s], bw_t[:live_s])

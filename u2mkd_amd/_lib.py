@@ -123,6 +123,9 @@ SIGNATURES = {
     'u2mkd_voxelize_backward_bf16': (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     'u2mkd_devoxelize_forward_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_segment_sum_bf16': (C.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_c2l_plan': (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    'u2mkd_l2c_keys': (C.c_int, [_p, _p, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_l2c_finish': (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     'u2mkd_csr_workspace_bytes': (_sz, [_i64, _i64]),
     'u2mkd_csr_build': (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p]),
     'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),

@@ -147,10 +147,11 @@ class _NchwToRows(torch.autograd.Function):
         return g.view(B, ncam, h, w, C).permute(0, 1, 4, 2, 3).contiguous()
 
 
-def _c2l_plan(pixel_coordinates, masks, h, w):
+def _c2l_plan_torch(pixel_coordinates, masks, h, w):
     """idx int32 [N, 8] / weights f32 [N, 8]: the 4 bilinear corners (align_corners=True, zero
     padding; slots 4..7 unused) of every point in the feature map of the LAST camera seeing it,
-    as rows of the [B*ncam*h*w, C] channel-last feature matrix."""
+    as rows of the [B*ncam*h*w, C] channel-last feature matrix.  (The torch formulation: what the HIP plan
+    kernel is held against, bit for bit, in tests/test_gpu_fusion_plans.py.)"""
     ncam = masks[0].shape[0]
     idx, wts = [], []
     for b, (coord, mask) in enumerate(zip(pixel_coordinates, masks)):
@@ -173,6 +174,27 @@ def _c2l_plan(pixel_coordinates, masks, h, w):
         idx.append(torch.stack(ii + [pad_i] * 4, 1))
         wts.append(torch.stack(ww + [pad_w] * 4, 1))
     return torch.cat(idx, 0).int().contiguous(), torch.cat(wts, 0).float().contiguous()
+
+
+def _mask_bytes(m):
+    return m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous().to(torch.uint8)
+
+
+def _c2l_plan(pixel_coordinates, masks, h, w):
+    """The same plan from ONE launch per sample (csrc/fusion.hip, u2mkd_c2l_plan)."""
+    from . import _lib as L
+    ncam = masks[0].shape[0]
+    n_tot = sum(m.shape[1] for m in masks)
+    dev = masks[0].device
+    idx8 = torch.empty(n_tot, 8, dtype=torch.int32, device=dev)
+    w8 = torch.empty(n_tot, 8, dtype=torch.float32, device=dev)
+    cur = 0
+    for b, (coord, mask) in enumerate(zip(pixel_coordinates, masks)):
+        n = mask.shape[1]
+        pc, mb = coord.contiguous().float(), _mask_bytes(mask)
+        L.call('u2mkd_c2l_plan', L.ptr(pc), L.ptr(mb), ncam, n, b, h, w, L.ptr(idx8[cur:]), L.ptr(w8[cur:]), L.stream())
+        cur += n
+    return idx8, w8
 
 
 def c2l_gather(feature_maps, pixel_coordinates, masks):
@@ -243,8 +265,9 @@ def _flat_entries(pixel_coordinates, masks):
     return coords, mask, torch.cat(slot), torch.cat(row), cur
 
 
-def _l2c_plan(pixel_coordinates, masks, ch, cw):
-    """Both CSR forms of the (camera pixel <- point) pixel-mean map of one grid size."""
+def _l2c_plan_torch(pixel_coordinates, masks, ch, cw):
+    """Both CSR forms of the (camera pixel <- point) pixel-mean map of one grid size.  (The torch formulation: what
+    the HIP plan is held against in tests/test_gpu_fusion_plans.py.)"""
     from .torchsparse.nn import functional as spf
     coords, mask, slot, row, n_pts = _flat_entries(pixel_coordinates, masks)
     u = torch.floor((coords[:, 0] + 1.0) / 2 * (cw - 1.0)).long().clamp(0, cw - 1)
@@ -256,15 +279,54 @@ def _l2c_plan(pixel_coordinates, masks, ch, cw):
     w = 1.0 / num[pix]
     order_d, seg_d = spf._csr_by_destination(key_d, n_dst)
     od = order_d.long()
-    # grouping by source point does not depend on the grid: one sort per batch, shared by all scales
-    def by_source():
-        key_s = torch.where(mask, row, torch.full_like(row, -1)).int()
-        order_s, seg_s = spf._csr_by_destination(key_s, n_pts)
-        return order_s.long(), seg_s
-    os_, seg_s = spf._plan(masks[0], 'l2c_by_source', by_source, *masks[1:])
+    key_s = torch.where(mask, row, torch.full_like(row, -1)).int()
+    order_s, seg_s = spf._csr_by_destination(key_s, n_pts)
+    os_ = order_s.long()
     fwd = (row[od].int().contiguous(), w[od].contiguous(), seg_d)
     bwd = (pix[os_].int().contiguous(), w[os_].contiguous(), seg_s)
     return fwd, bwd, n_dst
+
+
+def _l2c_plan(pixel_coordinates, masks, ch, cw):
+    """The same two lists from csrc/fusion.hip: one key launch per sample, u2mkd_csr_build by pixel (and, once per batch,
+    by point: the grouping by source does not depend on the grid), one finishing launch."""
+    from . import _lib as L
+    from .torchsparse.nn import functional as spf
+    ncam = masks[0].shape[0]
+    dev = masks[0].device
+    n_pts = sum(m.shape[1] for m in masks)
+    e = ncam * n_pts
+    n_dst = len(masks) * ncam * ch * cw
+    pix = torch.empty(e, dtype=torch.int32, device=dev)
+    key_d = torch.empty_like(pix)
+    row = torch.empty_like(pix)
+
+    def keys(key_s):
+        row0 = e0 = 0
+        for b, (coord, mask) in enumerate(zip(pixel_coordinates, masks)):
+            n = mask.shape[1]
+            pc, mb = coord.contiguous().float(), _mask_bytes(mask)
+            L.call('u2mkd_l2c_keys', L.ptr(pc), L.ptr(mb), ncam, n, b, row0, e0, ch, cw, L.ptr(pix), L.ptr(key_d),
+                   L.ptr(key_s), L.ptr(row), L.stream())
+            row0 += n
+            e0 += ncam * n
+
+    def by_source():
+        key_s = torch.empty_like(pix)
+        keys(key_s)
+        return spf._csr_by_destination(key_s, n_pts) + (True,)
+    hit = masks[0].__dict__.get('_u2mkd_plans', {}).get('l2c_by_source')
+    order_s, seg_s, fresh = spf._plan(masks[0], 'l2c_by_source', by_source, *masks[1:])
+    if hit is not None or not fresh:
+        keys(None)
+    masks[0].__dict__['_u2mkd_plans']['l2c_by_source'] = (masks[0].__dict__['_u2mkd_plans']['l2c_by_source'][0], (order_s, seg_s, False))
+    order_d, seg_d = spf._csr_by_destination(key_d, n_dst)
+    fwd_row, bwd_pix = torch.empty_like(pix), torch.empty_like(pix)
+    fwd_w = torch.empty(e, dtype=torch.float32, device=dev)
+    bwd_w = torch.empty_like(fwd_w)
+    L.call('u2mkd_l2c_finish', L.ptr(order_d), L.ptr(seg_d), L.ptr(order_s), L.ptr(pix), L.ptr(row), e, L.ptr(fwd_row),
+           L.ptr(fwd_w), L.ptr(bwd_pix), L.ptr(bwd_w), L.stream())
+    return (fwd_row, fwd_w, seg_d), (bwd_pix, bwd_w, seg_s), n_dst
 
 
 def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
