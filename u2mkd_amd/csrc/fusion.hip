@@ -20,6 +20,7 @@ constexpr int kFuThreads = 256;
 __global__ void __launch_bounds__(kFuThreads)
 c2l_plan_kernel(const float *__restrict__ pc /*[ncam,n,2]*/, const uint8_t *__restrict__ mask /*[ncam,n]*/, int ncam,
                 int64_t n, int sample, int h, int w, int32_t *__restrict__ idx8, float *__restrict__ w8) {
+#pragma clang fp contract(off)      // hipcc contracts a * b - c into one fma by default: the torch ops round after each step
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cam = -1;
@@ -59,6 +60,7 @@ __global__ void __launch_bounds__(kFuThreads)
 l2c_keys_kernel(const float *__restrict__ pc, const uint8_t *__restrict__ mask, int ncam, int64_t n, int sample,
                 int64_t row0, int64_t e0, int ch, int cw, int32_t *__restrict__ pix, int32_t *__restrict__ key_d,
                 int32_t *__restrict__ key_s /*or null*/, int32_t *__restrict__ row /*or null*/) {
+#pragma clang fp contract(off)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)ncam * n) return;
     const int cam = (int)(t / n);
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(kFuThreads)
 l2c_finish_kernel(const int32_t *__restrict__ order_d, const int32_t *__restrict__ seg_d, const int32_t *__restrict__ order_s,
                   const int32_t *__restrict__ pix, const int32_t *__restrict__ row, int64_t e, int32_t *__restrict__ fwd_row,
                   float *__restrict__ fwd_w, int32_t *__restrict__ bwd_pix, float *__restrict__ bwd_w) {
+#pragma clang fp contract(off)
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= e) return;
     {
