@@ -20,7 +20,8 @@ constexpr int kFuThreads = 256;
 __global__ void __launch_bounds__(kFuThreads)
 c2l_plan_kernel(const float *__restrict__ pc /*[ncam,n,2]*/, const uint8_t *__restrict__ mask /*[ncam,n]*/, int ncam,
                 int64_t n, int sample, int h, int w, int32_t *__restrict__ idx8, float *__restrict__ w8) {
-#pragma clang fp contract(off)      // hipcc contracts a * b - c into one fma by default: the torch ops round after each step
+#pragma clang fp contract(off)      // hipcc contracts a * b - c into one fma by default (also through the __f*_rn
+                                    // helpers, which are plain operators in a header): the torch ops round after each step
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cam = -1;
@@ -30,24 +31,24 @@ c2l_plan_kernel(const float *__restrict__ pc /*[ncam,n,2]*/, const uint8_t *__re
     if (cam < 0) cam = 0;
     const float cx = pc[((int64_t)cam * n + i) * 2], cy = pc[((int64_t)cam * n + i) * 2 + 1];
     // x = (cx + 1.0) * 0.5 * (w - 1)
-    const float x = __fmul_rn(__fmul_rn(__fadd_rn(cx, 1.0f), 0.5f), (float)(w - 1));
-    const float y = __fmul_rn(__fmul_rn(__fadd_rn(cy, 1.0f), 0.5f), (float)(h - 1));
+    const float x = ((cx + 1.0f) * 0.5f) * (float)(w - 1);
+    const float y = ((cy + 1.0f) * 0.5f) * (float)(h - 1);
     const float x0 = floorf(x), y0 = floorf(y);
-    const float fx = __fsub_rn(x, x0), fy = __fsub_rn(y, y0);
+    const float fx = x - x0, fy = y - y0;
     const int64_t base = ((int64_t)sample * ncam + cam) * ((int64_t)h * w);
     int32_t *oi = idx8 + i * 8;
     float *ow = w8 + i * 8;
     int s = 0;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        const float wy = dy ? fy : __fsub_rn(1.0f, fy);
+        const float wy = dy ? fy : 1.0f - fy;
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx, ++s) {
-            const float wx = dx ? fx : __fsub_rn(1.0f, fx);
+            const float wx = dx ? fx : 1.0f - fx;
             const long long xi = (long long)x0 + dx, yi = (long long)y0 + dy;
             const bool ok = seen && xi >= 0 && xi < w && yi >= 0 && yi < h;
             oi[s] = ok ? (int32_t)(base + yi * w + xi) : -1;
-            ow[s] = ok ? __fmul_rn(wx, wy) : 0.f;
+            ow[s] = ok ? wx * wy : 0.f;
         }
     }
 #pragma unroll
@@ -67,8 +68,8 @@ l2c_keys_kernel(const float *__restrict__ pc, const uint8_t *__restrict__ mask, 
     const int64_t i = t - (int64_t)cam * n;
     const float cx = pc[t * 2], cy = pc[t * 2 + 1];
     // u = floor((cx + 1.0) / 2 * (cw - 1.0)).long().clamp(0, cw - 1)
-    float fu = floorf(__fmul_rn(__fdiv_rn(__fadd_rn(cx, 1.0f), 2.0f), __fsub_rn((float)cw, 1.0f)));
-    float fv = floorf(__fmul_rn(__fdiv_rn(__fadd_rn(cy, 1.0f), 2.0f), __fsub_rn((float)ch, 1.0f)));
+    float fu = floorf(((cx + 1.0f) / 2.0f) * ((float)cw - 1.0f));
+    float fv = floorf(((cy + 1.0f) / 2.0f) * ((float)ch - 1.0f));
     // (float -> int64 of an out-of-range or NaN value is undefined in torch as well; the mask drops such entries)
     long long u = (fu >= -9.0e18f && fu <= 9.0e18f) ? (long long)fu : 0, v = (fv >= -9.0e18f && fv <= 9.0e18f) ? (long long)fv : 0;
     u = u < 0 ? 0 : (u > cw - 1 ? cw - 1 : u);
@@ -95,14 +96,14 @@ l2c_finish_kernel(const int32_t *__restrict__ order_d, const int32_t *__restrict
         int cnt = seg_d[px + 1] - seg_d[px];
         cnt = cnt < 1 ? 1 : cnt;
         fwd_row[p] = row[ed];
-        fwd_w[p] = __fdiv_rn(1.0f, (float)cnt);
+        fwd_w[p] = 1.0f / (float)cnt;
     }
     {
         const int es = order_s[p], px = pix[es];
         int cnt = seg_d[px + 1] - seg_d[px];
         cnt = cnt < 1 ? 1 : cnt;
         bwd_pix[p] = px;
-        bwd_w[p] = __fdiv_rn(1.0f, (float)cnt);
+        bwd_w[p] = 1.0f / (float)cnt;
     }
 }
 
