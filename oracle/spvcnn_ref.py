@@ -227,11 +227,14 @@ def mix_lovasz_cross_entropy(x, y, ignore_index=0):  # criterions.py:159-174 + f
     return lov + ce
 
 
-def fill_state_by_name(model, seed=0):
+def fill_state_by_name(model, seed=0, conv2d_he=False):
     """Deterministic, construction-order-independent parameter fill: every
     tensor of the state dict is drawn from a generator seeded by its KEY, so
     the reference class, this restatement and the HIP model get identical
-    weights without shipping a checkpoint."""
+    weights without shipping a checkpoint.  ``conv2d_he``: the camera branch's Conv2d (4-D) and the fusion blocks' Conv1d (3-D) weights get a zero-mean
+    He-scaled fill instead of the positive BatchNorm-gamma fill they share by default -- needed when BatchNorm runs on
+    its running statistics (eval mode): an all-positive 3x3xC filter multiplies the scale by ~9C per layer, which
+    batch statistics undo and running statistics do not."""
     import zlib
     sd = model.state_dict()
     out = {}
@@ -246,6 +249,8 @@ def fill_state_by_name(model, seed=0):
         elif key.endswith('.kernel'):
             fan = t.shape[-2] * (t.shape[0] if t.dim() == 3 else 1)
             out[key] = torch.randn(t.shape, generator=g) * (2.0 / fan) ** 0.5
+        elif t.dim() in (3, 4) and conv2d_he:  # Conv2d weight [out, in, kh, kw] / Conv1d weight [out, in, k]
+            out[key] = torch.randn(t.shape, generator=g) * (2.0 / t[0].numel()) ** 0.5
         elif t.dim() == 2:  # nn.Linear weight [out, in]
             out[key] = torch.randn(t.shape, generator=g) * (1.0 / t.shape[1]) ** 0.5
         elif key.endswith('weight'):  # BN gamma

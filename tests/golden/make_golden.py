@@ -130,8 +130,36 @@ def main():
         grad_qkv=grads[blk + 'qkv.weight'].numpy())
     with open(os.path.join(HERE, 'spformer_cr10_keys.json'), 'w') as f:
         json.dump({k: list(v.shape) for k, v in ref.state_dict().items()}, f, indent=0)
-    make_kd_golden(crit)
+    make_kd_golden(crit, seeds=FIRST_KD_SEEDS)
     print('golden written:', float(loss), float(l2), float(loss3))
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def shifted_quantisers(k):
+    """SphereFormer's hard quantisers fed with inputs moved k units in the last place: cart2sphere's two atan2-derived
+    angles and the logarithm exponential_split floors (the CPU and GPU libm differ there).  A scene whose outputs
+    survive +-4 holds no token within 4 ulp of a window / relative-position bin edge, so its fixture can be held to the
+    north-star 1e-3 without exception."""
+    import core.models.sphereformer.spherical_transformer as ST
+    from oracle import sptr_ref
+    real_c2s, real_split = ST.cart2sphere, ST.exponential_split
+
+    def c2s(xyz):
+        o = real_c2s(xyz)
+        ang = o[:, :2]
+        for _ in range(abs(k)):
+            ang = torch.nextafter(ang, torch.full_like(ang, float('inf') if k > 0 else -float('inf')))
+        return torch.cat([ang, o[:, 2:]], 1)
+    if k:
+        ST.cart2sphere = c2s
+        ST.exponential_split = lambda xyz, i0, i1, rpi, a=0.05 * 0.25: sptr_ref.exponential_split(xyz, i0, i1, rpi, a, _log_ulps=k)
+    try:
+        yield
+    finally:
+        ST.cart2sphere, ST.exponential_split = real_c2s, real_split
 
 
 def kd_inputs(b):
@@ -146,7 +174,12 @@ def kd_inputs(b):
     return stu, tea
 
 
-def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True):
+# candidate scenes of the first KD fixture: seeds on which tools/diag_kd_seed.py (GPU box) saw the HIP model give the
+# same outputs with the spherical angles from either libm; the +-4 ulp margin is asserted below on the CPU
+FIRST_KD_SEEDS = (78, 79, 80, 82, 85, 86)
+
+
+def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True, seeds=(77,)):
     """The reference's own SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL (student + teacher) and the KD loss
     arithmetic of NuScenesLCTSDFullTrainer._run_step, on CPU over the oracle operators.  (cr, cr_t) =
     (1.0, 1.0): the first fixture; (1.0, 2.0) = configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:32-43
@@ -166,7 +199,25 @@ def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write
     model = O.fill_state_by_name(SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL(**kw)).train()
     model.model_t.eval()
     model.model_s.dropout.p = 0.0
-    b = synth_kd_batch(n_vox, 2, seed=77, image_hw=(64, 112))
+    # fixture scene: the first candidate seed whose student / teacher outputs do not move when the quantiser inputs
+    # move by +-4 ulp (one candidate = the seed is taken as it is: the round-2 fixtures at the shipped widths, which
+    # hold the strict gate on the GPU)
+    for seed in seeds:
+        b = synth_kd_batch(n_vox, 2, seed=seed, image_hw=(64, 112))
+        if len(seeds) == 1:
+            break
+
+        def probe(k):
+            with torch.no_grad(), shifted_quantisers(k):
+                o = model({'student': kd_inputs(b)[0], 'teacher': kd_inputs(b)[1]})
+            return [o['stu']['x_vox'].clone(), o['stu']['pts_feats'][0].clone(), o['t']['x_vox'].clone()]
+        base = probe(0)
+        worst = max(float((x - y).abs().max()) for k in (4, -4) for x, y in zip(probe(k), base))
+        print(tag, 'seed', seed, 'output change under +-4 ulp of the quantiser inputs: %.3g' % worst, flush=True)
+        if worst < 1e-4:
+            break
+    else:
+        raise SystemExit('no candidate seed keeps every token 4 ulp away from the quantiser edges')
     stu, tea = kd_inputs(b)
     out = model({'student': stu, 'teacher': tea})
     s, t = b['student'], b['teacher']
@@ -192,7 +243,7 @@ def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write
     total.backward()
     g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     np.savez_compressed(
-        os.path.join(HERE, tag + '.npz'),
+        os.path.join(HERE, tag + '.npz'), seed=np.int64(seed),
         x_vox=x_vox.detach().numpy(), x_pix=x_pix.detach().numpy(), x_vox_t=out['t']['x_vox'].numpy(),
         mse=np.array([float(m) for m in out['stu']['mse_loss']], dtype=np.float32),
         pts_feats_s=out['stu']['pts_feats'][0].detach().numpy()[::16],
@@ -221,21 +272,6 @@ def make_teacher_multisweep_golden():
     kw = default_spformer_kwargs(cr=cr, drop_path_rate=0.0)
     for k in ('cr', 'in_channel', 'num_classes'):
         kw.pop(k)
-    import core.models.sphereformer.spherical_transformer as ST
-    real_c2s, real_split = ST.cart2sphere, ST.exponential_split
-
-    def shifted(k):
-        """cart2sphere with its two atan2-derived angles moved k units in the last place (the CPU and GPU libm differ
-        there): a scene whose logits survive +-4 holds no token within 4 ulp of an edge of SphereFormer's hard window /
-        relative-position quantisers, so the fixture can be held to the north-star 1e-3 without exception"""
-        def f(xyz):
-            o = real_c2s(xyz)
-            ang = o[:, :2]
-            for _ in range(abs(k)):
-                ang = torch.nextafter(ang, torch.full_like(ang, float('inf') if k > 0 else -float('inf')))
-            return torch.cat([ang, o[:, 2:]], 1)
-        return f
-
     def forward(seed, k=0):
         import gc
         gc.collect()
@@ -247,14 +283,8 @@ def make_teacher_multisweep_golden():
         # quant_size_sphere / window_size_sphere arguments in place
         ref = O.fill_state_by_name(SPF(**copy.deepcopy(kw))).train()
         ref.dropout.p = 0.0
-        ST.cart2sphere = shifted(k) if k else real_c2s
-        if k:      # the radial bins of exponential_split floor a logarithm: same libm dependence, same probe
-            from oracle import sptr_ref
-            ST.exponential_split = lambda xyz, i0, i1, rpi, a=0.05 * 0.25: sptr_ref.exponential_split(xyz, i0, i1, rpi, a, _log_ulps=k)
-        try:
+        with shifted_quantisers(k):
             out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
-        finally:
-            ST.cart2sphere, ST.exponential_split = real_c2s, real_split
         return ref, out, labels, kf
 
     for seed in (58, 61, 62, 63, 64, 65, 66):      # (seeds on which tools/diag_ms_golden.py saw the HIP model and the oracle agree to 5e-5 on the GPU box)
@@ -280,6 +310,55 @@ def make_teacher_multisweep_golden():
     print('teacher multi-sweep golden: loss', float(loss), 'key-frame voxels', int(kf.sum()), 'of', len(kf))
 
 
+
+
+def make_kd_eval_golden():
+    """Rows f2 of SURVEY.md 8f: the reference's own KD model class in eval mode (BatchNorm running statistics,
+    `debug_val` = the teacher evaluated as well) on the scene of the first KD fixture, and the arithmetic of the eval
+    branch of NuScenesLCTSDFullTrainer._run_step (core/nusc_trainers.py:367-418): per-point predictions of the voxel
+    head, the pixel head and the teacher.  Stored: the three logit matrices and the three prediction vectors."""
+    from u2mkd_amd.synth import synth_kd_batch, synth_eval_feed as eval_feed
+    from oracle.spformer_ref import default_spformer_kwargs
+    import_reference()
+    import_reference_spformer(1.0)
+    cfg = sys.modules['torchpack.utils.config'].configs
+    cfg['model'].update({'cr': 1.0, 'cr_t': 1.0, 'in_channel': 4, 'in_channel_t': 4, 'imagenet_pretrain': None})
+    cfg['eval'] = {'run_pix_decoder': True, 'run_align_loss': True}
+    cfg['debug'] = {'debug_val': True}
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from core.models.nuscenes.spvcnn_swiftnet18_spformer_tsd_full import SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL
+    kw = default_spformer_kwargs(drop_path_rate=0.0)
+    for k in ('cr', 'in_channel', 'num_classes'):
+        kw.pop(k)
+    model = O.fill_state_by_name(SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL(**kw), conv2d_he=True).eval()
+    seed = int(np.load(os.path.join(HERE, 'kd_cr10_3000.npz'))['seed'])       # a scene off the quantiser edges
+    b = synth_kd_batch(1500, 2, seed=seed, image_hw=(64, 112))
+    # the loader's image normalisation (lc_semantic_nusc_tsd_full.py: /255, ImageNet mean / std); with running
+    # statistics instead of batch statistics the raw 0..255 range overflows fp32 in the randomly initialised ResNet
+    b['student']['images'] = ((b['student']['images'] / 255.0 - 0.45) / 0.225).astype(np.float32)
+    stu, tea = kd_inputs(b)
+    with torch.no_grad():
+        outputs = model({'student': stu, 'teacher': tea})
+    for k in ('x_vox', 'x_pix'):
+        assert bool(torch.isfinite(outputs['stu'][k]).all()), k
+    f = eval_feed(b, seed)
+    s_c, t_c = stu['lidar'].C, tea['lidar'].C
+    inv_t = b['teacher']['inverse_map']
+    o_vox, o_pix, o_t = [], [], []
+    for idx in range(int(f['s_inverse_batch'].max()) + 1):                      # nusc_trainers.py:375-388, 400-409
+        cur_scene_pts = (s_c[:, -1] == idx).numpy()
+        cur_inv = f['s_inverse_map'][f['s_inverse_batch'] == idx]
+        o_vox.append(outputs['stu']['x_vox'][cur_scene_pts][cur_inv].argmax(1))
+        o_pix.append(outputs['stu']['x_pix'][cur_scene_pts][cur_inv].argmax(1))
+        cur_scene_pts = (t_c[:, -1] == idx).numpy()
+        cur_inv = inv_t[f['t_inverse_batch'] == idx]
+        o_t.append(outputs['t']['x_vox'][cur_scene_pts][cur_inv].argmax(1))
+    np.savez_compressed(
+        os.path.join(HERE, 'kd_eval_cr10_3000.npz'), seed=np.int64(seed),
+        x_vox=outputs['stu']['x_vox'].numpy(), x_pix=outputs['stu']['x_pix'].numpy(), x_vox_t=outputs['t']['x_vox'].numpy(),
+        outputs_vox=torch.cat(o_vox).numpy(), outputs_pix=torch.cat(o_pix).numpy(), outputs_vox_t=torch.cat(o_t).numpy())
+    print('kd eval golden: points', len(f['s_inverse_map']), 'teacher points', len(inv_t))
+
 def main_kd_widths():
     """Only the KD fixtures at the shipped widths (`python tests/golden/make_golden.py kd`)."""
     _, MixLovaszCrossEntropy = import_reference()
@@ -292,9 +371,16 @@ def main_kd_widths():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'kd':
         main_kd_widths()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'kd_first':
+        _, _Crit = import_reference()
+        import_reference_spformer(1.0)
+        make_kd_golden(_Crit(ignore_index=0), seeds=FIRST_KD_SEEDS)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'kd_eval':
+        make_kd_eval_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'teacher_ms':
         make_teacher_multisweep_golden()
     else:
         main()
         main_kd_widths()
         make_teacher_multisweep_golden()
+        make_kd_eval_golden()

@@ -1,0 +1,106 @@
+"""fp64 arbiter for parameter gradients of the piecewise-smooth networks (test helper).
+
+The CPU oracle evaluated in fp64 is the truth; the HIP model's gradient of every conv kernel must be within 1e-3
+(L2-relative) of it.  The only event that can break this on a correct path is a ReLU whose fp64
+pre-activation is within fp32 rounding of zero: the HIP evaluation (another summation order) lands on the other side,
+and that one mask element carries a visible share of a layer's gradient.  So both runs record every ReLU: the oracle
+its fp64 pre-activations, the HIP model its post-activation masks.  A scene that misses the strict bound must come with
+the flipped elements BY NAME (module, row, channel, fp64 pre-activation) -- a miss without a flip is a wrong kernel and
+fails."""
+import numpy as np
+import torch
+
+from oracle import torchsparse_cpu as ots
+
+
+def _feats(x):
+    return x.F if hasattr(x, 'F') else x
+
+
+def record_oracle_relus(model):
+    """fp64 (or fp32) oracle model: {relu module name: pre-activation [N, C] float32 copy}; returns (records, remove)."""
+    rec, handles = {}, []
+    for name, m in model.named_modules():
+        if isinstance(m, (torch.nn.ReLU, ots.nn.ReLU)):
+            def pre(mod, args, name=name):
+                rec[name] = _feats(args[0]).detach().to(torch.float32).clone()      # in-place ReLU: copy first
+            handles.append(m.register_forward_pre_hook(pre))
+    return rec, lambda: [h.remove() for h in handles]
+
+
+def record_hip_relus(model, monkeypatch):
+    """HIP model: {relu module name: mask [N, C] bool (CPU)} for every ReLU, fused into a BatchNorm pass or not."""
+    from u2mkd_amd.torchsparse import nn as spnn
+    from u2mkd_amd.torchsparse.nn import functional as spf
+    rec = {}
+    names = {id(m): n for n, m in model.named_modules()}
+    real_bn = spf.batch_norm
+
+    def bn(x, m, relu=False, residual=None):
+        y = real_bn(x, m, relu, residual)
+        if relu:
+            n = names[id(m)]
+            parent, _, idx = n.rpartition('.')
+            # BatchNorm -> ReLU fused: the ReLU is the next entry of the Sequential; the tail of a ResidualBlock
+            # (last BatchNorm of `net` + the block's `relu`): build_blocks.py:80-83
+            key = (parent.rpartition('.')[0] + '.relu') if residual is not None else '%s.%d' % (parent, int(idx) + 1)
+            rec[key] = (y.detach() > 0).cpu()
+        return y
+    monkeypatch.setattr(spf, 'batch_norm', bn)
+    for n, m in model.named_modules():
+        if isinstance(m, (torch.nn.ReLU, spnn.ReLU)):
+            def post(mod, args, out, n=n):
+                rec[n] = (_feats(out).detach() > 0).cpu()
+            m.register_forward_hook(post)
+    return rec
+
+
+def flipped_relu_elements(rec64, rec_hip, limit=8):
+    """[(module, row, channel, fp64 pre-activation)] where the HIP mask differs from the sign of the fp64 value,
+    smallest |pre-activation| first."""
+    assert set(rec64) == set(rec_hip), sorted(set(rec64) ^ set(rec_hip))
+    out = []
+    for name, x in rec64.items():
+        m = rec_hip[name]
+        assert m.shape == x.shape, (name, m.shape, x.shape)
+        d = (x > 0) != m
+        for r, c in d.nonzero().tolist():
+            out.append((name, r, c, float(x[r, c])))
+    out.sort(key=lambda t: abs(t[3]))
+    return out[:limit], len(out)
+
+
+def kernel_grad_errors(mg, m64, m32):
+    g64, g32 = dict(m64.named_parameters()), dict(m32.named_parameters())
+    names, hip_err, cpu_err = [], [], []
+    for name, p in mg.named_parameters():
+        if not name.endswith('kernel'):
+            continue
+        r = g64[name].grad
+        names.append(name)
+        hip_err.append(float((p.grad.cpu().double() - r).norm() / r.norm()))
+        cpu_err.append(float((g32[name].grad.double() - r).norm() / r.norm()))
+    return names, np.array(hip_err), np.array(cpu_err)
+
+
+def assert_grads_within_fp64_gate(label, mg, m64, m32, rec64, rec_hip):
+    """Strict: every conv kernel's HIP gradient within 1e-3 of fp64 (median 5e-4, and within 4x of what the CPU-fp32
+    reference arithmetic itself achieves).  Otherwise the flipped ReLU elements are named and must exist; the distance
+    then still has to stay in the range of a flip (2e-2)."""
+    names, hip_err, cpu_err = kernel_grad_errors(mg, m64, m32)
+    worst = names[int(hip_err.argmax())]
+    print('GRAD-FP64 %s kernels %d: HIP vs fp64 median %.2e max %.2e (%s) | CPU-fp32 vs fp64 median %.2e max %.2e'
+          % (label, len(names), np.median(hip_err), hip_err.max(), worst, np.median(cpu_err), cpu_err.max()))
+    strict = bool(hip_err.max() < 1e-3 and np.median(hip_err) < 5e-4
+                  and np.all(hip_err <= 4.0 * np.maximum(cpu_err, 2.5e-4)))
+    if strict:
+        return True
+    flips, n = flipped_relu_elements(rec64, rec_hip)
+    msg = ('%s: HIP gradient of %s is %.2e from fp64 (gate 1e-3); %d ReLU element(s) on the other side of zero than '
+           'in fp64: %s' % (label, worst, hip_err.max(), n,
+                            '; '.join('%s[%d,%d] fp64 pre-activation %.2e' % f for f in flips)))
+    print('GRAD-FP64-FLIP', msg)
+    assert n > 0, msg + ' -- no flipped ReLU explains the distance: a kernel is wrong'
+    assert min(abs(f[3]) for f in flips) < 1e-5, msg + ' -- the differing masks are not rounding-sized'
+    assert hip_err.max() < 2e-2, msg
+    return False

@@ -12,109 +12,76 @@ from u2mkd_amd.synth import synth_batch
 pytestmark = pytest.mark.gpu
 
 
-def _run_pair(n_vox, batch, cr, seed=11):
+def _run_three(n_vox, batch, cr, seed, monkeypatch):
+    """The same network, state dict and cloud three times: CPU oracle in fp64 (the arbiter), CPU oracle in fp32 (the
+    reference arithmetic: logits / loss are compared with it) and the HIP model; every ReLU recorded on the arbiter
+    and on the HIP run (tests/grad_arbiter.py)."""
+    import grad_arbiter as GA
     from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
     b = synth_batch(n_vox, batch, seed)
     feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
     kw = dict(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)
-    ref = O.fill_state_by_name(O.SPVCNN(**kw))
-    ref.train()
-    ref.dropout.p = 0.0            # random masks differ across implementations (SURVEY §8d "Weights")
-    out_ref = ref({'lidar': ots.SparseTensor(feats, coords)})['x_vox']
-    loss_ref = O.mix_lovasz_cross_entropy(out_ref, labels)
-    loss_ref.backward()
 
-    model = lidar.SPVCNN(**kw)
-    model.load_state_dict(ref.state_dict())     # same keys by construction
-    model.cuda().train()
-    model.dropout.p = 0.0
-    out = model({'lidar': ts.SparseTensor(feats.cuda(), coords.cuda())})['x_vox']
-    from u2mkd_amd.losses import MixLovaszCrossEntropy
-    loss = MixLovaszCrossEntropy(ignore_index=0)(out, labels.cuda())
+    crit = MixLovaszCrossEntropy(ignore_index=0)
+
+    def run_cpu(dtype, record):
+        m = O.fill_state_by_name(O.SPVCNN(**kw)).train().to(dtype)
+        m.dropout.p = 0.0            # random masks differ across implementations (SURVEY 8d "Weights")
+        rec, remove = GA.record_oracle_relus(m) if record else ({}, lambda: None)
+        out = m({'lidar': ots.SparseTensor(feats.to(dtype), coords)})['x_vox']
+        remove()
+        # (the oracle's Lovasz restatement computes in .float() like core/criterions.py; the fp64 arbiter takes the
+        # dtype-generic form of the same loss)
+        loss = O.mix_lovasz_cross_entropy(out, labels) if dtype == torch.float32 else crit(out, labels)
+        loss.backward()
+        return m, out.detach(), loss.detach(), rec
+    m64, _, _, rec64 = run_cpu(torch.float64, True)
+    m32, out32, loss32, _ = run_cpu(torch.float32, False)
+    mg = lidar.SPVCNN(**kw)
+    mg.load_state_dict(m32.state_dict())     # same keys by construction
+    mg.cuda().train()
+    mg.dropout.p = 0.0
+    rec_hip = GA.record_hip_relus(mg, monkeypatch)
+    out = mg({'lidar': ts.SparseTensor(feats.cuda(), coords.cuda())})['x_vox']
+    loss = crit(out, labels.cuda())
     loss.backward()
-    return ref, out_ref, loss_ref, model, out, loss
+    return m64, m32, out32, loss32, mg, out, loss, rec64, rec_hip
 
 
 @pytest.mark.parametrize('n_vox,batch,cr', [(3000, 2, 0.5), (30000, 1, 0.5), (6000, 1, 1.0)])
-def test_spvcnn_logits_and_grads(hip, n_vox, batch, cr):
-    ref, out_ref, loss_ref, model, out, loss = _run_pair(n_vox, batch, cr)
-    err = float((out.detach().cpu() - out_ref.detach()).abs().max())
+def test_spvcnn_logits_and_grads(hip, monkeypatch, n_vox, batch, cr):
+    import grad_arbiter as GA
+    m64, m32, out_ref, loss_ref, model, out, loss, rec64, rec_hip = _run_three(n_vox, batch, cr, 11, monkeypatch)
+    err = float((out.detach().cpu() - out_ref).abs().max())
     assert err < 1e-3, f'logit max abs err {err}'
     assert abs(float(loss) - float(loss_ref)) < 1e-3
-    # Gradient gate.  The network is only piecewise smooth: a ReLU input within fp32 rounding of 0
-    # flips between two fp32 evaluations with different summation order, and one flipped element
-    # moves a parameter gradient by ~1/N of its norm.  tools/dbg_fp64.py shows the CPU-fp32 oracle is
-    # itself 1e-3..1e-2 (max-norm) away from a CPU-fp64 run on the same tensors, the same band as the
-    # HIP path, while every smooth operator is held to 1e-4 in test_gpu_torchsparse_ops.py.  So the
-    # end-to-end gate is an L2-relative bound per conv kernel.
-    ref_grads = dict(ref.named_parameters())
-    rels = []
+    # Gradient gate (SURVEY 8d: 1e-3 relative per conv kernel), against the fp64 arbiter.  The network is only
+    # piecewise smooth: a ReLU input within fp32 rounding of 0 flips between two fp32 evaluation orders, and one
+    # flipped element can carry a visible share of a layer's gradient -- such a scene passes only with the flipped
+    # elements found and named (grad_arbiter.assert_grads_within_fp64_gate); smooth operators are held to 1e-4 in
+    # test_gpu_torchsparse_ops.py.
+    GA.assert_grads_within_fp64_gate('scene 11 (%d voxels x %d, cr %.1f)' % (n_vox, batch, cr), model, m64, m32, rec64, rec_hip)
+    ref_grads = dict(m32.named_parameters())
     for name, p in model.named_parameters():
-        g, gr = p.grad.detach().cpu().double(), ref_grads[name].grad.double()
-        if float(gr.abs().max()) < 1e-7:
+        if float(ref_grads[name].grad.abs().max()) < 1e-7:
             # structurally zero gradient (a Linear bias feeding a train-mode BatchNorm)
-            assert float(g.abs().max()) < 1e-6, name
-            continue
-        rel = float((g - gr).norm() / gr.norm())
-        if name.endswith('kernel'):
-            rels.append(rel)
-            assert rel < 2e-2, f'{name}: L2-relative grad err {rel}'
-    assert float(np.median(rels)) < 5e-3
+            assert float(p.grad.abs().max()) < 1e-6, name
 
 
-def test_kernel_grads_are_as_close_to_fp64_as_the_fp32_reference_is(hip):
-    """The claim behind the L2-relative gradient gate above, as a test: the same network and cloud evaluated by the
-    CPU oracle in fp64 is the arbiter.  Per conv kernel, the HIP gradient's distance from the fp64 gradient is
-    compared with the distance of the CPU-fp32 oracle (the reference arithmetic) from it: against fp64 every conv
-    kernel's HIP gradient is within 1e-3 (L2-relative), a small multiple of the CPU-fp32 oracle's own distance.
-
-    The network is only piecewise smooth, and the statement holds per scene up to ONE kind of event: a ReLU input
-    within a rounding of zero whose gradient entry is a visible share of the whole gradient flips between any two
-    fp32 evaluation orders.  Observed on scene 11 when nn.Linear moved from f32 MFMA to bf16x3 arithmetic: every
-    activation and every upstream gradient of the two runs agreed to 5e-7, ONE mask element of vox_ups.2.1.0
-    differed, and it carried 0.5 % of that layer's gradient norm -- all 40 kernels below it moved by 2e-3 while both
-    nn.Linear variants were within 1.5e-7 of fp64.  So three scenes are evaluated: the strict gate must hold on
-    at least two of them, and on every scene the distance stays in the range of a flip (< 2e-2), never of a wrong
-    kernel."""
-    from u2mkd_amd import lidar, torchsparse as ts
-    from u2mkd_amd.losses import MixLovaszCrossEntropy
-    kw = dict(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05)
-    crit = MixLovaszCrossEntropy(ignore_index=0)
+def test_kernel_grads_are_as_close_to_fp64_as_the_fp32_reference_is(hip, monkeypatch):
+    """The same gate over three more clouds.  What a miss looked like when it happened (scene 11, when nn.Linear moved
+    from f32 MFMA to bf16x3 arithmetic): every activation and every upstream gradient of the two runs agreed to 5e-7,
+    ONE mask element of vox_ups.2.1.0 differed and carried 0.5 % of that layer's gradient norm -- all 40 kernels below
+    it moved by 2e-3 while both nn.Linear variants were within 1.5e-7 of fp64.  The arbiter now finds and names such
+    elements itself; a scene misses the strict bound only with them, and never by more than a flip's size."""
+    import grad_arbiter as GA
     strict = []
-    for seed in (11, 12, 13):
-        b = synth_batch(3000, 2, seed)
-        feats, coords, labels = (torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
-
-        def run_cpu(dtype):
-            m = O.fill_state_by_name(O.SPVCNN(**kw)).train().to(dtype)
-            m.dropout.p = 0.0
-            crit(m({'lidar': ots.SparseTensor(feats.to(dtype), coords)})['x_vox'], labels).backward()
-            return m
-        m64, m32 = run_cpu(torch.float64), run_cpu(torch.float32)
-        mg = lidar.SPVCNN(**kw)
-        mg.load_state_dict(m32.state_dict())
-        mg.cuda().train()
-        mg.dropout.p = 0.0
-        crit(mg({'lidar': ts.SparseTensor(feats.cuda(), coords.cuda())})['x_vox'], labels.cuda()).backward()
-        g64, g32 = dict(m64.named_parameters()), dict(m32.named_parameters())
-        hip_err, cpu_err = [], []
-        for name, p in mg.named_parameters():
-            if not name.endswith('kernel'):
-                continue
-            r = g64[name].grad
-            hip_err.append(float((p.grad.cpu().double() - r).norm() / r.norm()))
-            cpu_err.append(float((g32[name].grad.double() - r).norm() / r.norm()))
-        hip_err, cpu_err = np.array(hip_err), np.array(cpu_err)
-        print('GRAD-FP64 scene %d kernels %d: HIP vs fp64 median %.2e max %.2e | CPU-fp32 vs fp64 median %.2e max %.2e | worst ratio %.2f'
-              % (seed, len(hip_err), np.median(hip_err), hip_err.max(), np.median(cpu_err), cpu_err.max(),
-                 (hip_err / np.maximum(cpu_err, 1e-4)).max()))
-        assert hip_err.max() < 2e-2, (seed, hip_err.max())
-        # SURVEY 8d asks 1e-3 relative on every conv kernel's gradient: held against the fp64 gradient (measured on
-        # MI355X, scene 11 before the flip described above: HIP median 2.3e-4 / max 6.4e-4; the CPU-fp32 oracle itself
-        # median 1.1e-4 / max 2.8e-4)
-        strict.append(bool(hip_err.max() < 1e-3 and np.median(hip_err) < 5e-4
-                           and np.all(hip_err <= 4.0 * np.maximum(cpu_err, 2.5e-4))))
-    assert sum(strict) >= 2, strict
+    for seed in (12, 13, 14):
+        m64, m32, _, _, mg, _, _, rec64, rec_hip = _run_three(3000, 2, 0.5, seed, monkeypatch)
+        strict.append(GA.assert_grads_within_fp64_gate('scene %d' % seed, mg, m64, m32, rec64, rec_hip))
+        monkeypatch.undo()
+    print('GRAD-FP64 strict on', strict)
 
 
 def test_ddp_syncbn_path_on_gpu_single_rank(hip):

@@ -4,7 +4,7 @@ from tests.test_kd_path import _build, _kd_tensors, G
 from oracle.spvcnn_ref import fill_state_by_name
 from u2mkd_amd import kd, torchsparse as ts
 from u2mkd_amd.synth import synth_kd_batch
-gold = np.load(os.path.join(G, 'kd_cr10_3000.npz'))
+gold = np.load(os.path.join(G, 'kd_cr10_3000_edge_seed77.npz'))
 model = fill_state_by_name(_build('cuda')).cuda().train(); model.model_t.eval(); model.model_s.dropout.p = 0.0
 b = synth_kd_batch(1500, 2, seed=77, image_hw=(64, 112)); s, t = b['student'], b['teacher']
 pc, ms = _kd_tensors(b, 'cuda')

@@ -250,3 +250,22 @@ def synth_kd_batch(n_vox: int, batch: int = 1, seed: int = 1234, image_hw=(360, 
     if (sweeps or 0) > 1:
         teacher['keyframe_mask_full'] = np.concatenate(T['keyframe_mask_full'])
     return {'student': student, 'teacher': teacher}
+
+
+def synth_eval_feed(b, seed: int):
+    """The pieces of the eval feed dict that synth_kd_batch does not carry (core/datasets/
+    lc_semantic_nusc_tsd_full.py:436-486, consumed by core/nusc_trainers.py:367-418): the student's raw points ->
+    voxel map (``inverse_map``: index within the scene) with their labels and in-view labels, and the scene index /
+    labels of the teacher's raw points.  Random but seeded (the golden generator and the tests build the same)."""
+    rng = np.random.default_rng(seed)
+    s, t = b['student'], b['teacher']
+    inv, ib = [], []
+    for i, nv in enumerate(s['num_vox']):
+        n_pts = int(1.3 * nv)
+        inv.append(rng.integers(0, nv, n_pts))
+        ib.append(np.full(n_pts, i))
+    inv, ib = np.concatenate(inv).astype(np.int64), np.concatenate(ib).astype(np.int64)
+    tb = np.concatenate([np.full(n, i) for i, n in enumerate(t['num_pts'])]).astype(np.int64)
+    return {'s_inverse_map': inv, 's_inverse_batch': ib, 'targets_mapped': rng.integers(0, 17, len(inv)),
+            'label_fov': rng.integers(0, 17, len(inv)), 't_inverse_batch': tb,
+            'targets_mapped_t': rng.integers(0, 17, len(tb))}

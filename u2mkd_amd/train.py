@@ -86,6 +86,23 @@ class LidarStep:
         self.sched.step()
         return loss.detach()
 
+    @torch.no_grad()
+    def evaluate(self, feats, coords, inverse_map, inverse_batch, targets_mapped, keyframe_mask_full=None):
+        """The branch of ``_run_step`` taken when the model is not training (core/spformer_trainer.py:95-117): voxel
+        logits -> per-point predictions through ``inverse_map`` (index of every raw point's voxel within its scene;
+        ``inverse_batch`` = its scene), concatenated scene by scene; multi-sweep inputs keep the key-frame points.
+        Returns the reference's dictionary (``outputs_vox``, ``targets``) for evaluate.MeanIoU, on the device."""
+        from .evaluate import voxel_logits_to_point_predictions
+        assert not self.model.training, 'evaluate() is the eval branch: call model.eval() first (core/spformer_trainer.py:119-120)'
+        with self.amp.autocast():
+            out = self.net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+        pred = voxel_logits_to_point_predictions(out, coords[:, -1], inverse_map, inverse_batch, keyframe_mask_full)
+        order = torch.argsort(inverse_batch.long(), stable=True)
+        targets = targets_mapped[order]
+        if keyframe_mask_full is not None:
+            targets = targets[keyframe_mask_full[order]]
+        return {'outputs_vox': pred, 'targets': targets}
+
 
 def kd_batch_to_device(b, device='cuda'):
     """numpy KD batch (synth.synth_kd_batch / the reference's collate schema) -> device tensors
@@ -162,6 +179,31 @@ class KDStep:
         self.amp.backward_and_step(ld['total'], self.opt)
         self.sched.step()
         return ld['total'].detach()
+
+    @torch.no_grad()
+    def evaluate(self, d, s_inverse_map, s_inverse_batch, targets_mapped, label_fov, t_inverse_batch=None,
+                 targets_mapped_t=None):
+        """The eval branch of ``NuScenesLCTSDFullTrainer._run_step`` (core/nusc_trainers.py:367-418): the student's
+        voxel logits and pixel-branch logits -> per-point predictions through the student's ``inverse_map``
+        (``s_inverse_map`` [Np] voxel index within the scene, ``s_inverse_batch`` [Np] scene), with the mapped labels
+        and the in-view labels; with ``debug_val`` (kd.TSDFull(debug_val=True)) also the teacher's predictions through
+        ``d['inverse_map']``, key-frame points only for multi-sweep teachers.  Same dictionary keys as the
+        reference, tensors stay on the device."""
+        from .evaluate import voxel_logits_to_point_predictions as v2p
+        assert not self.model.training, 'evaluate() is the eval branch: call model.eval() first (core/nusc_trainers.py:420-421)'
+        with self.amp.autocast():
+            out = self.net(self._in_mod(d))
+        vb = d['s_coords'][:, -1]
+        order = torch.argsort(s_inverse_batch.long(), stable=True)
+        ret = {'outputs_vox': v2p(out['stu']['x_vox'], vb, s_inverse_map, s_inverse_batch),
+               'outputs_pix': v2p(out['stu']['x_pix'], vb, s_inverse_map, s_inverse_batch),
+               'targets': targets_mapped[order], 'targets_fov': label_fov[order]}
+        if self.model.debug_val:
+            kf = d.get('keyframe_mask_full')
+            ret['outputs_vox_t'] = v2p(out['t']['x_vox'], d['t_coords'][:, -1], d['inverse_map'], t_inverse_batch, kf)
+            order_t = torch.argsort(t_inverse_batch.long(), stable=True)
+            ret['targets_t'] = targets_mapped_t[order_t] if kf is None else targets_mapped_t[order_t][kf[order_t]]
+        return ret
 
 
 # ------------------------------------------------------------------------------------- checkpoints
