@@ -1,0 +1,42 @@
+"""Upper bounds for step-level changes, measured instead of estimated: the pipelined KD step (fresh batches, geometry
+prefetch) with parts of the work switched off.  One variant per process (env / argv), wall ms per step printed.
+  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [no_cam_bwd] [no_teacher]"""
+import sys, time, os; sys.path.insert(0, '.')
+import torch
+from u2mkd_amd import lidar, train as T, kd as KD
+from u2mkd_amd.synth import synth_kd_batch
+
+flags = set(sys.argv[1:])
+torch.manual_seed(0)
+sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+model = KD.TSDFull(cr=1.0, cr_t=2.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp,
+                   run_pix_decoder='no_pix_decoder' not in flags).cuda()
+if 'no_cam_wgrad' in flags:        # camera convolutions without weight gradients (their data gradients stay)
+    for n, p in model.model_s.pix_branch.named_parameters():
+        if p.dim() == 4:
+            p.requires_grad_(False)
+run = T.KDStep(model, num_epochs=50, batch_size=1)
+run.train_mode()
+res = [T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234 + i, image_hw=(360, 640))) for i in range(4)]
+if 'no_pix_decoder' in flags:
+    orig = KD.kd_losses
+    def losses(out, targets, fov, *a, **k):
+        out['stu']['x_pix'] = out['stu']['x_vox']          # the loss arithmetic stays, the decoder's work goes
+        return orig(out, targets, fov, *a, **k)
+    KD.kd_losses = losses
+
+
+def loop(steps):
+    cur = T.fresh_batch(res[0])
+    for i in range(steps):
+        nxt = T.fresh_batch(res[(i + 1) % 4])
+        run(cur, prefetch=nxt)
+        cur = nxt
+
+
+loop(6)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+loop(16)
+torch.cuda.synchronize()
+print('VARIANT %-40s %.2f ms/step' % (' '.join(sorted(flags)) or 'baseline', (time.perf_counter() - t0) / 16 * 1e3), flush=True)

@@ -229,6 +229,93 @@ sptr_attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k, c
     lse[p * h + hh] = m + __logf(l);
 }
 
+// ---- forward, key-split form: S lanes per (token, head) ------------------------------------------------------------
+// The spherical branch's windows grow with the stage (window_size_sphere x window_size_scale^stage): at the coarsest
+// stage a few thousand tokens sit in windows of hundreds, so one thread per (token, head) walking its window serially
+// is a handful of waves per CU in a long chain of dependent loads -- latency-bound, and the kernel lasts as long as
+// the largest window (measured: 754 us forward for 7 552 tokens at stride 16 against 121 us for 57 216 at stride 2).
+// Here S consecutive lanes share a token: lane s walks keys s, s + S, ... with its own online-softmax state, and the
+// states are merged by a butterfly over the S lanes (a fixed tree: deterministic; every lane ends with the same
+// value).  S x more waves hide the latency and the longest chain is S x shorter.
+template <int S>
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_attn_fwd_split_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                           const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
+                           const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
+                           const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,
+                           const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ out,
+                           float *__restrict__ lse, SptrLayout ly) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    static_assert(S >= 2 && S <= 16 && (S & (S - 1)) == 0, "lanes per token: 2, 4, 8 or 16");
+    constexpr int TPB = kSptrThreads / S;
+    const int hh = blockIdx.y;
+    load_tables(s_tab, tq, tk, tv, L, h, hh);
+    __syncthreads();
+    const float *Tq = s_tab, *Tk = s_tab + L * 3 * kTabRow, *Tv = s_tab + 2 * L * 3 * kTabRow;
+    const int sub = threadIdx.x % S;
+    const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x / S;
+    const bool live = p < n;                     // (no early return: the merge shuffles need every lane of the wave)
+    const int64_t pp = live ? p : n - 1;
+    const int64_t t = sort_idx[pp];
+    const size_t hc = ly.ld_qkv;
+    float qi[kHd];
+    load16(q + t * hc + hh * kHd, qi);
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) qi[d] *= ly.q_scale;
+    int qci[3] = {qc[pp * 3], qc[pp * 3 + 1], qc[pp * 3 + 2]};
+    float ri = radial ? radial[pp] : 0.f;
+    const int ws = wstart[pp], wl = live ? wlen[pp] : 0;
+    float m = -INFINITY, l = 0.f, acc[kHd];
+#pragma unroll
+    for (int d = 0; d < kHd; ++d) acc[d] = 0.f;
+    for (int jj = sub; jj < wl; jj += S) {
+        const int pj = ws + jj;
+        const int64_t tj = sort_idx[pj];
+        int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
+        float rj = radial ? radial[pj] : 0.f;
+        int r[3];
+        rel_rows(rc, qci, ri, qcj, rj, r);
+        float kj[kHd], ts[kHd];
+        load16(k + tj * hc + hh * kHd, kj);
+        tab_sum(Tq, r, ts);
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) sc += qi[d] * (kj[d] + ts[d]);
+        tab_sum(Tk, r, ts);
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) sc += kj[d] * ts[d];
+        float mn = fmaxf(m, sc);
+        float corr = __expf(m - mn), pe = __expf(sc - mn);
+        l = l * corr + pe;
+        float vj[kHd];
+        load16(v + tj * hc + hh * kHd, vj);
+        tab_sum(Tv, r, ts);
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) acc[d] = acc[d] * corr + pe * (vj[d] + ts[d]);
+        m = mn;
+    }
+    // merge the S partial softmax states (a lane without keys carries m = -inf, l = 0)
+#pragma unroll
+    for (int off = S >> 1; off >= 1; off >>= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        const float c1 = m == -INFINITY ? 0.f : __expf(m - mn), c2 = m2 == -INFINITY ? 0.f : __expf(m2 - mn);
+        l = l * c1 + l2 * c2;
+#pragma unroll
+        for (int d = 0; d < kHd; ++d) acc[d] = acc[d] * c1 + __shfl_xor(acc[d], off) * c2;
+        m = mn;
+    }
+    if (live && sub == 0) {
+        const float inv = 1.f / l;
+        float *o = out + t * (size_t)ly.ld_out + hh * kHd;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4)
+            reinterpret_cast<float4 *>(o)[v4] =
+                make_float4(acc[4 * v4] * inv, acc[4 * v4 + 1] * inv, acc[4 * v4 + 2] * inv, acc[4 * v4 + 3] * inv);
+        lse[p * h + hh] = m + __logf(l);
+    }
+}
+
 // delta[p,h] = sum_d dout[t,h,d] * out[t,h,d]
 __global__ void sptr_delta_kernel(const float *__restrict__ dout, const float *__restrict__ out,
                                   const int32_t *__restrict__ sort_idx, int64_t n, int h, float *__restrict__ delta,
@@ -584,6 +671,16 @@ int u2mkd_sptr_quant_coords(const float *xyz, const int32_t *sort_idx, int64_t n
     return check_launch("u2mkd_sptr_quant_coords");
 }
 
+// Lanes per (token, head).  The window length is only known on the device; what the host knows is the token count
+// and the branch: the cubic windows hold a few tokens at every stage, the spherical windows grow as the token count
+// shrinks (coarser stages, wider cones).  U2MKD_SPTR_SPLIT = 1 / 2 / 4 / 8 / 16 overrides (A/B runs).
+static int sptr_split(int64_t n, float split_a) {
+    static const int forced = [] { const char *e = getenv("U2MKD_SPTR_SPLIT"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
+    if (split_a <= 0.f) return 1;
+    return n < 12000 ? 16 : n < 24000 ? 8 : n < 48000 ? 4 : 2;
+}
+
 static int sptr_check(const char *who, int64_t n, int h, int hdim, int L, int qgl, float a) {
     U2_REQUIRE(hdim == kHd, "%s: head dim %d != 16 (the reference asserts hdim == 16)", who, hdim);
     U2_REQUIRE(h > 0 && h <= 65535, "%s: bad head count %d", who, h);
@@ -610,9 +707,20 @@ int u2mkd_sptr_attention_forward_strided(const float *q, const float *k, const f
     RelCtx rc{qgl, split_a};
     SptrLayout ly{ld_qkv, ld_out, 0, q_scale};
     size_t lds = (size_t)3 * L * 3 * kTabRow * sizeof(float);
-    hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
-                       as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, split_a > 0.f ? radial : nullptr, tq, tk, tv,
-                       L, rc, n, h, out, lse, ly);
+    const float *rad = split_a > 0.f ? radial : nullptr;
+    const int S = sptr_split(n, split_a);
+#define U2_SPTR_FWD(SS)                                                                                                  \
+    hipLaunchKernelGGL(sptr_attn_fwd_split_kernel<SS>, dim3((unsigned)ceil_div(n, kSptrThreads / SS), h),                \
+                       dim3(kSptrThreads), lds, as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L,   \
+                       rc, n, h, out, lse, ly)
+    if (S == 16) U2_SPTR_FWD(16);
+    else if (S == 8) U2_SPTR_FWD(8);
+    else if (S == 4) U2_SPTR_FWD(4);
+    else if (S == 2) U2_SPTR_FWD(2);
+    else
+        hipLaunchKernelGGL(sptr_attn_fwd_kernel, dim3((unsigned)ceil_div(n, kSptrThreads), h), dim3(kSptrThreads), lds,
+                           as_stream(s), q, k, v, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, out, lse, ly);
+#undef U2_SPTR_FWD
     return check_launch("u2mkd_sptr_attention_forward");
 }
 

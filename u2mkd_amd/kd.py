@@ -199,14 +199,7 @@ class StudentMSP2IFM(nn.Module):
             pts_feat.F = self.c2l_fusion_blocks[idx](pts_feat.F, img_feat_tensor)
             vox_feats.append(point_to_voxel(vox_out, pts_feat))
 
-        # the pixel decoder (camera side) next to the voxel decoder (LiDAR side)
-        x_pix = None
-        if self.run_pix_decoder:
-            def pix_decoder():
-                fmap = self._piece('decoder_%dx%d' % (ih, iw))(*img_feats)
-                fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
-                return feature_fetch(masks, pixel_coordinates, fmap)
-            x_pix = on_side(pix_decoder, *img_feats)
+        fused = fork.mark()           # the pixel decoder's inputs (img_feats) are complete here
         _, x1, x2, x3, x4 = vox_feats
         z1 = pts_feat
         z1.F = z1.F + self.point_transforms[0](z0.F)
@@ -229,7 +222,20 @@ class StudentMSP2IFM(nn.Module):
 
         ret = {'x_vox': self.classifier_vox(z3.F), 'num_pts': [c.shape[1] for c in pixel_coordinates],
                'mse_loss': mse_loss, 'pts_feats': pts_feats}
-        if x_pix is not None:
+        # The pixel decoder (camera side) runs next to the voxel decoder (LiDAR side) on the camera stream.  It is QUEUED
+        # after the voxel decoder on purpose: autograd issues the backward in reverse creation order, so the decoder's
+        # backward -- the head of the camera branch's backward chain, which every fusion stage's gradient waits for --
+        # is the first thing the host issues when the backward starts, instead of following the voxel decoder's
+        # few hundred launches (measured: the camera stream sat idle for the first ~6 ms of every backward).  In the
+        # forward the order costs nothing: the camera stream only depends on img_feats, and in the pipelined steady
+        # state the host issues the forward well ahead of the GPU (the side stream waits for the event `fused`, not for
+        # the voxel decoder).
+        if self.run_pix_decoder:
+            def pix_decoder():
+                fmap = self._piece('decoder_%dx%d' % (ih, iw))(*img_feats)
+                fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
+                return feature_fetch(masks, pixel_coordinates, fmap)
+            x_pix = on_side(pix_decoder, *img_feats, after=fused)
             join(x_pix)
             ret['x_pix'] = x_pix
         return ret
@@ -324,10 +330,22 @@ class _Fork:
         self.main = torch.cuda.current_stream() if ref.is_cuda else None
         self.side = _side_stream(ref, role) if (enabled and ref.is_cuda) else None
 
-    def on_side(self, fn, *inputs):
+    def mark(self):
+        """An event on the main stream: `on_side(..., after=mark)` orders the side stream behind the work queued up to
+        here only, whatever the main stream receives in between."""
+        if self.side is None:
+            return None
+        e = torch.cuda.Event()
+        e.record(self.main)
+        return e
+
+    def on_side(self, fn, *inputs, after=None):
         if self.side is None:
             return fn()
-        self.side.wait_stream(self.main)
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(self.main)
         for t in inputs:
             t.record_stream(self.side)       # allocated on the main stream, read on the side stream
         with torch.cuda.stream(self.side):
