@@ -331,6 +331,27 @@ int u2mkd_csr_build(const int32_t *keys /*[n_entries]*/, int64_t n_entries, int6
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 
+/* ---- the pixel head's full-resolution tail at the pixels that are read (csrc/pixhead.hip) -----------------------------
+ * Replaces the dense evaluation of  Feature_Fetch(classifier_pix(upsample(x, image size)))  (the final F.interpolate of
+ * core/models/image_branch/swiftnet.py forward_up, the BNReluConv `classifier_pix` of
+ * core/models/nuscenes/spvcnn_swiftnet18_spformer_tsd_full.py and Feature_Fetch, core/models/fusion_blocks.py:257-278):
+ *   u2mkd_up_plan          sample point * 4 + corner: the 4 low-resolution bilinear sources (align_corners; slots 4..7
+ *                          unused) of full-resolution pixel idx8[point][corner] (rows (image * H + y) * W + x, -1 = none)
+ *                          as rows (image * h + i) * w + j; rh = (h - 1) / (H - 1), rw likewise, in fp32
+ *   u2mkd_upbn_stats       partial [n_img * c][chunks][2]: per plane and row chunk the sums of the UP-SAMPLED map shifted
+ *                          by the channel's first element, taken on the low-resolution map x [n_img, c, h, w]:
+ *                          sum a_i b_j (x - K) and sum (x - K) (Ay (x - K) Ax); a [h], b [w] = column sums of the two
+ *                          interpolation matrices, ay [3][h], ax [3][w] = lower / main / upper diagonal of Wy^T Wy, Wx^T Wx
+ *   u2mkd_upbn_dense_grad  dx = c0[ch] a_i b_j + c1[ch] (Ay x Ax)[i][j]: what the BatchNorm backward's dense terms
+ *                          (c0 + c1 U on every up-sampled pixel) send back through the up-sampling                      */
+int u2mkd_up_plan(const int32_t *idx8 /*[n,8]*/, int64_t n, int32_t H, int32_t W, int32_t h, int32_t w, float rh, float rw,
+                  int32_t *idx_out /*[4n,8]*/, float *w_out /*[4n,8]*/, u2mkd_stream_t s);
+int u2mkd_upbn_stats(const float *x, int32_t n_img, int32_t c, int32_t h, int32_t w, const float *a, const float *b,
+                     const float *ay, const float *ax, int32_t rows_per_chunk, float *partial, u2mkd_stream_t s);
+int u2mkd_upbn_dense_grad(const float *x, int32_t n_img, int32_t c, int32_t h, int32_t w, const float *a, const float *b,
+                          const float *ay, const float *ax, const float *c0 /*[c]*/, const float *c1 /*[c]*/,
+                          float *dx, u2mkd_stream_t s);
+
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
  * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and

@@ -1,6 +1,6 @@
 """Upper bounds for step-level changes, measured instead of estimated: the pipelined KD step (fresh batches, geometry
 prefetch) with parts of the work switched off.  One variant per process (env / argv), wall ms per step printed.
-  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [no_cam_bwd] [no_teacher]"""
+  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [half_res_tail]"""
 import sys, time, os; sys.path.insert(0, '.')
 import torch
 from u2mkd_amd import lidar, train as T, kd as KD
@@ -15,6 +15,10 @@ if 'no_cam_wgrad' in flags:        # camera convolutions without weight gradient
     for n, p in model.model_s.pix_branch.named_parameters():
         if p.dim() == 4:
             p.requires_grad_(False)
+if 'half_res_tail' in flags:      # the pixel head evaluated on the H/2 map (no final x2 up-sampling): what the full-resolution tail costs
+    pb = model.model_s.pix_branch
+    fu = pb.forward_up
+    pb.forward_up = lambda feats, im_size=None: fu(feats, im_size=None)
 run = T.KDStep(model, num_epochs=50, batch_size=1)
 run.train_mode()
 res = [T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234 + i, image_hw=(360, 640))) for i in range(4)]

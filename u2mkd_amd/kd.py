@@ -18,6 +18,7 @@ from . import torchsparse
 from .camera import BNReluConv, SwiftNetRes18
 from .graphs import PieceCache, StaticPiece
 from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c_scatter
+from .pixel_head import sampled_head_applies, sampled_pixel_logits
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
 from .lidar.point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, voxel_to_point
@@ -123,6 +124,9 @@ class StudentMSP2IFM(nn.Module):
             elif name.startswith('l2c'):
                 blk = self.l2c_fusion_blocks[int(name[3:])]
                 fn, mods = (lambda fmap, skip: blk(fmap, skip)), [blk]
+            elif name == 'decoder_low':
+                # the decoder up to its last blend (H/2 x W/2): the tail is evaluated at the sampled pixels (pixel_head.py)
+                fn, mods = (lambda *feats: pb.forward_up(list(feats), im_size=None)), [pb.upsample]
             else:
                 # the up-sampling target is part of the piece's NAME: two image sizes with equal feature-map shapes
                 # (H = 359 and 360 both give H/2 = 180) must not share a captured graph
@@ -231,7 +235,13 @@ class StudentMSP2IFM(nn.Module):
         # state the host issues the forward well ahead of the GPU (the side stream waits for the event `fused`, not for
         # the voxel decoder).
         if self.run_pix_decoder:
+            sampled = sampled_head_applies(img_feats[0], self.classifier_pix)
+
             def pix_decoder():
+                if sampled:
+                    # up-sampling to the image size + BatchNorm + ReLU + classifier only at the pixels Feature_Fetch reads
+                    fmap = self._piece('decoder_low')(*img_feats)
+                    return sampled_pixel_logits(fmap, self.classifier_pix, pixel_coordinates, masks, (ih, iw), ib, ncam)
                 fmap = self._piece('decoder_%dx%d' % (ih, iw))(*img_feats)
                 fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
                 return feature_fetch(masks, pixel_coordinates, fmap)

@@ -1,0 +1,160 @@
+"""The pixel head of the camera branch evaluated at the pixels the LiDAR points read (csrc/pixhead.hip).
+
+Reference (core/models/nuscenes/spvcnn_swiftnet18_spformer_tsd_full.py, the `run_pix_decoder` branch of the student's
+forward): ``x_pix = Feature_Fetch(masks, pixel_coordinates, classifier_pix(pix_branch.forward_up(feats, im_size)))`` --
+the decoder's [b*ncam, 128, H/2, W/2] map is up-sampled to the image size (swiftnet.py forward_up), BatchNorm + ReLU +
+a 1x1 convolution run over every one of the b*ncam*H*W pixels, and Feature_Fetch (fusion_blocks.py:257-278) then reads
+the logits at the <= 4 bilinear corners of every LiDAR point.  Here the same numbers come from the low-resolution map:
+
+* BatchNorm's batch statistics over the up-sampled map are two quadratures on the low-resolution map
+  (`u2mkd_upbn_stats`; running statistics are updated with them exactly as nn.BatchNorm2d would);
+* every (point, corner) sample gathers its up-sampled 128-vector from 4 low-resolution pixels (`u2mkd_up_plan` composes
+  the two bilinear maps, the gather is the row operator `spdevoxelize` with its deterministic CSR backward), is
+  normalised, rectified and multiplied by the classifier (the row operator `linear`), and the 4 corners of a point are
+  blended with Feature_Fetch's weights;
+* backward: the sampled rows carry their own gradient back through the gather; the BatchNorm backward's terms that
+  reach EVERY up-sampled pixel (dU = c0 + c1 U) fold through the up-sampling in closed form (`u2mkd_upbn_dense_grad`).
+
+Same result as the dense evaluation up to fp32 summation order (tests/test_gpu_pixel_head.py); 6 x 128 x 360 x 640
+floats (708 MB, 4.4 GB at 900 x 1600) per tensor of the dense tail are never formed."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+__all__ = ['sampled_pixel_logits', 'sampled_head_applies']
+
+_ENABLED = os.environ.get('U2MKD_SAMPLED_PIXEL_HEAD', '1') != '0'
+_COEF = {}
+_ROWS_PER_CHUNK = 16
+
+
+def _interp_coefficients(n_in, n_out, device):
+    """(scale, a [n_in], diagonals [3, n_in]) of W = the [n_out, n_in] matrix of F.interpolate(mode='bilinear',
+    align_corners=True) along one axis, with torch's fp32 index arithmetic (src = scale * dst, lambda = src - floor):
+    a = W^T 1 (column sums), diagonals = lower / main / upper diagonal of W^T W (tridiagonal: a row of W has two
+    neighbouring entries).  Built once per size in fp64 on the host."""
+    key = (n_in, n_out, str(device))
+    if key not in _COEF:
+        r = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+        src = (r * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+        i0 = src.astype(np.int64)
+        ip = (i0 < n_in - 1).astype(np.int64)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        l0 = (np.float32(1) - l1).astype(np.float32)
+        wm = np.zeros((n_out, n_in), np.float64)
+        np.add.at(wm, (np.arange(n_out), i0), l0.astype(np.float64))
+        np.add.at(wm, (np.arange(n_out), i0 + ip), l1.astype(np.float64))
+        gram = wm.T @ wm
+        diag = np.zeros((3, n_in))
+        diag[1] = np.diag(gram)
+        diag[0, 1:] = np.diag(gram, -1)
+        diag[2, :-1] = np.diag(gram, 1)
+        _COEF[key] = (float(r), torch.tensor(wm.sum(0), dtype=torch.float32, device=device),
+                      torch.tensor(diag, dtype=torch.float32, device=device).contiguous())
+    return _COEF[key]
+
+
+class _UpsampledBatchNormReLU(torch.autograd.Function):
+    """relu(batch_norm(up(x))) at sampled pixels: x [N, C, h, w] the low-resolution map, u [S, C] the up-sampled values
+    at the samples (gathered from x by the caller, so their gradient flows through the gather)."""
+
+    @staticmethod
+    def forward(ctx, x, u, weight, bias, bn, size):
+        n, c, h, w = x.shape
+        big_h, big_w = size
+        count = n * big_h * big_w
+        training = bn.training or bn.running_mean is None
+        coef = None
+        if training:
+            _, a, ay = _interp_coefficients(h, big_h, x.device)
+            _, b, ax = _interp_coefficients(w, big_w, x.device)
+            coef = (a, b, ay, ax)
+            chunks = (h + _ROWS_PER_CHUNK - 1) // _ROWS_PER_CHUNK
+            partial = torch.empty(n * c, chunks, 2, dtype=torch.float32, device=x.device)
+            L.call('u2mkd_upbn_stats', L.ptr(x), n, c, h, w, L.ptr(a), L.ptr(b), L.ptr(ay), L.ptr(ax), _ROWS_PER_CHUNK,
+                   L.ptr(partial), L.stream())
+            sums = partial.view(n, c, chunks, 2).double().sum((0, 2))               # [C, 2], shifted by x[0, :, 0, 0]
+            m1 = sums[:, 0] / count
+            mean = x[0, :, 0, 0].double() + m1
+            var = (sums[:, 1] / count - m1 * m1).clamp_(min=0.0)
+            if bn.track_running_stats and bn.running_mean is not None:
+                with torch.no_grad():
+                    bn.num_batches_tracked.add_(1)
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
+                    bn.running_var.mul_(1.0 - m).add_((var * (count / max(count - 1, 1))).to(bn.running_var.dtype), alpha=m)
+        else:
+            mean, var = bn.running_mean.double(), bn.running_var.double()
+        invstd = (var + bn.eps).rsqrt().float()
+        mean = mean.float()
+        xhat = (u - mean) * invstd
+        y = torch.relu(xhat * weight + bias)
+        ctx.save_for_backward(x, xhat, y, weight, invstd, mean)
+        ctx.meta = (training, count, coef)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, xhat, y, weight, invstd, mean = ctx.saved_tensors
+        training, count, coef = ctx.meta
+        g = gy * (y > 0)
+        dbeta = g.sum(0)
+        dgamma = (g * xhat).sum(0)
+        scale = weight * invstd
+        du = g * scale
+        dx = None
+        if training:
+            # dU = scale * (g - mean(g) - xhat * mean(g * xhat)) over ALL count pixels; g = 0 off the samples.  The two
+            # mean terms reach every pixel: c0 + c1 * U, folded through the up-sampling by the dense-gradient kernel.
+            c1 = -(scale * invstd) * (dgamma / count)
+            c0 = -scale * (dbeta / count) - c1 * mean
+            a, b, ay, ax = coef
+            n, c, h, w = x.shape
+            dx = torch.empty_like(x)
+            L.call('u2mkd_upbn_dense_grad', L.ptr(x), n, c, h, w, L.ptr(a), L.ptr(b), L.ptr(ay), L.ptr(ax),
+                   L.ptr(c0.contiguous()), L.ptr(c1.contiguous()), L.ptr(dx), L.stream())
+        return dx, du, dgamma, dbeta, None, None
+
+
+def sampled_head_applies(x, head):
+    """fp32 device map, plain (non-synchronising) BatchNorm2d head, no autocast.  (SyncBatchNorm needs the statistics
+    of every rank: the dense path serves DistributedDataParallel.)"""
+    from .camera import BatchNorm2d
+    return (_ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and type(head.norm) is BatchNorm2d and head.conv.bias is None and head.conv.kernel_size == (1, 1))
+
+
+def sampled_pixel_logits(x, head, pixel_coordinates, masks, im_size, ib, ncam):
+    """``feature_fetch(masks, pixel_coordinates, head(upsample(x, im_size)).view(ib, ncam, ...))`` without the
+    full-resolution tensors.  x [ib*ncam, C, h, w]; head = camera.BNReluConv(C, classes, k=1); returns
+    [sum N_b, classes]."""
+    from .fusion import _NchwToRows, _c2l_plan
+    from .torchsparse.nn import functional as spf
+    L.require_cuda(x)
+    big_h, big_w = im_size
+    n, c, h, w = x.shape
+    assert n == ib * ncam, (n, ib, ncam)
+    x = x.contiguous()
+    # Feature_Fetch's corners in the full-resolution map (the same plan its dense form uses) ...
+    idx8f, w8f = spf._plan(masks[0], 'c2l_%d_%d' % (big_h, big_w),
+                           lambda: _c2l_plan(pixel_coordinates, masks, big_h, big_w), *masks[1:], *pixel_coordinates)
+
+    def compose():
+        npts = idx8f.shape[0]
+        ia = torch.empty(npts * 4, 8, dtype=torch.int32, device=x.device)
+        wa = torch.empty(npts * 4, 8, dtype=torch.float32, device=x.device)
+        rh, rw = _interp_coefficients(h, big_h, x.device)[0], _interp_coefficients(w, big_w, x.device)[0]
+        L.call('u2mkd_up_plan', L.ptr(idx8f), npts, big_h, big_w, h, w, rh, rw, L.ptr(ia), L.ptr(wa), L.stream())
+        return ia, wa
+    # ... composed with the up-sampling: 4 low-resolution sources per (point, corner) sample
+    ia, wa = spf._plan(masks[0], 'up_%d_%d_%d_%d' % (big_h, big_w, h, w), compose, *masks[1:], *pixel_coordinates)
+    rows = _NchwToRows.apply(x.view(ib, ncam, c, h, w))
+    u = spf.spdevoxelize(rows, ia, wa)                                              # [4 * points, C]
+    y = _UpsampledBatchNormReLU.apply(x, u, head.norm.weight, head.norm.bias, head.norm, (big_h, big_w))
+    z = spf.linear(y, head.conv.weight.view(head.conv.out_channels, c), None)      # [4 * points, classes]
+    return (z.view(-1, 4, z.shape[1]) * w8f[:, :4].unsqueeze(-1)).sum(1)
