@@ -368,15 +368,16 @@ __device__ __forceinline__ float hist_row(const float *hist, int ax, int base, i
 }
 
 // wave-private contraction of the 64 tokens of this wave: acc[ax][rb] += P^T vec
-template <int NT>
+template <int NT, int S>
 __device__ __forceinline__ void hist_contract(const float *s_hist, int hs, const float *s_vec, const int *s_base,
                                               int wave, int lane, bool sphere, f32x4 (&acc)[NT][3][3]) {
+    constexpr int TPB = kSptrThreads / S, TW = 64 / S;           // tokens per workgroup / per wave (S lanes per token)
     const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb) {
-        for (int ks = 0; ks < 16; ++ks) {
-            const int i = 64 * wave + 4 * ks + kq;               // token (thread) index in the workgroup
-            const float bvec = s_vec[(tb * kSptrThreads + i) * kVecRow + col];
+        for (int ks = 0; ks < TW / 4; ++ks) {
+            const int i = TW * wave + 4 * ks + kq;               // token slot in the workgroup
+            const float bvec = s_vec[(tb * TPB + i) * kVecRow + col];
             const float *hist = s_hist + (size_t)i * hs + tb * kHistTab;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
@@ -408,7 +409,13 @@ __device__ __forceinline__ void hist_store_slab(float *slab, const int (&table_o
                 }
 }
 
+// Both backward kernels take S lanes per token like the forward (S = 1: one thread walks the window): lane s handles
+// pairs s, s + S, ...; the token's histogram strips are shared by its S lanes (LDS float adds; the lanes of a token sit
+// in ONE wave, whose instructions execute in program order, so the sums are reproducible), the per-lane partial row
+// gradients are summed by a butterfly.  A workgroup then holds 128 / S tokens: S x fewer strips, more workgroups per
+// CU, S x shorter chains.
 // query role: dq_i, and the Tq / Tv table gradients
+template <int S>
 __global__ void __launch_bounds__(kSptrThreads)
 sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                       const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
@@ -418,19 +425,20 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
                       const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dq,
                       float *__restrict__ slabs, SptrLayout ly) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
-    constexpr int NT = 2, HS = NT * kHistTab + 1;
+    constexpr int NT = 2, HS = NT * kHistTab + 1, TPB = kSptrThreads / S, TW = 64 / S;
     const int hh = blockIdx.y;
     const int tabf = L * 3 * kTabRow;
-    float *s_hist = s_tab + 3 * tabf;                              // [threads][HS]
-    float *s_vec = s_hist + kSptrThreads * HS;                     // [NT][threads][kVecRow]
-    int *s_base = reinterpret_cast<int *>(s_vec + NT * kSptrThreads * kVecRow);   // [threads][3]
+    float *s_hist = s_tab + 3 * tabf;                              // [tokens][HS]
+    float *s_vec = s_hist + TPB * HS;                              // [NT][tokens][kVecRow]
+    int *s_base = reinterpret_cast<int *>(s_vec + NT * TPB * kVecRow);   // [tokens][3]
     load_tables(s_tab, tq, tk, tv, L, h, hh);
     __syncthreads();
     const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % S, slot = tid / S;
     const bool sphere = rc.a > 0.f;
     const size_t hc = ly.ld_qkv;
-    float *hist = s_hist + (size_t)tid * HS;
+    float *hist = s_hist + (size_t)slot * HS;
     f32x4 acc[NT][3][3];
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb)
@@ -438,10 +446,16 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
         for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) acc[tb][ax][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int64_t nblk = (n + kSptrThreads - 1) / kSptrThreads;
+    const int64_t nblk = (n + TPB - 1) / TPB;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t p = blk * kSptrThreads + tid;
-        for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        const int64_t p = blk * TPB + slot;
+        if (S == 1) {
+            for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        } else {                                         // the wave clears the strips of its tokens
+            for (int e = lane; e < TW * HS; e += 64) s_hist[(size_t)wave * TW * HS + e] = 0.f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
         float qi[kHd], doi[kHd];
 #pragma unroll
         for (int d = 0; d < kHd; ++d) { qi[d] = 0.f; doi[d] = 0.f; }
@@ -461,7 +475,7 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
             float dqi[kHd];
 #pragma unroll
             for (int d = 0; d < kHd; ++d) dqi[d] = 0.f;
-            for (int jj = 0; jj < wl; ++jj) {
+            for (int jj = sub; jj < wl; jj += S) {
                 const int pj = ws + jj;
                 const int64_t tj = sort_idx[pj];
                 int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
@@ -491,25 +505,38 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
                     const int bin = radial_ax ? r[2] : r[ax] - base[ax];
                     if ((unsigned)bin < (unsigned)(radial_ax ? 2 * kNB : kNB)) {   // always true for qc_span <= kNB
                         const int off = radial_ax ? kHistAx + bin : ax * kNB + bin;
-                        hist[off] += ds;                    // Hq
-                        hist[kHistTab + off] += pr;         // Hv
+                        if (S == 1) {
+                            hist[off] += ds;                    // Hq
+                            hist[kHistTab + off] += pr;         // Hv
+                        } else {
+                            atomicAdd(&hist[off], ds);
+                            atomicAdd(&hist[kHistTab + off], pr);
+                        }
                     }
                 }
             }
-            float *o1 = dq + t * (size_t)ly.ld_grad + hh * kHd;      // d(unscaled q) = q_scale * d(q)
 #pragma unroll
-            for (int d = 0; d < kHd; ++d) o1[d] = dqi[d] * ly.q_scale;
+            for (int off = S >> 1; off >= 1; off >>= 1)
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) dqi[d] += __shfl_xor(dqi[d], off);
+            if (sub == 0) {
+                float *o1 = dq + t * (size_t)ly.ld_grad + hh * kHd;      // d(unscaled q) = q_scale * d(q)
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) o1[d] = dqi[d] * ly.q_scale;
+            }
         }
+        if (sub == 0) {
 #pragma unroll
-        for (int d = 0; d < kHd; ++d) {
-            s_vec[(0 * kSptrThreads + tid) * kVecRow + d] = qi[d];
-            s_vec[(1 * kSptrThreads + tid) * kVecRow + d] = doi[d];
+            for (int d = 0; d < kHd; ++d) {
+                s_vec[(0 * TPB + slot) * kVecRow + d] = qi[d];
+                s_vec[(1 * TPB + slot) * kVecRow + d] = doi[d];
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) s_base[slot * 3 + ax] = base[ax];
         }
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
         __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-        hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        hist_contract<NT, S>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
         __builtin_amdgcn_wave_barrier();
     }
     const int table_of[NT] = {0, 2};
@@ -518,6 +545,7 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
 }
 
 // key role: dk_j, dv_j and the Tk table gradient
+template <int S>
 __global__ void __launch_bounds__(kSptrThreads)
 sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                     const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
@@ -527,28 +555,35 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
                     const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h, float *__restrict__ dk,
                     float *__restrict__ dv, float *__restrict__ slabs, SptrLayout ly) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
-    constexpr int NT = 1, HS = NT * kHistTab + 1;
+    constexpr int NT = 1, HS = NT * kHistTab + 1, TPB = kSptrThreads / S, TW = 64 / S;
     const int hh = blockIdx.y;
     const int tabf = L * 3 * kTabRow;
     float *s_hist = s_tab + 3 * tabf;
-    float *s_vec = s_hist + kSptrThreads * HS;
-    int *s_base = reinterpret_cast<int *>(s_vec + NT * kSptrThreads * kVecRow);
+    float *s_vec = s_hist + TPB * HS;
+    int *s_base = reinterpret_cast<int *>(s_vec + NT * TPB * kVecRow);
     load_tables(s_tab, tq, tk, tv, L, h, hh);
     __syncthreads();
     const float *Tq = s_tab, *Tk = s_tab + tabf, *Tv = s_tab + 2 * tabf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % S, slot = tid / S;
     const bool sphere = rc.a > 0.f;
     const size_t hc = ly.ld_qkv;
-    float *hist = s_hist + (size_t)tid * HS;
+    float *hist = s_hist + (size_t)slot * HS;
     f32x4 acc[NT][3][3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) acc[0][ax][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int64_t nblk = (n + kSptrThreads - 1) / kSptrThreads;
+    const int64_t nblk = (n + TPB - 1) / TPB;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t p = blk * kSptrThreads + tid;
-        for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        const int64_t p = blk * TPB + slot;
+        if (S == 1) {
+            for (int e = 0; e < HS; ++e) hist[e] = 0.f;
+        } else {
+            for (int e = lane; e < TW * HS; e += 64) s_hist[(size_t)wave * TW * HS + e] = 0.f;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
         float ki[kHd];
 #pragma unroll
         for (int d = 0; d < kHd; ++d) ki[d] = 0.f;
@@ -566,7 +601,7 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
             float dki[kHd], dvi[kHd];
 #pragma unroll
             for (int d = 0; d < kHd; ++d) { dki[d] = 0.f; dvi[d] = 0.f; }
-            for (int jj = 0; jj < wl; ++jj) {
+            for (int jj = sub; jj < wl; jj += S) {
                 const int pj = ws + jj;                       // the QUERY of this pair
                 const int64_t tj = sort_idx[pj];
                 int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
@@ -598,21 +633,35 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
                 for (int ax = 0; ax < 3; ++ax) {
                     const bool radial_ax = ax == 2 && sphere;
                     const int bin = radial_ax ? r[2] : r[ax] - base[ax];
-                    if ((unsigned)bin < (unsigned)(radial_ax ? 2 * kNB : kNB))
-                        hist[(radial_ax ? kHistAx : ax * kNB) + bin] += ds2;   // Hk
+                    if ((unsigned)bin < (unsigned)(radial_ax ? 2 * kNB : kNB)) {
+                        float *hk = &hist[(radial_ax ? kHistAx : ax * kNB) + bin];   // Hk
+                        if (S == 1) *hk += ds2;
+                        else atomicAdd(hk, ds2);
+                    }
                 }
             }
-            float *o2 = dk + t * (size_t)ly.ld_grad + hh * kHd, *o3 = dv + t * (size_t)ly.ld_grad + hh * kHd;
 #pragma unroll
-            for (int d = 0; d < kHd; ++d) { o2[d] = dki[d]; o3[d] = dvi[d]; }
+            for (int off = S >> 1; off >= 1; off >>= 1)
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) {
+                    dki[d] += __shfl_xor(dki[d], off);
+                    dvi[d] += __shfl_xor(dvi[d], off);
+                }
+            if (sub == 0) {
+                float *o2 = dk + t * (size_t)ly.ld_grad + hh * kHd, *o3 = dv + t * (size_t)ly.ld_grad + hh * kHd;
+#pragma unroll
+                for (int d = 0; d < kHd; ++d) { o2[d] = dki[d]; o3[d] = dvi[d]; }
+            }
         }
+        if (sub == 0) {
 #pragma unroll
-        for (int d = 0; d < kHd; ++d) s_vec[tid * kVecRow + d] = ki[d];
+            for (int d = 0; d < kHd; ++d) s_vec[slot * kVecRow + d] = ki[d];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) s_base[tid * 3 + ax] = base[ax];
+            for (int ax = 0; ax < 3; ++ax) s_base[slot * 3 + ax] = base[ax];
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        hist_contract<NT>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
+        hist_contract<NT, S>(s_hist, HS, s_vec, s_base, wave, lane, sphere, acc);
         __builtin_amdgcn_wave_barrier();
     }
     const int table_of[NT] = {1};
@@ -733,13 +782,21 @@ int u2mkd_sptr_attention_forward(const float *q, const float *k, const float *v,
                                                 L, qgl, split_a, n, h, hdim, out, (int64_t)h * kHd, lse, s);
 }
 
-static int sptr_bwd_grid(int64_t n) {
-    int64_t nblk = ceil_div(n, kSptrThreads);
-    return (int)(nblk < 512 ? nblk : 512);
+// persistent grid of the backward kernels: S lanes per token -> 128 / S tokens per workgroup pass
+static int sptr_bwd_grid(int64_t n, int S) {
+    int64_t nblk = ceil_div(n, kSptrThreads / S);
+    const int64_t cap = S == 1 ? 512 : 128;            // (a slab per wave: the table reduce reads 2 x grid x heads of them)
+    return (int)(nblk < cap ? nblk : cap);
+}
+
+static int sptr_bwd_grid_max(int64_t n) {
+    int g = sptr_bwd_grid(n, 1);
+    for (int S = 2; S <= 16; S *= 2) g = std::max(g, sptr_bwd_grid(n, S));
+    return g;
 }
 
 size_t u2mkd_sptr_backward_workspace_bytes(int64_t n, int32_t h, int32_t L) {
-    return (size_t)2 * sptr_bwd_grid(n) * h * 3 * L * 3 * kHd * sizeof(float);   // one slab per wave
+    return (size_t)2 * sptr_bwd_grid_max(n) * h * 3 * L * 3 * kHd * sizeof(float);   // one slab per wave, any split
 }
 
 int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
@@ -765,7 +822,8 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
     hipStream_t st = as_stream(s);
     hipLaunchKernelGGL(sptr_delta_kernel, dim3((unsigned)ceil_div(n * h, 256)), dim3(256), 0, st, dout, out, sort_idx,
                        n, h, delta, ld_out);
-    const int G = sptr_bwd_grid(n);
+    const int S = sptr_split(n, split_a);
+    const int G = sptr_bwd_grid(n, S);
     float *slabs = reinterpret_cast<float *>(workspace);
     const float *rad = split_a > 0.f ? radial : nullptr;
     const int per = 3 * L * 3 * kHd;
@@ -775,18 +833,26 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
                "u2mkd_sptr_attention_backward: qc_span=%d (window / quant size) must be in 1..%d, qgl=%d below %d, L=%d <= 48 "
                "(every U2MKD configuration has span = qgl = 24)", qc_span, kNB, qgl, kNB, L);
     const int tabf = L * 3 * kTabRow;
-    size_t lds_q = ((size_t)3 * tabf + (size_t)kSptrThreads * (2 * kHistTab + 1) + 2 * kSptrThreads * kVecRow +
-                    kSptrThreads * 3) * sizeof(float);
-    size_t lds_k = ((size_t)3 * tabf + (size_t)kSptrThreads * (kHistTab + 1) + kSptrThreads * kVecRow +
-                    kSptrThreads * 3) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_query_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-    hipLaunchKernelGGL(sptr_bwd_query_kernel, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse, delta,
-                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs, ly);
-    hipLaunchKernelGGL(sptr_bwd_key_kernel, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse, delta,
-                       sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs, ly);
+    const int tpb = kSptrThreads / S;
+    size_t lds_q = ((size_t)3 * tabf + (size_t)tpb * (2 * kHistTab + 1) + 2 * tpb * kVecRow + tpb * 3) * sizeof(float);
+    size_t lds_k = ((size_t)3 * tabf + (size_t)tpb * (kHistTab + 1) + tpb * kVecRow + tpb * 3) * sizeof(float);
+#define U2_SPTR_BWD(SS)                                                                                                  \
+    do {                                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_query_kernel<SS>),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_key_kernel<SS>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                               \
+        hipLaunchKernelGGL(sptr_bwd_query_kernel<SS>, dim3(G, h), dim3(kSptrThreads), lds_q, st, q, k, v, dout, lse,     \
+                           delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, slabs, ly);              \
+        hipLaunchKernelGGL(sptr_bwd_key_kernel<SS>, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse,       \
+                           delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs, ly);          \
+    } while (0)
+    if (S == 16) U2_SPTR_BWD(16);
+    else if (S == 8) U2_SPTR_BWD(8);
+    else if (S == 4) U2_SPTR_BWD(4);
+    else if (S == 2) U2_SPTR_BWD(2);
+    else U2_SPTR_BWD(1);
+#undef U2_SPTR_BWD
     hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, 2 * G, L, h,
                        dtq, dtk, dtv);
     return check_launch("u2mkd_sptr_attention_backward");

@@ -34,7 +34,7 @@ def _rows_linear(x, weight, bias):
     """x [N, Cin] @ weight[Cout, Cin(,1)]^T + bias on the MFMA pipeline when the shapes allow (k = 1 Conv1d
     weights are [Cout, Cin, 1])."""
     w = weight.squeeze(-1) if weight.dim() == 3 else weight
-    if x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+    if x.is_cuda and w.shape[1] % 4 == 0:
         from .torchsparse.nn import functional as spf
         return spf.linear(x, w, bias)
     return F.linear(x, w, bias)
@@ -69,7 +69,9 @@ class IA_Layer(nn.Module):
         img_feats = img_feats.contiguous()
         ri = _rows_linear(_rows_bn(self.fc1[0], img_feats, relu=True), self.fc1[2].weight, self.fc1[2].bias)
         rp = _rows_linear(point_feats.contiguous(), self.fc2.weight, self.fc2.bias)
-        att = torch.sigmoid(F.linear(torch.tanh(ri + rp), self.fc3.weight, self.fc3.bias))          # [N, 1]
+        # (fc3 has ONE output feature: rocBLAS answers its weight gradient -- a [1, rc] product over K = N rows -- with a
+        # single-tile split-K kernel of ~0.3 ms; the row operator pads the output to a column block and is deterministic)
+        att = torch.sigmoid(_rows_linear(torch.tanh(ri + rp), self.fc3.weight, self.fc3.bias))      # [N, 1]
         img = _rows_bn(self.conv1[1], _rows_linear(img_feats, self.conv1[0].weight, self.conv1[0].bias), relu=True)
         return img * att
 
