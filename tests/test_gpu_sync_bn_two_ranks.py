@@ -293,3 +293,91 @@ def test_hip_sync_batchnorm2d_two_ranks_equals_batchnorm2d_over_all_images(hip, 
         assert got[rk]['tracked'] == 3
         assert float((got[rk]['running_mean'].double() - ref.running_mean).abs().max()) < 1e-5
         assert float((got[rk]['running_var'].double() - ref.running_var).abs().max()) < 1e-4
+
+
+_CHILD_HEAD = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+import torch, torch.distributed as dist
+from u2mkd_amd import camera
+from u2mkd_amd.lidar.point_voxel import SparseSyncBatchNorm
+from u2mkd_amd.pixel_head import sampled_head_applies, sampled_pixel_logits
+from u2mkd_amd.synth import synth_kd_batch
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+torch.cuda.set_device(0)
+hw, low, c, classes, ncam = (64, 112), (32, 56), 32, 17, 6
+b = synth_kd_batch(900, 2, seed=9, image_hw=hw)['student']
+pc = [torch.from_numpy(b['pixel_coordinates'][rank]).cuda()]          # rank r holds sample r
+ms = [torch.from_numpy(b['masks'][rank]).cuda()]
+g = torch.Generator().manual_seed(21)
+head = camera.BNReluConv(c, classes, k=1)
+with torch.no_grad():
+    head.norm.weight.copy_(torch.rand(c, generator=g) + 0.5); head.norm.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    head.conv.weight.copy_(torch.randn(classes, c, 1, 1, generator=g) * 0.2)
+head = SparseSyncBatchNorm.convert_sync_batchnorm(head).cuda().train()
+x_all = torch.randn(2 * ncam, c, *low, generator=g) * 1.7 + 3.0
+gy_all = [torch.randn(m.shape[1], classes, generator=g) for m in b['masks']]
+x = x_all[rank * ncam:(rank + 1) * ncam].cuda().requires_grad_(True)
+assert isinstance(head.norm, camera.SyncBatchNorm2d) and sampled_head_applies(x, head)
+y = sampled_pixel_logits(x, head, pc, ms, hw, 1, ncam)
+y.backward(gy_all[rank].cuda())
+torch.save({'y': y.detach().cpu(), 'dx': x.grad.cpu(), 'dgamma': head.norm.weight.grad.cpu(), 'dbeta': head.norm.bias.grad.cpu(),
+            'dw': head.conv.weight.grad.cpu(), 'running_mean': head.norm.running_mean.cpu(), 'running_var': head.norm.running_var.cpu()}, out)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_sampled_pixel_head_two_ranks_equals_the_dense_head_over_both_samples(hip, tmp_path):
+    """The sampled pixel head (u2mkd_amd/pixel_head.py) under SyncBatchNorm: two processes with one sample (6 cameras)
+    each against ONE dense fp64 evaluation over both samples -- logits and map gradient per rank, the BatchNorm affine
+    and classifier gradients summed over the ranks, running statistics over all 12 up-sampled maps."""
+    import torch.nn.functional as F
+    from test_gpu_pixel_head import _dense_fp64
+    from u2mkd_amd import camera
+    from u2mkd_amd.synth import synth_kd_batch
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    outs = [str(tmp_path / f'h{r}.pt') for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_HEAD, ROOT, str(r), '2', str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    got = [torch.load(o) for o in outs]
+    hw, low, c, classes, ncam = (64, 112), (32, 56), 32, 17, 6
+    b = synth_kd_batch(900, 2, seed=9, image_hw=hw)['student']
+    pc = [torch.from_numpy(p).cuda() for p in b['pixel_coordinates']]
+    ms = [torch.from_numpy(m).cuda() for m in b['masks']]
+    g = torch.Generator().manual_seed(21)
+    head = camera.BNReluConv(c, classes, k=1)
+    with torch.no_grad():
+        head.norm.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        head.norm.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        head.conv.weight.copy_(torch.randn(classes, c, 1, 1, generator=g) * 0.2)
+    head = head.cuda().train()
+    x_all = torch.randn(2 * ncam, c, *low, generator=g) * 1.7 + 3.0
+    gy_all = [torch.randn(m.shape[1], classes, generator=g) for m in b['masks']]
+    xd = x_all.cuda().double().requires_grad_(True)
+    want, u = _dense_fp64(xd, head, pc, ms, hw, 2, ncam)
+    want.backward(torch.cat(gy_all).cuda().double())
+    n0 = ms[0].shape[1]
+    scale = float(want.abs().max())
+    for r, sl, isl in ((0, slice(0, n0), slice(0, ncam)), (1, slice(n0, None), slice(ncam, None))):
+        assert float((got[r]['y'].double() - want.detach()[sl].cpu()).abs().max()) < 2e-5 * scale, r
+        assert float((got[r]['dx'].double() - xd.grad[isl].cpu()).abs().max()) < 5e-5 * float(xd.grad.abs().max()), r
+    for key, ref in (('dgamma', head.norm.weight.grad), ('dbeta', head.norm.bias.grad), ('dw', head.conv.weight.grad)):
+        tot = got[0][key].double() + got[1][key].double()
+        assert float((tot - ref.cpu().double()).abs().max()) < 5e-5 * float(ref.abs().max()), key
+    m = 0.1
+    mean, var = u.detach().mean((0, 2, 3)).cpu(), u.detach().var((0, 2, 3), unbiased=True).cpu()
+    for r in range(2):
+        assert float((got[r]['running_mean'].double() - m * mean).abs().max()) < 1e-5
+        assert float((got[r]['running_var'].double() - ((1 - m) + m * var)).abs().max()) < 1e-5 * float(var.max())

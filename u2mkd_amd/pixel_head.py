@@ -64,10 +64,12 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, u, weight, bias, bn, size):
+        from .torchsparse.nn.functional import _sync_group
         n, c, h, w = x.shape
         big_h, big_w = size
         count = n * big_h * big_w
         training = bn.training or bn.running_mean is None
+        sync = _sync_group(bn) if training else None
         coef = None
         if training:
             _, a, ay = _interp_coefficients(h, big_h, x.device)
@@ -81,12 +83,29 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
             m1 = sums[:, 0] / count
             mean = x[0, :, 0, 0].double() + m1
             var = (sums[:, 1] / count - m1 * m1).clamp_(min=0.0)
+            if sync is not None:
+                # SyncBatchNorm: every rank's (mean, M2, count) in ONE all_gather of [2C+1] floats, merged in rank order
+                # (Chan) -- the statistics torch.nn.SyncBatchNorm takes over the ranks' up-sampled maps
+                from .torchsparse.nn.functional import _gather_rows
+                group, world = sync
+                row = torch.cat([mean, var * count, torch.full((1,), float(count), dtype=torch.float64, device=x.device)]).float()
+                rows = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+                if world > 1:
+                    _gather_rows(rows, row, group)
+                else:
+                    rows[0] = row
+                rows = rows.double()
+                cnt = rows[:, 2 * c]
+                count = cnt.sum()                               # (a device scalar: no host round trip)
+                mean = (rows[:, :c] * cnt[:, None]).sum(0) / count
+                var = ((rows[:, c:2 * c] + cnt[:, None] * (rows[:, :c] - mean) ** 2).sum(0) / count).clamp_(min=0.0)
             if bn.track_running_stats and bn.running_mean is not None:
                 with torch.no_grad():
                     bn.num_batches_tracked.add_(1)
                     m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                     bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
-                    bn.running_var.mul_(1.0 - m).add_((var * (count / max(count - 1, 1))).to(bn.running_var.dtype), alpha=m)
+                    unbias = count / (count - 1).clamp(min=1) if torch.is_tensor(count) else count / max(count - 1, 1)
+                    bn.running_var.mul_(1.0 - m).add_((var * unbias).to(bn.running_var.dtype), alpha=m)
         else:
             mean, var = bn.running_mean.double(), bn.running_var.double()
         invstd = (var + bn.eps).rsqrt().float()
@@ -94,14 +113,14 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
         xhat = (u - mean) * invstd
         y = torch.relu(xhat * weight + bias)
         ctx.save_for_backward(x, xhat, y, weight, invstd, mean)
-        ctx.meta = (training, count, coef)
+        ctx.meta = (training, count, coef, sync)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         x, xhat, y, weight, invstd, mean = ctx.saved_tensors
-        training, count, coef = ctx.meta
+        training, count, coef, sync = ctx.meta
         g = gy * (y > 0)
         dbeta = g.sum(0)
         dgamma = (g * xhat).sum(0)
@@ -111,8 +130,14 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
         if training:
             # dU = scale * (g - mean(g) - xhat * mean(g * xhat)) over ALL count pixels; g = 0 off the samples.  The two
             # mean terms reach every pixel: c0 + c1 * U, folded through the up-sampling by the dense-gradient kernel.
-            c1 = -(scale * invstd) * (dgamma / count)
-            c0 = -scale * (dbeta / count) - c1 * mean
+            sb, sg = dbeta, dgamma
+            if sync is not None and sync[1] > 1:          # the two sums over every rank's pixels: ONE all_reduce of [2C]
+                from .torchsparse.nn.functional import _sum_over_ranks
+                both = torch.cat([dbeta, dgamma])
+                _sum_over_ranks(both, sync[0])
+                sb, sg = both[:dbeta.numel()], both[dbeta.numel():]
+            c1 = -(scale * invstd) * (sg / count)
+            c0 = -scale * (sb / count) - c1 * mean
             a, b, ay, ax = coef
             n, c, h, w = x.shape
             dx = torch.empty_like(x)
@@ -122,11 +147,14 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
 
 
 def sampled_head_applies(x, head):
-    """fp32 device map, plain (non-synchronising) BatchNorm2d head, no autocast.  (SyncBatchNorm needs the statistics
-    of every rank: the dense path serves DistributedDataParallel.)"""
-    from .camera import BatchNorm2d
-    return (_ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
-            and type(head.norm) is BatchNorm2d and head.conv.bias is None and head.conv.kernel_size == (1, 1))
+    """A device map and a BatchNorm2d -> ReLU -> bias-free 1x1 convolution head (this package's BatchNorm2d, or the
+    SyncBatchNorm2d DistributedDataParallel training converts it to: its statistics then take one small collective per
+    pass, like every other synchronised BatchNorm).  Under autocast the tail is evaluated in fp32 from the reduced map
+    (nn.BatchNorm is an fp32 operator under autocast anyway)."""
+    from .camera import BatchNorm2d, SyncBatchNorm2d
+    return (_ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and type(head.norm) in (BatchNorm2d, SyncBatchNorm2d) and head.norm.momentum is not None
+            and head.conv.bias is None and head.conv.kernel_size == (1, 1))
 
 
 def sampled_pixel_logits(x, head, pixel_coordinates, masks, im_size, ib, ncam):
@@ -136,6 +164,13 @@ def sampled_pixel_logits(x, head, pixel_coordinates, masks, im_size, ib, ncam):
     from .fusion import _NchwToRows, _c2l_plan
     from .torchsparse.nn import functional as spf
     L.require_cuda(x)
+    with torch.autocast('cuda', enabled=False):
+        return _sampled_pixel_logits(x.float(), head, pixel_coordinates, masks, im_size, ib, ncam)
+
+
+def _sampled_pixel_logits(x, head, pixel_coordinates, masks, im_size, ib, ncam):
+    from .fusion import _NchwToRows, _c2l_plan
+    from .torchsparse.nn import functional as spf
     big_h, big_w = im_size
     n, c, h, w = x.shape
     assert n == ib * ncam, (n, ib, ncam)
@@ -155,6 +190,6 @@ def sampled_pixel_logits(x, head, pixel_coordinates, masks, im_size, ib, ncam):
     ia, wa = spf._plan(masks[0], 'up_%d_%d_%d_%d' % (big_h, big_w, h, w), compose, *masks[1:], *pixel_coordinates)
     rows = _NchwToRows.apply(x.view(ib, ncam, c, h, w))
     u = spf.spdevoxelize(rows, ia, wa)                                              # [4 * points, C]
-    y = _UpsampledBatchNormReLU.apply(x, u, head.norm.weight, head.norm.bias, head.norm, (big_h, big_w))
-    z = spf.linear(y, head.conv.weight.view(head.conv.out_channels, c), None)      # [4 * points, classes]
+    y = _UpsampledBatchNormReLU.apply(x, u, head.norm.weight.float(), head.norm.bias.float(), head.norm, (big_h, big_w))
+    z = spf.linear(y, head.conv.weight.float().view(head.conv.out_channels, c), None)      # [4 * points, classes]
     return (z.view(-1, 4, z.shape[1]) * w8f[:, :4].unsqueeze(-1)).sum(1)
