@@ -163,6 +163,14 @@ class SyncBatchNorm2d(nn.SyncBatchNorm):
             if self.num_batches_tracked is not None:
                 self.num_batches_tracked.add_(1)
             return _SyncBatchNorm2dFunction.apply(x, self.weight, self.bias, residual, self, relu, sync[0], sync[1])
+        if (sync is None and _HIP_BN2D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+                and x.numel() > 0 and not torch.is_autocast_enabled() and (self.momentum is not None or not self.training)
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape))):
+            # nothing to synchronise with (one rank, or evaluation): the fused single-process pass of BatchNorm2d above
+            # (torch.nn.SyncBatchNorm makes the same decision and calls F.batch_norm)
+            if residual is not None:
+                residual = residual.contiguous()
+            return _BatchNorm2dFunction.apply(x, self.weight, self.bias, residual, self, relu)
         y = super().forward(x)
         if residual is not None:
             y = y + residual

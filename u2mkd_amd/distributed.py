@@ -63,9 +63,19 @@ def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int 
         from .lidar.point_voxel import SparseSyncBatchNorm
         model = SparseSyncBatchNorm.convert_sync_batchnorm(model)
     ids = [torch.cuda.current_device()] if on_gpu else None
-    return torch.nn.parallel.DistributedDataParallel(
+    # broadcast_buffers=False: DDP's default re-broadcasts every buffer from rank 0 before each forward.  The only
+    # buffers here are BatchNorm running statistics and step counters, and with every BatchNorm synchronised (or frozen:
+    # the teacher) each rank computes the same values from the same all-gathered statistics in the same order, so the
+    # broadcast would move hundreds of small tensors per step to overwrite them with themselves.
+    ddp = torch.nn.parallel.DistributedDataParallel(
         model, device_ids=ids, find_unused_parameters=False, gradient_as_bucket_view=True,
-        bucket_cap_mb=bucket_cap_mb)
+        bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
+    # The built-in reduction divides every parameter's gradient view by the world size as it becomes ready: one tiny
+    # kernel per parameter per step (485 for the KD student, on the backward's stream).  The stock all-reduce hook does
+    # the same division once per BUCKET before the same all-reduce.
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    ddp.register_comm_hook(state=None, hook=default_hooks.allreduce_hook)
+    return ddp
 
 
 def max_over_ranks(value: float) -> float:
