@@ -143,6 +143,24 @@ def test_downsample_rejects_coordinates_outside_the_key_range(F, bad):
     assert np.array_equal(out, want)
 
 
+def test_deferred_range_check_raises_once_at_the_end_of_the_context(F):
+    """Inside `deferred_range_check()` (point_voxel.prepare_geometry builds the four levels of the encoder in it) the
+    flag of every spdownsample call is read once, when the context ends."""
+    ok = np.array([[131070, -131072, 6, 0], [2, 4, 6, 511], [0, 0, 0, 0], [1, 1, 1, 0]], np.int32)
+    bad = np.concatenate([ok, np.array([[0, 0, 0, 512]], np.int32)])
+    with F.deferred_range_check():
+        a = F.spdownsample(_dev(ok), 2, 2, 1)
+        b = F.spdownsample(a, 2, 2, 2)
+    assert np.array_equal(a.cpu().numpy(), R.spdownsample(ok, 2, 2, 1)) and b.shape[0] > 0
+    with pytest.raises(ValueError):
+        with F.deferred_range_check():
+            F.spdownsample(_dev(ok), 2, 2, 1)
+            F.spdownsample(_dev(bad), 2, 2, 1)          # no error here ...
+            F.spdownsample(_dev(ok), 2, 2, 1)
+        # ... but here
+    assert np.array_equal(F.spdownsample(_dev(ok), 2, 2, 1).cpu().numpy(), R.spdownsample(ok, 2, 2, 1))   # flag cleared
+
+
 def test_floor_coords_kernel_equals_the_torch_formula(F):
     """u2mkd_floor_coords vs torch.floor(xyz / s).int() * s | b.int() bit for bit, negative and fractional inputs."""
     from u2mkd_amd.lidar.point_voxel import _floor_coords

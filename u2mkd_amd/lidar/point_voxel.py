@@ -65,7 +65,8 @@ def prepare_geometry(x: SparseTensor, pres, vres):
     prepare batch k+1 while step k's backward drains (train.KDStep ``prefetch=``)."""
     z = PointTensor(x.F, x.C.float())
     x0 = initial_voxelize(z, pres, vres)
-    spf.prefetch_kmaps(x0, KMAP_SPECS)
+    with spf.deferred_range_check():          # the four down-samplings' out-of-range flag: one read instead of four
+        spf.prefetch_kmaps(x0, KMAP_SPECS)
     return z, x0
 
 

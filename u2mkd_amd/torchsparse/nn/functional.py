@@ -270,17 +270,52 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     flag = _range_flag(coords.device)
     L.call('u2mkd_downsample_keys_checked', L.ptr(coords), n, ss[0], ss[1], ss[2], L.ptr(keys), L.ptr(flag), L.stream())
     uniq = torch.unique(keys)  # sorted int64 == (b,x,y,z) lexicographic
-    # (the unique above has just synchronised the stream: reading the 4-byte flag costs no queue drain)
-    if n and int(flag) != 0:
-        flag.zero_()
-        raise ValueError('spdownsample: coordinates outside the packed key range (|x|, |y|, |z| < 131072 voxels, '
-                         '0 <= batch index < 512)')
+    # (the unique above has just synchronised the stream: reading the 4-byte flag costs no queue drain -- but it is a
+    # second round trip per level; a caller that builds several levels in a row reads the flag once, at the end)
+    if _DEFERRED_RANGE_CHECK[0]:
+        _DEFERRED_RANGE_CHECK.append(flag)
+    elif n:
+        _check_range_flag(flag)
     out = torch.empty(uniq.shape[0], 4, dtype=torch.int32, device=coords.device)
     L.call('u2mkd_unpack_keys', L.ptr(uniq), uniq.shape[0], L.ptr(out), L.stream())
     return out
 
 
 _RANGE_FLAGS = {}
+_DEFERRED_RANGE_CHECK = [False]           # [active, flag, flag, ...]
+
+
+def _check_range_flag(flag):
+    if int(flag) != 0:
+        flag.zero_()
+        raise ValueError('spdownsample: coordinates outside the packed key range (|x|, |y|, |z| < 131072 voxels, '
+                         '0 <= batch index < 512)')
+
+
+class deferred_range_check:
+    """spdownsample calls inside this context leave their out-of-range flag unread; the flag (sticky on the device) is
+    read ONCE when the context ends -- one host round trip for a whole pyramid of down-samplings instead of one per
+    level.  The error is the same, raised a few launches later."""
+
+    def __enter__(self):
+        self._outer = _DEFERRED_RANGE_CHECK[0]
+        _DEFERRED_RANGE_CHECK[0] = True
+        self._start = len(_DEFERRED_RANGE_CHECK)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        flags = _DEFERRED_RANGE_CHECK[self._start:]
+        del _DEFERRED_RANGE_CHECK[self._start:]
+        _DEFERRED_RANGE_CHECK[0] = self._outer
+        if exc_type is None and not self._outer:
+            seen = set()
+            for f in flags:
+                if id(f) not in seen:
+                    seen.add(id(f))
+                    _check_range_flag(f)
+        elif self._outer:
+            _DEFERRED_RANGE_CHECK.extend(flags)
+        return False
 
 
 def _range_flag(device):
