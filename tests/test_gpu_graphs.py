@@ -120,7 +120,7 @@ def test_kd_step_with_captured_camera_side_equals_eager_step(hip, monkeypatch):
         losses[mode] = [float(run(d)) for _ in range(3)]
         if mode:
             pieces = run.model.model_s._pieces
-            assert sorted(pieces) == sorted(['head', 'stage1', 'stage2', 'stage3', 'l2c0', 'l2c1', 'l2c2', 'l2c3', 'decoder_64x112'])
+            assert sorted(pieces) == sorted(['head', 'stage1', 'stage2', 'stage3', 'l2c0', 'l2c1', 'l2c2', 'l2c3', 'decoder_low'])
             for name, p in pieces.items():
                 assert p._records and all(r is not None for r in p._records.values()), name
             for n, p in run.model.model_s.named_parameters():

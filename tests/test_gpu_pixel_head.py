@@ -126,9 +126,10 @@ def test_student_uses_the_sampled_head_and_matches_the_dense_path(hip, monkeypat
                      ms_.classifier_pix.norm.running_var.clone()))
     assert len(used) == 1
     # two dense passes calibrate what run-to-run differences of the library convolutions do to each quantity (the stem's
-    # gradient passes through the whole camera branch); the sampled pass must sit within that band or 1e-4
+    # gradient passes through the whole camera branch: 2e-4 .. 2e-3 between two identical dense passes); the sampled pass
+    # must sit within that band (one pair is a noisy estimate of it: factor 10) or 1e-4 -- a wrong term would be O(0.1)
     for a, bb, cc, name in zip(outs[1], outs[2], outs[0], ('x_pix', 'classifier', 'gamma', 'last blend', 'stem conv', 'running_var')):
         err = float((a - bb).norm() / bb.norm())
         floor = float((cc - bb).norm() / bb.norm())
         print('PIXHEAD', name, 'sampled vs dense %.2e   dense vs dense %.2e' % (err, floor))
-        assert err < max(1e-4, 4.0 * floor), (name, err, floor)
+        assert err < max(1e-4, 10.0 * floor), (name, err, floor)

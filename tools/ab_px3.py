@@ -47,4 +47,5 @@ def main(shapes=None):
 
 
 if __name__ == '__main__':
-    main()
+    # optional shapes on the command line: stride,cin,cout ...
+    main([tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or None)
