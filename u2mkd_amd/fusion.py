@@ -30,13 +30,13 @@ __all__ = ['IA_Layer', 'Atten_Fusion_Conv', 'L2CAILayer', 'L2CFusion', 'feature_
            'l2c_scatter', 'feature_fetch', 'l2c_scatter_torch', 'c2l_gather_torch']
 
 
-def _rows_linear(x, weight, bias):
+def _rows_linear(x, weight, bias, before=None):
     """x [N, Cin] @ weight[Cout, Cin(,1)]^T + bias on the MFMA pipeline when the shapes allow (k = 1 Conv1d
-    weights are [Cout, Cin, 1])."""
+    weights are [Cout, Cin, 1]).  ``before`` = the BatchNorm the result goes straight into, if any."""
     w = weight.squeeze(-1) if weight.dim() == 3 else weight
     if x.is_cuda and w.shape[1] % 4 == 0:
         from .torchsparse.nn import functional as spf
-        return spf.linear(x, w, bias)
+        return spf.linear(x, w, bias, bias_feeds_batchnorm=before is not None and before.training)
     return F.linear(x, w, bias)
 
 
@@ -72,7 +72,7 @@ class IA_Layer(nn.Module):
         # (fc3 has ONE output feature: rocBLAS answers its weight gradient -- a [1, rc] product over K = N rows -- with a
         # single-tile split-K kernel of ~0.3 ms; the row operator pads the output to a column block and is deterministic)
         att = torch.sigmoid(_rows_linear(torch.tanh(ri + rp), self.fc3.weight, self.fc3.bias))      # [N, 1]
-        img = _rows_bn(self.conv1[1], _rows_linear(img_feats, self.conv1[0].weight, self.conv1[0].bias), relu=True)
+        img = _rows_bn(self.conv1[1], _rows_linear(img_feats, self.conv1[0].weight, self.conv1[0].bias, before=self.conv1[1]), relu=True)
         return img * att
 
 
@@ -87,7 +87,7 @@ class Atten_Fusion_Conv(nn.Module):
         """[N, P], [N, I] -> [N, outplanes] (fusion_blocks.py:49-68, row-major)."""
         img = self.ai_layer(img_features, point_features)
         fused = torch.cat([point_features, img], dim=1)
-        return _rows_bn(self.bn1, _rows_linear(fused, self.conv1.weight, self.conv1.bias), relu=True)
+        return _rows_bn(self.bn1, _rows_linear(fused, self.conv1.weight, self.conv1.bias, before=self.bn1), relu=True)
 
 
 class L2CAILayer(nn.Module):

@@ -63,6 +63,9 @@ class FusedSequential(nn.Sequential):
                 else:
                     x = spf.batch_norm(x, m, True)
                 i += 2
+            elif isinstance(m, PointLinear) and type(nxt).__name__ in _FUSABLE_BN and nxt.training and not isinstance(x, SparseTensor):
+                x = spf.linear(x, m.weight, m.bias, bias_feeds_batchnorm=True)     # (its bias gradient is identically zero)
+                i += 1
             else:
                 x = m(x)
                 i += 1

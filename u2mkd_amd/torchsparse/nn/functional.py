@@ -759,7 +759,7 @@ class LinearFunction(Function):
     gradient on the pair kernel's dense mode, weight gradient on the pair-list wgrad kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bias_grad_is_zero=False):
         L.require_cuda(x, weight)
         weight = weight.contiguous().float()
         want16 = bf16_rows()
@@ -772,6 +772,7 @@ class LinearFunction(Function):
             raise RuntimeError('linear: in/out features must be multiples of 4 on the HIP path')
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_grad_is_zero = bool(bias_grad_is_zero)
         if x.shape[0] == 0:
             return x.new_zeros(0, weight.shape[0])
         b = bias.contiguous().float() if bias is not None else None
@@ -788,7 +789,7 @@ class LinearFunction(Function):
         cout, cin = weight.shape
         gx = gw = gb = None
         if n == 0:
-            return x.new_zeros(x.shape), torch.zeros_like(weight), (weight.new_zeros(cout) if ctx.has_bias else None)
+            return x.new_zeros(x.shape), torch.zeros_like(weight), (weight.new_zeros(cout) if ctx.has_bias else None), None
         if ctx.needs_input_grad[0] and ctx.x3:
             gx = _dense_x3(g, weight, False)
         elif ctx.needs_input_grad[0]:
@@ -804,28 +805,32 @@ class LinearFunction(Function):
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin,
                    L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), L.stream())
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0, dtype=torch.float32)
+            # a bias that feeds a train-mode BatchNorm has the gradient sum(dY) = 0 identically (BatchNorm's input gradient
+            # sums to zero over the batch: sum(x_hat) = 0); the reduction over [N, C] would compute rounding noise
+            gb = weight.new_zeros(cout) if ctx.bias_grad_is_zero else g.sum(0, dtype=torch.float32)
         if gx is not None and gx.dtype != ctx.in_dtype:
             gx = gx.to(ctx.in_dtype)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, bias_feeds_batchnorm=False):
     """nn.functional.linear for [N, C] feature matrices on the HIP path (CPU tensors raise).  in / out features that
     are not multiples of 4 (the 17-class heads) are zero-padded to the next multiple of 32 / 4 -- rows of `weight` and
     entries of `bias` for the outputs, columns of `weight` and of `x` for the inputs; differentiable, the padding
-    receives zero gradient and the extra output columns are dropped (as conv3d does for odd channel counts)."""
+    receives zero gradient and the extra output columns are dropped (as conv3d does for odd channel counts).
+    ``bias_feeds_batchnorm``: the output goes straight into a BatchNorm in training mode -- the bias gradient is then
+    exactly zero and is returned as such instead of being reduced from the output gradient."""
     cout, cin = weight.shape
     pin = (-cin) % 4
     pout = 0 if cout % 4 == 0 else ((-cout) % 32 if cin % 32 == 0 else (-cout) % 4)
     if pin == 0 and pout == 0:
-        return LinearFunction.apply(x, weight, bias)
+        return LinearFunction.apply(x, weight, bias, bias_feeds_batchnorm)
     if pin:
         x = torch.nn.functional.pad(x, (0, pin))
     weight = torch.nn.functional.pad(weight, (0, pin, 0, pout))
     if bias is not None and pout:
         bias = torch.nn.functional.pad(bias, (0, pout))
-    return LinearFunction.apply(x, weight, bias)[:, :cout]
+    return LinearFunction.apply(x, weight, bias, bias_feeds_batchnorm)[:, :cout]
 
 
 _OVERLAP_WGRAD = os.environ.get('U2MKD_OVERLAP_WGRAD', '1') != '0'
