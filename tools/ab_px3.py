@@ -1,7 +1,7 @@
 """A/B on the GPU: wide-layer pair kernel in f32 MFMA (conv_pairs_kernel) vs bf16x3 (conv_px3_kernel), forward and
 the swapped-role walk (input gradient), with the deviation between the two and against an fp64 reference of a
 sample of rows."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import ts_ref as R
 from u2mkd_amd import _lib as L
