@@ -1,6 +1,6 @@
 """KD step: host time per step (until the Python call returns, queue still draining) against wall time per step,
 the host floor on a tiny scene, the sync points of a step, and a cProfile of the host side."""
-import sys, time, os; sys.path.insert(0, '.')
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from u2mkd_amd import lidar, train as T, kd as KD
 from u2mkd_amd.synth import synth_kd_batch

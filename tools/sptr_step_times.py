@@ -1,7 +1,7 @@
 """Duration of every sptr attention launch of one KD step (student + teacher, forward and backward), by HIP events
 around the C-ABI calls; also the window statistics of every call (tokens, mean / max window length).
 Run once per U2MKD_SPTR_SPLIT value for an A/B of the key-split kernels.   python tools/sptr_step_times.py"""
-import os, sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from u2mkd_amd import _lib as L, train as T
 from tools.kd_host import build
