@@ -431,6 +431,25 @@ int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t 
                             const float *mean, const float *invstd, const float *gamma, const float *beta,
                             int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx, u2mkd_stream_t s);
 
+/* the same three pieces with the residual branch of a ResidualBlock (build_blocks.py:80-83 under SyncBatchNorm):
+ * y = relu(bn(x) + res) in the apply pass; the backward recomputes the mask from x and res, dres = the masked dy */
+int u2mkd_bn_apply_res(const float *x, const float *res, int64_t n, int32_t c, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int32_t relu, float *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_local_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
+                                const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
+                                float *sums, u2mkd_stream_t s);
+int u2mkd_bn_backward_apply_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *total_n,
+                                const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                const float *sums, float *dx, float *dres, u2mkd_stream_t s);
+int u2mkd_bn_apply_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int32_t relu, void *y, u2mkd_stream_t s);
+int u2mkd_bn_backward_local_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *mean,
+                                     const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
+                                     float *sums, u2mkd_stream_t s);
+int u2mkd_bn_backward_apply_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *total_n,
+                                     const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                     int32_t relu, const float *sums, void *dx, void *dres, u2mkd_stream_t s);
+
 /* The BatchNorm entries above on BF16 ROWS (BASELINE.json configs[4]; under autocast the reference's nn.BatchNorm1d takes
  * and returns half rows while its statistics stay fp32): x, res, y, dy, dx, dres are bf16 [n, c]; gamma, beta, running
  * statistics, mean, invstd, partial, dgamma, dbeta, stats and sums are fp32 exactly as above; every value is rounded to

@@ -44,6 +44,14 @@ for relu in (False, True):
     res['relu%d' % relu] = {'y': y.detach().cpu(), 'dx': x.grad.cpu(), 'dgamma': bn.weight.grad.cpu(), 'dbeta': bn.bias.grad.cpu()}
 res['running_mean'], res['running_var'] = bn.running_mean.cpu(), bn.running_var.cpu()
 res['tracked'] = int(bn.num_batches_tracked)
+# the tail of a ResidualBlock: relu(bn(x) + r) inside the synchronising pieces
+rs = [torch.randn(n, C, generator=g) for n in rows]
+x = xs[rank].cuda().requires_grad_(True)
+r = rs[rank].cuda().requires_grad_(True)
+bn.zero_grad(set_to_none=True)
+y = F.batch_norm(x, bn, True, r)
+(y * ws[rank].cuda()).sum().backward()
+res['res'] = {'y': y.detach().cpu(), 'dx': x.grad.cpu(), 'dres': r.grad.cpu(), 'dgamma': bn.weight.grad.cpu(), 'dbeta': bn.bias.grad.cpu()}
 torch.save(res, out)
 dist.barrier()
 dist.destroy_process_group()
@@ -104,6 +112,30 @@ def test_hip_sync_batchnorm_two_ranks_equals_batchnorm_over_all_rows(hip, tmp_pa
             want_db, want_dg = dyp[sl].sum(0), (dyp[sl] * xhat[sl]).sum(0)             # the rank's own sums
             assert float((k['dbeta'].double() - want_db).abs().max()) < 2e-4 * max(1.0, float(want_db.abs().max())), (relu, r)
             assert float((k['dgamma'].double() - want_dg).abs().max()) < 2e-4 * max(1.0, float(want_dg.abs().max())), (relu, r)
+    # the residual form: relu(bn(x) + r), y / dx / dres per rank, the rank's own dgamma / dbeta
+    rs = [torch.randn(n, C, generator=g) for n in rows]
+    x = torch.cat(xs).double().requires_grad_(True)
+    rr = torch.cat(rs).double().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    pre = bn(x) + rr
+    y = torch.relu(pre)
+    (y * torch.cat(ws).double()).sum().backward()
+    clear = pre.detach().abs() > 1e-4
+    xhat = (x.detach() - x.detach().mean(0)) / torch.sqrt(x.detach().var(0, unbiased=False) + bn.eps)
+    dyp = torch.cat(ws).double() * (pre.detach() > 0)
+    lo = 0
+    for r, n in enumerate(rows):
+        sl = slice(lo, lo + n)
+        lo += n
+        k = got[r]['res']
+        assert float((k['y'].double() - y.detach()[sl]).abs().max()) < 2e-5 * float(y.detach().abs().max()), r
+        assert float(((k['dx'].double() - x.grad[sl]) * clear[sl]).abs().max()) < 2e-4 * max(1.0, float(x.grad.abs().max())), r
+        assert float(((k['dres'].double() - rr.grad[sl]) * clear[sl]).abs().max()) < 2e-5 * max(1.0, float(rr.grad.abs().max())), r
+        want_db, want_dg = dyp[sl].sum(0), (dyp[sl] * xhat[sl]).sum(0)
+        assert float((k['dbeta'].double() - want_db).abs().max()) < 2e-4 * max(1.0, float(want_db.abs().max())), r
+        assert float((k['dgamma'].double() - want_dg).abs().max()) < 2e-4 * max(1.0, float(want_dg.abs().max())), r
     # running statistics after the two passes (global mean, unbiased global variance), equal on both ranks
     ref = torch.nn.BatchNorm1d(C, momentum=0.1).double().train()
     for _ in range(2):

@@ -91,6 +91,12 @@ SIGNATURES = {
     'u2mkd_bn_eval_forward_res_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_res_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'u2mkd_bn_local_stats_bf16': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    'u2mkd_bn_apply_res': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_bn_backward_local_res': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward_apply_res': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    'u2mkd_bn_apply_res_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_bn_backward_local_res_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn_backward_apply_res_bf16': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_bn_apply_bf16': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_bn_backward_local_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_apply_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),

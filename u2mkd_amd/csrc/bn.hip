@@ -495,20 +495,20 @@ static int bn_local_stats_impl(const T *x, int64_t n, int32_t c, float *partial,
 
 template <typename T>
 static int bn_apply_impl(const T *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
-                         const float *beta, int32_t relu, T *y, u2mkd_stream_t s) {
+                         const float *beta, int32_t relu, T *y, u2mkd_stream_t s, const T *res = nullptr) {
     U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_apply: c=%d must be a positive multiple of 4", c);
     if (n == 0) return 0;
     U2_REQUIRE(x && mean && invstd && y, "u2mkd_bn_apply: null pointer");
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), x, total4,
-                       c / 4, mean, invstd, gamma, beta, relu, y, (const T *)nullptr);
+                       c / 4, mean, invstd, gamma, beta, relu, y, res);
     return check_launch("u2mkd_bn_apply");
 }
 
 template <typename T>
 static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c, const float *mean, const float *invstd,
                                   const float *gamma, const float *beta, int32_t relu, float *partial, float *sums,
-                                  u2mkd_stream_t s) {
+                                  u2mkd_stream_t s, const T *res = nullptr) {
     U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward_local: c=%d must be a multiple of 4 in 4..1024", c);
     U2_REQUIRE(sums, "u2mkd_bn_backward_local: null pointer");
     hipStream_t st = as_stream(s);
@@ -519,7 +519,7 @@ static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c,
     U2_REQUIRE(dy && x && mean && invstd && partial, "u2mkd_bn_backward_local: null pointer");
     int nslab = (int)u2mkd_bn_num_slabs(n);
     hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
-                       invstd, gamma, beta, relu, partial, (const T *)nullptr);
+                       invstd, gamma, beta, relu, partial, res);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
                        sums, sums + c);
     return check_launch("u2mkd_bn_backward_local");
@@ -528,14 +528,13 @@ static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c,
 template <typename T>
 static int bn_backward_apply_impl(const T *dy, const T *x, int64_t n, int32_t c, const float *total_n, const float *mean,
                                   const float *invstd, const float *gamma, const float *beta, int32_t relu,
-                                  const float *sums, T *dx, u2mkd_stream_t s) {
+                                  const float *sums, T *dx, u2mkd_stream_t s, const T *res = nullptr, T *dres = nullptr) {
     U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_bn_backward_apply: c=%d must be a positive multiple of 4", c);
     if (n == 0) return 0;
     U2_REQUIRE(dy && x && total_n && mean && invstd && sums && dx, "u2mkd_bn_backward_apply: null pointer");
     int64_t total4 = n * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, as_stream(s), dy, x,
-                       total4, c / 4, 0.f, total_n, mean, invstd, gamma, beta, relu, sums, sums + c, dx, (const T *)nullptr,
-                       (T *)nullptr);
+                       total4, c / 4, 0.f, total_n, mean, invstd, gamma, beta, relu, sums, sums + c, dx, res, dres);
     return check_launch("u2mkd_bn_backward_apply");
 }
 
@@ -633,6 +632,25 @@ int u2mkd_bn_backward_apply(const float *dy, const float *x, int64_t n, int32_t 
     return bn_backward_apply_impl<float>(dy, x, n, c, total_n, mean, invstd, gamma, beta, relu, sums, dx, s);
 }
 
+/* the three pieces with the residual branch of a ResidualBlock: y = relu(bn(x) + res); the backward recomputes the mask
+ * from x and res and returns dres = the masked dy */
+int u2mkd_bn_apply_res(const float *x, const float *res, int64_t n, int32_t c, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int32_t relu, float *y, u2mkd_stream_t s) {
+    return bn_apply_impl<float>(x, n, c, mean, invstd, gamma, beta, relu, y, s, res);
+}
+
+int u2mkd_bn_backward_local_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *mean,
+                                const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
+                                float *sums, u2mkd_stream_t s) {
+    return bn_backward_local_impl<float>(dy, x, n, c, mean, invstd, gamma, beta, relu, partial, sums, s, res);
+}
+
+int u2mkd_bn_backward_apply_res(const float *dy, const float *x, const float *res, int64_t n, int32_t c, const float *total_n,
+                                const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                const float *sums, float *dx, float *dres, u2mkd_stream_t s) {
+    return bn_backward_apply_impl<float>(dy, x, n, c, total_n, mean, invstd, gamma, beta, relu, sums, dx, s, res, dres);
+}
+
 /* ---- the same on BF16 rows (x, res, y, dy, dx, dres are bf16 [n, c]; every statistic, parameter and sum fp32) ---- */
 int u2mkd_bn_train_forward_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *gamma,
                                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
@@ -675,6 +693,24 @@ int u2mkd_bn_backward_apply_bf16(const void *dy, const void *x, int64_t n, int32
                                  const float *invstd, const float *gamma, const float *beta, int32_t relu, const float *sums,
                                  void *dx, u2mkd_stream_t s) {
     return bn_backward_apply_impl<bf16row>(BF(dy), BF(x), n, c, total_n, mean, invstd, gamma, beta, relu, sums, BFW(dx), s);
+}
+
+int u2mkd_bn_apply_res_bf16(const void *x, const void *res, int64_t n, int32_t c, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int32_t relu, void *y, u2mkd_stream_t s) {
+    return bn_apply_impl<bf16row>(BF(x), n, c, mean, invstd, gamma, beta, relu, BFW(y), s, BF(res));
+}
+
+int u2mkd_bn_backward_local_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *mean,
+                                     const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
+                                     float *sums, u2mkd_stream_t s) {
+    return bn_backward_local_impl<bf16row>(BF(dy), BF(x), n, c, mean, invstd, gamma, beta, relu, partial, sums, s, BF(res));
+}
+
+int u2mkd_bn_backward_apply_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *total_n,
+                                     const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                     int32_t relu, const float *sums, void *dx, void *dres, u2mkd_stream_t s) {
+    return bn_backward_apply_impl<bf16row>(BF(dy), BF(x), n, c, total_n, mean, invstd, gamma, beta, relu, sums, BFW(dx), s,
+                                           BF(res), BFW(dres));
 }
 
 }  // extern "C"

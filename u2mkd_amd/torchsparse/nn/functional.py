@@ -1074,13 +1074,16 @@ class SyncBatchNormFunction(Function):
     stats / gather / elemt / ReLU kernels."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world, res=None):
         import torch.distributed as dist
         L.require_cuda(x)
         b16 = bf16_rows() or (x.dtype == torch.bfloat16 and _BF16_ROWS)
         sfx = '_bf16' if b16 else ''
         ctx.in_dtype = x.dtype
         x = _rows(x, b16)
+        if res is not None:          # relu(bn(x) + res): the tail of a ResidualBlock inside the apply pass
+            ctx.res_dtype = res.dtype
+            res = _rows(res, b16)
         n, c = x.shape
         dev = x.device
         st = L.stream()
@@ -1099,16 +1102,20 @@ class SyncBatchNormFunction(Function):
         L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(eps), float(momentum), L.ptr(running_mean),
                L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.ptr(total), L.stream())
         y = torch.empty_like(x)
-        L.call('u2mkd_bn_apply' + sfx, L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
-               L.ptr(y), L.stream())
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, total)
+        if res is None:
+            L.call('u2mkd_bn_apply' + sfx, L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
+                   L.ptr(y), L.stream())
+        else:
+            L.call('u2mkd_bn_apply_res' + sfx, L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                   L.ptr(beta), int(relu), L.ptr(y), L.stream())
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, total, res)
         ctx.relu, ctx.group, ctx.world = bool(relu), group, world
         return y
 
     @staticmethod
     def backward(ctx, dy):
         import torch.distributed as dist
-        x, gamma, beta, mean, invstd, total = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, total, res = ctx.saved_tensors
         b16 = x.dtype == torch.bfloat16
         sfx = '_bf16' if b16 else ''
         dy = _rows(dy, b16)
@@ -1117,18 +1124,30 @@ class SyncBatchNormFunction(Function):
         slabs = L.load().u2mkd_bn_num_slabs(n)
         partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        L.call('u2mkd_bn_backward_local' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-               L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
+        if res is None:
+            L.call('u2mkd_bn_backward_local' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                   L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
+        else:
+            L.call('u2mkd_bn_backward_local_res' + sfx, L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd),
+                   L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
         local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
         dx = torch.empty_like(x)
-        L.call('u2mkd_bn_backward_apply' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
-               L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.stream())
+        dres = None
+        if res is None:
+            L.call('u2mkd_bn_backward_apply' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(total), L.ptr(mean), L.ptr(invstd),
+                   L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.stream())
+        else:
+            dres = torch.empty_like(x)
+            L.call('u2mkd_bn_backward_apply_res' + sfx, L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(total), L.ptr(mean),
+                   L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(sums), L.ptr(dx), L.ptr(dres), L.stream())
+            if dres.dtype != ctx.res_dtype:
+                dres = dres.to(ctx.res_dtype)
         if dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return (dx, local[c:] if gamma is not None else None, local[:c] if beta is not None else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, dres)
 
 
 def _sync_group(bn):
@@ -1170,10 +1189,7 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
     if residual is not None and not relu:
         raise ValueError('batch_norm: a residual input is fused together with the ReLU only')
     if sync is not None:
-        if residual is not None:     # the synchronising path keeps the add and the ReLU as separate passes
-            y = SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, False, sync[0], sync[1])
-            return torch.relu(y + residual)
-        return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1])
+        return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1], residual)
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
     return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual)
