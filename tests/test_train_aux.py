@@ -63,6 +63,28 @@ def _train_a_bit(r, steps=3):
         r.sched.step()
 
 
+def test_optimizer_variants_split_the_sphereformer_blocks_like_the_reference():
+    """core/builder.py:670-716: `sgd_spformer` / `adamw_spformer` give the parameters whose name contains
+    "transformer_block" their own group at a reduced learning rate; `adam` / `adamw` take everything at once."""
+    net = torch.nn.ModuleDict({'stem': torch.nn.Linear(4, 4), 'transformer_blocks': torch.nn.ModuleList([torch.nn.Linear(4, 4)])})
+    net['stem'].bias.requires_grad_(False)
+    opt = T.make_optimizer(net, name='sgd_spformer')
+    assert isinstance(opt, torch.optim.SGD) and len(opt.param_groups) == 2
+    rest, blocks = opt.param_groups
+    assert [id(p) for p in rest['params']] == [id(net['stem'].weight)]                     # frozen bias left out
+    assert [id(p) for p in blocks['params']] == [id(p) for p in net['transformer_blocks'].parameters()]
+    assert rest['lr'] == 0.24 and abs(blocks['lr'] - 0.024) < 1e-12 and all(g['nesterov'] and g['momentum'] == 0.9 for g in opt.param_groups)
+    opt = T.make_optimizer(net, name='adamw_spformer', lr=1e-3, weight_decay=0.05, transformer_lr_scale=0.5)
+    assert isinstance(opt, torch.optim.AdamW) and [g['lr'] for g in opt.param_groups] == [1e-3, 5e-4]
+    assert isinstance(T.make_optimizer(net.parameters(), name='adam', lr=1e-3), torch.optim.Adam)
+    assert isinstance(T.make_optimizer(net, name='adamw', lr=1e-3), torch.optim.AdamW)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        T.make_optimizer(net.parameters(), name='lion')
+    with pytest.raises(TypeError):
+        T.make_optimizer(net.parameters(), name='sgd_spformer')
+
+
 def test_checkpoint_roundtrip_and_ddp_prefix(tmp_path):
     a = _Runner(wrap=True)
     _train_a_bit(a)

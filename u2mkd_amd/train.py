@@ -27,9 +27,34 @@ def cosine_schedule_with_warmup(k, num_epochs, batch_size, dataset_size, world):
     return 0.5 * (1 + np.cos(np.pi * (k - warmup_iters) / (num_epochs * iter_per_epoch)))
 
 
-def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4):
-    """core/builder.py:663-669 (SGD, nesterov)."""
-    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
+def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4, name='sgd', nesterov=True, transformer_lr_scale=0.1):
+    """``make_optimizer`` of core/builder.py:662-718 with the values of configs/nuscenes/default.yaml:18-23 as defaults
+    (`sgd`: SGD, nesterov -- what every shipped configuration trains with).  ``params``: an iterable of parameters, or,
+    for the `*_spformer` variants (SphereFormer blocks at a reduced learning rate: 0.1 x for `sgd_spformer`,
+    ``transformer_lr_scale`` for `adamw_spformer`), the module itself -- the groups are split by parameter name
+    ("transformer_block" in the name) exactly as the reference does."""
+    if name in ('sgd_spformer', 'adamw_spformer'):
+        if not isinstance(params, torch.nn.Module):
+            raise TypeError(f'make_optimizer({name!r}) splits the parameters by name: pass the module')
+        named = [(n, p) for n, p in params.named_parameters() if p.requires_grad]
+        rest = [p for n, p in named if 'transformer_block' not in n]
+        blocks = [p for n, p in named if 'transformer_block' in n]
+        if name == 'sgd_spformer':
+            common = dict(momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+            return torch.optim.SGD([dict(params=rest, lr=lr, **common), dict(params=blocks, lr=lr * 0.1, **common)],
+                                   lr=lr, **common)
+        return torch.optim.AdamW([dict(params=rest, lr=lr, weight_decay=weight_decay),
+                                  dict(params=blocks, lr=lr * transformer_lr_scale, weight_decay=weight_decay)],
+                                 lr=lr, weight_decay=weight_decay)
+    if isinstance(params, torch.nn.Module):
+        params = params.parameters()
+    if name == 'sgd':
+        return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+    if name == 'adam':
+        return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
+    if name == 'adamw':
+        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+    raise NotImplementedError(name)
 
 
 class _Amp:
