@@ -429,10 +429,15 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
         desc = ('BASELINE.json configs[1]: SPVCNN cr=%g LiDAR-only train step (fwd + Lovasz/CE + bwd + SGD), '
                 'one %d-voxel synthetic scene per GPU' % (args.cr, args.voxels))
 
+        prefetch = os.environ.get('U2MKD_PREFETCH_GEOMETRY', '1') != '0'
+        nxt = [None]
+
         def step():
-            feats, coords, labels = (t.clone() for t in res[counter[0] % n_batches])      # fresh tensors every step
+            # fresh tensors every step; the next batch's geometry is prepared between this step's forward and backward
+            feats, coords, labels = nxt[0] or tuple(t.clone() for t in res[counter[0] % n_batches])
             counter[0] += 1
-            return runner(feats, coords, labels)
+            nxt[0] = tuple(t.clone() for t in res[counter[0] % n_batches])
+            return runner(feats, coords, labels, prefetch=nxt[0][:2] if prefetch else None)
         return step, res[0][0].shape[0], desc
     from u2mkd_amd import kd as KD
     sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}

@@ -101,12 +101,27 @@ class LidarStep:
         self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
         self.sched = _scheduler(self.opt, num_epochs, batch_size)
 
-    def __call__(self, feats, coords, targets, keyframe_mask=None):
+    def __call__(self, feats, coords, targets, keyframe_mask=None, prefetch=None):
+        """One training step.  ``prefetch`` = (feats, coords) of the NEXT batch (the tensors the next call will receive):
+        its geometry -- voxel set and kernel maps, every host synchronisation of a step (point_voxel.prepare_geometry) --
+        is built between this step's forward and backward, and the next call issues its forward without waiting for the
+        GPU (as KDStep does)."""
+        queued = self.__dict__.pop('_queued', None)
+        in_mod = {'lidar': ts.SparseTensor(feats, coords)}
+        if queued is not None and queued[0] is feats and queued[1] is coords:
+            in_mod = queued[2]
         with self.amp.autocast():
-            out = self.net({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+            out = self.net(in_mod)['x_vox']
             if keyframe_mask is not None:
                 out, targets = out[keyframe_mask], targets[keyframe_mask]
             loss = self.criterion(out, targets)
+        if prefetch is not None:
+            from .lidar.point_voxel import prepare_geometry
+            nf, nc = prefetch
+            nxt = {'lidar': ts.SparseTensor(nf, nc)}
+            with self.amp.autocast(), torch.no_grad():
+                nxt['_geometry'] = prepare_geometry(nxt['lidar'], self.model.pres, self.model.vres)
+            self._queued = (nf, nc, nxt)
         self.amp.backward_and_step(loss, self.opt)
         self.sched.step()
         return loss.detach()
