@@ -1,6 +1,6 @@
 """Upper bounds for step-level changes, measured instead of estimated: the pipelined KD step (fresh batches, geometry
 prefetch) with parts of the work switched off.  One variant per process (env / argv), wall ms per step printed.
-  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [half_res_tail]"""
+  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [half_res_tail] [cached_plans]"""
 import sys, time, os; sys.path.insert(0, '.')
 import torch
 from u2mkd_amd import lidar, train as T, kd as KD
@@ -30,10 +30,17 @@ if 'no_pix_decoder' in flags:
     KD.kd_losses = losses
 
 
+def fresh(i):
+    d = T.fresh_batch(res[i % 4])
+    if 'cached_plans' in flags:      # the point<->pixel plans hang on masks[0]: keep the resident tensors -> plans are built once
+        d['masks'], d['pixel_coordinates'], d['fov_mask'] = res[i % 4]['masks'], res[i % 4]['pixel_coordinates'], res[i % 4]['fov_mask']
+    return d
+
+
 def loop(steps):
-    cur = T.fresh_batch(res[0])
+    cur = fresh(0)
     for i in range(steps):
-        nxt = T.fresh_batch(res[(i + 1) % 4])
+        nxt = fresh(i + 1)
         run(cur, prefetch=nxt)
         cur = nxt
 
