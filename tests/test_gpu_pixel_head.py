@@ -93,6 +93,35 @@ def test_sampled_pixel_head_equals_the_dense_evaluation(hip, hw, low):
     assert float((got_e.double() - want_e).abs().max()) < 2e-5 * float(want_e.abs().max())
 
 
+def test_sampled_pixel_head_with_a_sample_no_camera_sees(hip):
+    """One sample of the batch is seen by no camera (all masks False) and one camera of the other sample sees nothing:
+    those points read zeros in the dense formulation (Feature_Fetch's `zeros` padding); the sampled head must agree in
+    logits and gradients (their samples carry zero weight, so they add nothing to the BatchNorm backward sums)."""
+    from u2mkd_amd import camera
+    from u2mkd_amd.pixel_head import sampled_pixel_logits
+    torch.manual_seed(11)
+    hw, low, ib, ncam, c, classes = (64, 112), (32, 56), 2, 6, 16, 17
+    pc, ms = _inputs(4, hw)
+    ms[1][:] = False
+    ms[0][3] = False
+    head = camera.BNReluConv(c, classes, k=1).cuda().train()
+    x = (torch.randn(ib * ncam, c, *low, device='cuda') + 1.0).requires_grad_(True)
+    got = sampled_pixel_logits(x, head, pc, ms, hw, ib, ncam)
+    n0 = ms[0].shape[1]
+    assert float(got[n0:].abs().max()) == 0.0
+    g = torch.randn_like(got)
+    got.backward(g)
+    grads = [x.grad.clone(), head.norm.weight.grad.clone(), head.norm.bias.grad.clone(), head.conv.weight.grad.clone()]
+    xd = x.detach().double().requires_grad_(True)
+    for p in head.parameters():
+        p.grad = None
+    want, _ = _dense_fp64(xd, head, pc, ms, hw, ib, ncam)
+    want.backward(g.double())
+    assert float((got.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    for a, b, name in zip(grads, [xd.grad, head.norm.weight.grad, head.norm.bias.grad, head.conv.weight.grad], ('map', 'gamma', 'beta', 'classifier')):
+        assert float((a.double() - b.double()).abs().max()) < 5e-5 * float(b.abs().max()), name
+
+
 def test_student_uses_the_sampled_head_and_matches_the_dense_path(hip, monkeypatch):
     """Whole student forward / backward with the sampled head against the same model with it switched off (same
     weights, same batch; BatchNorm buffers put back in between)."""
