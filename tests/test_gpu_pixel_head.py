@@ -93,6 +93,41 @@ def test_sampled_pixel_head_equals_the_dense_evaluation(hip, hw, low):
     assert float((got_e.double() - want_e).abs().max()) < 2e-5 * float(want_e.abs().max())
 
 
+def test_sampled_pixel_head_at_the_full_camera_size(hip):
+    """BASELINE.json configs[2]'s literal camera size, 6 x 900 x 1600 with the shipped 128-channel decoder map: the
+    sampled head against the dense head evaluated by torch in fp32 on the same map (4.4 GB per full-resolution
+    tensor) -- logits, the gradient of the map and of the classifier."""
+    from u2mkd_amd import camera
+    from u2mkd_amd.fusion import c2l_gather_torch
+    from u2mkd_amd.pixel_head import sampled_pixel_logits
+    torch.manual_seed(2)
+    hw, low, ib, ncam, c, classes = (900, 1600), (450, 800), 1, 6, 128, 17
+    pc, ms = _inputs(12, hw, n_vox=40000, batch=1)
+    head = camera.BNReluConv(c, classes, k=1).cuda().train()
+    with torch.no_grad():
+        head.norm.weight.uniform_(0.5, 1.5)
+        head.norm.bias.normal_(0, 0.3)
+    x = (torch.randn(ib * ncam, c, *low, device='cuda') + 0.5).requires_grad_(True)
+    got = sampled_pixel_logits(x, head, pc, ms, hw, ib, ncam)
+    g = torch.randn_like(got)
+    got.backward(g)
+    gx, gw = x.grad.clone(), head.conv.weight.grad.clone()
+    x.grad = None
+    for p in head.parameters():
+        p.grad = None
+    u = F.interpolate(x, hw, mode='bilinear', align_corners=True)
+    y = F.batch_norm(u, None, None, head.norm.weight, head.norm.bias, True, 0.0, head.norm.eps)
+    # (the 1x1 classifier as a matrix product over the pixels: MIOpen's weight gradient of this convolution is WRONG at
+    # this size -- its input is 4.4 GB, beyond 32-bit byte offsets; tools/dbg_miopen_large.py, DESIGN.md section 7b)
+    z = (torch.relu(y).permute(0, 2, 3, 1).reshape(-1, c) @ head.conv.weight.view(classes, c).t())
+    z = z.view(ib * ncam, hw[0], hw[1], classes).permute(0, 3, 1, 2).reshape(ib, ncam, classes, *hw)
+    want = c2l_gather_torch(z, pc, ms)
+    want.backward(g)
+    assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
+    assert float((gx - x.grad).norm() / x.grad.norm()) < 1e-4
+    assert float((gw - head.conv.weight.grad).norm() / head.conv.weight.grad.norm()) < 1e-4
+
+
 def test_sampled_pixel_head_with_a_sample_no_camera_sees(hip):
     """One sample of the batch is seen by no camera (all masks False) and one camera of the other sample sees nothing:
     those points read zeros in the dense formulation (Feature_Fetch's `zeros` padding); the sampled head must agree in

@@ -242,6 +242,12 @@ class StudentMSP2IFM(nn.Module):
                     # up-sampling to the image size + BatchNorm + ReLU + classifier only at the pixels Feature_Fetch reads
                     fmap = self._piece('decoder_low')(*img_feats)
                     return sampled_pixel_logits(fmap, self.classifier_pix, pixel_coordinates, masks, (ih, iw), ib, ncam)
+                if ib * ncam * self.pix_branch.num_features * ih * iw * 4 >= 2 ** 32:
+                    # MIOpen's weight gradient of the 1x1 classifier is wrong once its input passes 4 GiB (6 x 128 x 900 x
+                    # 1600 floats; tools/dbg_miopen_large.py): no silent wrong gradients
+                    raise RuntimeError('the dense pixel head would form a %.1f GB tensor, beyond what MIOpen computes '
+                                       'correctly: use the sampled head (U2MKD_SAMPLED_PIXEL_HEAD=1, the default)'
+                                       % (ib * ncam * self.pix_branch.num_features * ih * iw * 4 / 1e9))
                 fmap = self._piece('decoder_%dx%d' % (ih, iw))(*img_feats)
                 fmap = fmap.view(ib, ncam, fmap.shape[1], fmap.shape[2], fmap.shape[3])
                 return feature_fetch(masks, pixel_coordinates, fmap)
