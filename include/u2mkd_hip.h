@@ -350,7 +350,11 @@ int u2mkd_upbn_stats(const float *x, int32_t n_img, int32_t c, int32_t h, int32_
                      const float *ay, const float *ax, int32_t rows_per_chunk, float *partial, u2mkd_stream_t s);
 int u2mkd_upbn_dense_grad(const float *x, int32_t n_img, int32_t c, int32_t h, int32_t w, const float *a, const float *b,
                           const float *ay, const float *ax, const float *c0 /*[c]*/, const float *c1 /*[c]*/,
-                          float *dx, u2mkd_stream_t s);
+                          int32_t rows_per_chunk, float *dx, u2mkd_stream_t s);
+
+/* out[b][j][i] = in[b][i][j] (fp32): the NCHW <-> channel-last-rows copies around the point <-> pixel gathers
+ * (`features.permute(...)` of core/models/fusion_blocks.py:241-254, tsd_full.py:482-495) as an LDS-tiled transpose      */
+int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, u2mkd_stream_t s);
 
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the

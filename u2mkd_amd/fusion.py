@@ -141,11 +141,22 @@ class _NchwToRows(torch.autograd.Function):
     def forward(ctx, fm):
         ctx.shape = fm.shape
         B, ncam, C, h, w = fm.shape
+        if fm.is_cuda and fm.dtype == torch.float32 and fm.is_contiguous() and B * ncam <= 65535 and fm.numel():
+            from . import _lib as L
+            out = torch.empty(B * ncam * h * w, C, dtype=torch.float32, device=fm.device)
+            L.call('u2mkd_transpose_batched', L.ptr(fm), L.ptr(out), B * ncam, C, h * w, L.stream())
+            return out
         return fm.permute(0, 1, 3, 4, 2).contiguous().view(B * ncam * h * w, C)
 
     @staticmethod
     def backward(ctx, g):
         B, ncam, C, h, w = ctx.shape
+        if g.is_cuda and g.dtype == torch.float32 and B * ncam <= 65535 and g.numel():
+            from . import _lib as L
+            g = g.contiguous()
+            out = torch.empty(B, ncam, C, h, w, dtype=torch.float32, device=g.device)
+            L.call('u2mkd_transpose_batched', L.ptr(g), L.ptr(out), B * ncam, h * w, C, L.stream())
+            return out
         return g.view(B, ncam, h, w, C).permute(0, 1, 4, 2, 3).contiguous()
 
 

@@ -32,6 +32,11 @@ _COEF = {}
 _ROWS_PER_CHUNK = 16
 
 
+def _rows_per_chunk(w):
+    """rows of one plane a workgroup stages in LDS (with two halo rows) for the stencil kernels: <= 60 KB"""
+    return max(1, min(_ROWS_PER_CHUNK, (60 * 1024 // 4) // max(w, 1) - 2))
+
+
 def _interp_coefficients(n_in, n_out, device):
     """(scale, a [n_in], diagonals [3, n_in]) of W = the [n_out, n_in] matrix of F.interpolate(mode='bilinear',
     align_corners=True) along one axis, with torch's fp32 index arithmetic (src = scale * dst, lambda = src - floor):
@@ -75,9 +80,10 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
             _, a, ay = _interp_coefficients(h, big_h, x.device)
             _, b, ax = _interp_coefficients(w, big_w, x.device)
             coef = (a, b, ay, ax)
-            chunks = (h + _ROWS_PER_CHUNK - 1) // _ROWS_PER_CHUNK
+            rpc = _rows_per_chunk(w)
+            chunks = (h + rpc - 1) // rpc
             partial = torch.empty(n * c, chunks, 2, dtype=torch.float32, device=x.device)
-            L.call('u2mkd_upbn_stats', L.ptr(x), n, c, h, w, L.ptr(a), L.ptr(b), L.ptr(ay), L.ptr(ax), _ROWS_PER_CHUNK,
+            L.call('u2mkd_upbn_stats', L.ptr(x), n, c, h, w, L.ptr(a), L.ptr(b), L.ptr(ay), L.ptr(ax), rpc,
                    L.ptr(partial), L.stream())
             sums = partial.view(n, c, chunks, 2).double().sum((0, 2))               # [C, 2], shifted by x[0, :, 0, 0]
             m1 = sums[:, 0] / count
@@ -142,7 +148,7 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
             n, c, h, w = x.shape
             dx = torch.empty_like(x)
             L.call('u2mkd_upbn_dense_grad', L.ptr(x), n, c, h, w, L.ptr(a), L.ptr(b), L.ptr(ay), L.ptr(ax),
-                   L.ptr(c0.contiguous()), L.ptr(c1.contiguous()), L.ptr(dx), L.stream())
+                   L.ptr(c0.contiguous()), L.ptr(c1.contiguous()), _rows_per_chunk(w), L.ptr(dx), L.stream())
         return dx, du, dgamma, dbeta, None, None
 
 
