@@ -352,6 +352,13 @@ int u2mkd_upbn_dense_grad(const float *x, int32_t n_img, int32_t c, int32_t h, i
                           const float *ay, const float *ax, const float *c0 /*[c]*/, const float *c1 /*[c]*/,
                           int32_t rows_per_chunk, float *dx, u2mkd_stream_t s);
 
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the SwiftNet stem (core/models/image_branch/swiftnet.py): x
+ * [planes, h, w] -> y [planes, oh, ow] with oh = (h - 1) / 2 + 1; `code` = one byte per output, the position of the
+ * maximum inside its 3 x 3 window (first maximum in row-major order, as torch); backward: dx [planes, h, w]            */
+int u2mkd_maxpool3s2_forward(const float *x, int64_t planes, int32_t h, int32_t w, float *y, uint8_t *code, u2mkd_stream_t s);
+int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t planes, int32_t h, int32_t w, float *dx,
+                              u2mkd_stream_t s);
+
 /* out[b][j][i] = in[b][i][j] (fp32): the NCHW <-> channel-last-rows copies around the point <-> pixel gathers
  * (`features.permute(...)` of core/models/fusion_blocks.py:241-254, tsd_full.py:482-495) as an LDS-tiled transpose      */
 int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, u2mkd_stream_t s);

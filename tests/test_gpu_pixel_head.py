@@ -198,3 +198,24 @@ def test_student_uses_the_sampled_head_and_matches_the_dense_path(hip, monkeypat
         print('PIXHEAD', name, 'sampled vs dense %.2e   dense vs dense %.2e' % (err, floor))
         # (the stem's gradient: two identical dense passes differ by 2e-4 .. 2e-3 -- one pair is a poor estimate of that band)
         assert err < max(5e-3 if name == 'stem conv' else 1e-4, 10.0 * floor), (name, err, floor)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 37, 52), (3, 8, 64, 112), (1, 3, 7, 9), (1, 2, 2, 2)])
+def test_maxpool_3x3_s2_equals_torch_including_ties(hip, shape):
+    """camera.MaxPool3x3s2 (one byte per output instead of an int64 index, gathering backward) against nn.MaxPool2d(3, 2, 1):
+    outputs and input gradients EQUAL, also on maps full of ties (the zeros a ReLU leaves: the first maximum in row-major
+    window order must win, as in torch), odd sizes and windows clipped by the border."""
+    from u2mkd_amd import camera
+    torch.manual_seed(sum(shape))
+    pool, ref = camera.MaxPool3x3s2(), torch.nn.MaxPool2d(3, 2, 1)
+    for relu in (False, True):
+        x0 = torch.randn(*shape, device='cuda')
+        if relu:
+            x0 = torch.relu(x0 - 0.8)                         # mostly zeros: all-tie windows
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        ya, yb = pool(xa), ref(xb)
+        assert ya.shape == yb.shape and torch.equal(ya, yb)
+        g = torch.randn_like(ya)
+        ya.backward(g)
+        yb.backward(g)
+        assert torch.equal(xa.grad, xb.grad), float((xa.grad - xb.grad).abs().max())

@@ -19,6 +19,44 @@ __all__ = ['SwiftNetRes18', 'SwiftNetResNet', 'BNReluConv', 'BatchNorm2d', 'Sync
 _HIP_BN2D = os.environ.get('U2MKD_BN2D', '1') != '0'
 
 
+class _MaxPool3s2Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib as L
+        n, c, h, w = x.shape
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+        code = torch.empty(n, c, oh, ow, dtype=torch.uint8, device=x.device)
+        L.call('u2mkd_maxpool3s2_forward', L.ptr(x), n * c, h, w, L.ptr(y), L.ptr(code), L.stream())
+        ctx.save_for_backward(code)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib as L
+        code, = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=g.device)
+        L.call('u2mkd_maxpool3s2_backward', L.ptr(g.contiguous()), L.ptr(code), n * c, h, w, L.ptr(dx), L.stream())
+        return dx
+
+
+class MaxPool3x3s2(nn.MaxPool2d):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (the stem's pooling, swiftnet.py) on csrc/pixhead.hip's two
+    kernels for fp32 device maps: a byte per output instead of torch's int64 index, a gathering backward (0.7 ms -> 0.15 ms
+    on the 6 x 64 x 360 x 640 map, at the very end of the step's camera chain); the same element wins a tie."""
+
+    def __init__(self):
+        super().__init__(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() and not torch.is_autocast_enabled():
+            return _MaxPool3s2Function.apply(x)
+        return super().forward(x)
+
+
 def _up(x, size):
     return F.interpolate(x, size, mode='bilinear', align_corners=True)
 
@@ -261,7 +299,7 @@ class SwiftNetResNet(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = MaxPool3x3s2()
         skips = []
         self.layer1 = self._make_layer(64, layers[0])
         skips.append(self.inplanes)

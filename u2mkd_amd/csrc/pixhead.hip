@@ -155,6 +155,73 @@ transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows
     }
 }
 
+// ---- MaxPool2d(kernel 3, stride 2, padding 1) of the SwiftNet stem (swiftnet.py: self.maxpool) -------------------------
+// torch keeps an int64 index per output (177 MB at 6 x 64 x 180 x 320) and its backward walks the candidate outputs of
+// every input pixel comparing those indices: 0.7 ms, at the very end of the step's camera chain.  Here the forward
+// stores the position of the maximum inside its window as one byte (row-major over the window clipped to the map, the
+// first maximum wins -- torch's scan order and strict `>`, so ties between equal values, e.g. the zeros a ReLU leaves,
+// go to the same element), and the backward gathers: every input pixel sums the gradients of the <= 4 windows that
+// selected it.
+__global__ void __launch_bounds__(256)
+maxpool3s2_fwd_kernel(const float *__restrict__ x, int64_t total_out, int h, int w, int oh, int ow, float *__restrict__ y,
+                      uint8_t *__restrict__ code) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total_out) return;
+    const int ox = (int)(e % ow);
+    const int64_t r = e / ow;
+    const int oy = (int)(r % oh);
+    const int64_t plane = r / oh;
+    const float *xp = x + plane * (int64_t)h * w;
+    const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
+    float best = -INFINITY;
+    int bc = 0;
+    bool first = true;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y0 + dy;
+        if (yy < 0 || yy >= h) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = x0 + dx;
+            if (xx < 0 || xx >= w) continue;
+            const float v = xp[(int64_t)yy * w + xx];
+            if (first || v > best || v != v) { best = v; bc = dy * 3 + dx; first = false; }
+        }
+    }
+    y[e] = best;
+    code[e] = (uint8_t)bc;
+}
+
+__global__ void __launch_bounds__(256)
+maxpool3s2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ code, int64_t total_in, int h, int w, int oh,
+                      int ow, float *__restrict__ dx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total_in) return;
+    const int xx = (int)(e % w);
+    const int64_t r = e / w;
+    const int yy = (int)(r % h);
+    const int64_t plane = r / h;
+    const float *gp = dy + plane * (int64_t)oh * ow;
+    const uint8_t *cp = code + plane * (int64_t)oh * ow;
+    // windows (oy, ox) with 2 oy - 1 <= yy <= 2 oy + 1: oy in {yy / 2, (yy + 1) / 2}
+    float g = 0.f;
+    const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1, ox0 = xx >> 1, ox1 = (xx + 1) >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = a ? oy1 : oy0;
+        if ((a && oy1 == oy0) || oy >= oh) continue;
+        const int dyw = yy - (2 * oy - 1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = b ? ox1 : ox0;
+            if ((b && ox1 == ox0) || ox >= ow) continue;
+            const int dxw = xx - (2 * ox - 1);
+            if (cp[(int64_t)oy * ow + ox] == dyw * 3 + dxw) g += gp[(int64_t)oy * ow + ox];
+        }
+    }
+    dx[e] = g;
+}
+
 }  // namespace u2mkd
 
 using namespace u2mkd;
@@ -206,6 +273,27 @@ int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, kTrTile), (unsigned)ceil_div(rows, kTrTile), (unsigned)batch),
                        dim3(256), 0, as_stream(s), in, out, rows, cols);
     return check_launch("u2mkd_transpose_batched");
+}
+
+int u2mkd_maxpool3s2_forward(const float *x, int64_t planes, int32_t h, int32_t w, float *y, uint8_t *code, u2mkd_stream_t s) {
+    if (planes == 0) return 0;
+    U2_REQUIRE(x && y && code && planes > 0 && h > 0 && w > 0, "u2mkd_maxpool3s2_forward: bad arguments");
+    const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
+    const int64_t total = planes * oh * ow;
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), x, total, h, w, oh,
+                       ow, y, code);
+    return check_launch("u2mkd_maxpool3s2_forward");
+}
+
+int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t planes, int32_t h, int32_t w, float *dx,
+                              u2mkd_stream_t s) {
+    if (planes == 0) return 0;
+    U2_REQUIRE(dy && code && dx && planes > 0 && h > 0 && w > 0, "u2mkd_maxpool3s2_backward: bad arguments");
+    const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
+    const int64_t total = planes * h * w;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), dy, code, total, h,
+                       w, oh, ow, dx);
+    return check_launch("u2mkd_maxpool3s2_backward");
 }
 
 }  // extern "C"
