@@ -35,7 +35,15 @@ def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, valid: torch
     errors = (fg - pt).abs()
     if valid is not None:
         errors = torch.where(valid.unsqueeze(0), errors, errors.new_full((), -1.))
-    errors_sorted, perm = torch.sort(errors, 1, descending=True)
+    # One flat sort instead of a row-wise one: torch answers sort(dim=1) of [17, 80 000] with ~77 merge-sort launches
+    # (0.65 ms on MI355X, twice per KD step, between the forward and the backward); the composite key 4c - error in
+    # float64 (exact: an integer plus a float32) orders class-major and error-descending in ONE radix sort, and block c of
+    # the result holds exactly the P entries of class c.
+    with torch.no_grad():
+        cls = torch.arange(C, device=probas.device).unsqueeze(1)
+        keys = (cls * 4).to(torch.float64) - errors.detach().to(torch.float64)
+        perm = torch.sort(keys.view(-1))[1].view(C, P) - cls * P
+    errors_sorted = torch.gather(errors, 1, perm)
     fg_sorted = torch.gather(fg, 1, perm)
     gts = fg_sorted.sum(1, keepdim=True)                         # [C, 1]
     cs = fg_sorted.cumsum(1)
