@@ -14,6 +14,7 @@ GPU only: CPU tensors raise (there is no fallback path).
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -272,8 +273,8 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     uniq = torch.unique(keys)  # sorted int64 == (b,x,y,z) lexicographic
     # (the unique above has just synchronised the stream: reading the 4-byte flag costs no queue drain -- but it is a
     # second round trip per level; a caller that builds several levels in a row reads the flag once, at the end)
-    if _DEFERRED_RANGE_CHECK[0]:
-        _DEFERRED_RANGE_CHECK.append(flag)
+    if _deferred()[0]:
+        _deferred().append(flag)
     elif n:
         _check_range_flag(flag)
     out = torch.empty(uniq.shape[0], 4, dtype=torch.int32, device=coords.device)
@@ -282,7 +283,14 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
 
 
 _RANGE_FLAGS = {}
-_DEFERRED_RANGE_CHECK = [False]           # [active, flag, flag, ...]
+_DEFERRED_RANGE_CHECK = threading.local()      # .state = [active, flag, flag, ...], one per host thread
+
+
+def _deferred():
+    st = getattr(_DEFERRED_RANGE_CHECK, 'state', None)
+    if st is None:
+        st = _DEFERRED_RANGE_CHECK.state = [False]
+    return st
 
 
 def _check_range_flag(flag):
@@ -298,15 +306,17 @@ class deferred_range_check:
     level.  The error is the same, raised a few launches later."""
 
     def __enter__(self):
-        self._outer = _DEFERRED_RANGE_CHECK[0]
-        _DEFERRED_RANGE_CHECK[0] = True
-        self._start = len(_DEFERRED_RANGE_CHECK)
+        st = _deferred()
+        self._outer = st[0]
+        st[0] = True
+        self._start = len(st)
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        flags = _DEFERRED_RANGE_CHECK[self._start:]
-        del _DEFERRED_RANGE_CHECK[self._start:]
-        _DEFERRED_RANGE_CHECK[0] = self._outer
+        st = _deferred()
+        flags = st[self._start:]
+        del st[self._start:]
+        st[0] = self._outer
         if exc_type is None and not self._outer:
             seen = set()
             for f in flags:
@@ -314,7 +324,7 @@ class deferred_range_check:
                     seen.add(id(f))
                     _check_range_flag(f)
         elif self._outer:
-            _DEFERRED_RANGE_CHECK.extend(flags)
+            st.extend(flags)
         return False
 
 
