@@ -291,34 +291,9 @@ class TSDFull(nn.Module):
         forward is bound by the host's launch rate), so the waits are short, and the host then issues the next
         forward while step k's backward -- ~30 ms of queued kernels -- drains, instead of sitting in the next
         forward's first synchronisation for as long."""
-        xs, xt = in_mod['student']['lidar'], in_mod['teacher']['lidar']
-        side = _side_stream(xt.F, 'teacher') if (_PREPARE_THREADS and _TEACHER_STREAM and (self.training or self.debug_val)) else None
-        if side is not None:
-            # EXPERIMENT (U2MKD_PREPARE_THREADS=1): the two geometries are independent chains of host round trips; the
-            # teacher's runs in a second host thread on the teacher's stream, so one chain's launches are issued while
-            # the other waits (the wait releases the interpreter lock)
-            import threading
-            side.wait_stream(torch.cuda.current_stream())
-            box = {}
-
-            def work():
-                try:
-                    with torch.cuda.stream(side), torch.no_grad():
-                        box['g'] = prepare_geometry(xt, self.model_t.pres, self.model_t.vres)
-                except BaseException as e:           # noqa: BLE001 -- re-raised by the caller's thread
-                    box['e'] = e
-            th = threading.Thread(target=work)
-            th.start()
-            with torch.no_grad():
-                g_s = prepare_geometry(xs, self.model_s.pres, self.model_s.vres)
-            th.join()
-            if 'e' in box:
-                raise box['e']
-            g_t = box['g']
-        else:
-            with torch.no_grad():
-                g_s = prepare_geometry(xs, self.model_s.pres, self.model_s.vres)
-                g_t = prepare_geometry(xt, self.model_t.pres, self.model_t.vres)
+        with torch.no_grad():
+            g_s = prepare_geometry(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres)
+            g_t = prepare_geometry(in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)
         in_mod['student']['_geometry'] = g_s
         in_mod['teacher']['_geometry'] = g_t
         return in_mod
@@ -354,7 +329,6 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
-_PREPARE_THREADS = os.environ.get('U2MKD_PREPARE_THREADS', '0') == '1'
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 _SIDE = {}
 
