@@ -352,6 +352,17 @@ int u2mkd_upbn_dense_grad(const float *x, int32_t n_img, int32_t c, int32_t h, i
                           const float *ay, const float *ax, const float *c0 /*[c]*/, const float *c1 /*[c]*/,
                           int32_t rows_per_chunk, float *dx, u2mkd_stream_t s);
 
+/* F.interpolate(mode='bilinear', align_corners=True) of NCHW maps, optionally + skip (the decoder's `_up(x) + skip`,
+ * core/models/image_branch/swiftnet.py _Upsample.forward): x [planes, h, w] -> y [planes, H, W], rh = (h - 1) / (H - 1) in
+ * fp32 (rw likewise).  Backward: a deterministic gather; taps_y [h][2] = (first output row, number of output rows) that
+ * read input row i, wy [h][8] their weights (0 beyond the count), taps_x / wx likewise for columns -- built by the
+ * caller from the same index arithmetic.  tiled != 0: the window of g of a 16 x 64 tile of inputs is staged in LDS
+ * (the caller has checked that every tile's window fits 40 rows x 136 columns and planes <= 65535)                                                                              */
+int u2mkd_up_bilinear_forward(const float *x, const float *skip /*or NULL*/, int64_t planes, int32_t h, int32_t w, int32_t H,
+                              int32_t W, float rh, float rw, float *y, u2mkd_stream_t s);
+int u2mkd_up_bilinear_backward(const float *g, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, const int32_t *taps_y,
+                               const float *wy, const int32_t *taps_x, const float *wx, int32_t tiled, float *dx, u2mkd_stream_t s);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the SwiftNet stem (core/models/image_branch/swiftnet.py): x
  * [planes, h, w] -> y [planes, oh, ow] with oh = (h - 1) / 2 + 1; `code` = one byte per output, the position of the
  * maximum inside its 3 x 3 window (first maximum in row-major order, as torch); backward: dx [planes, h, w]            */

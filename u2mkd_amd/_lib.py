@@ -132,6 +132,8 @@ SIGNATURES = {
     'u2mkd_c2l_plan': (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _i32, _p, _p, _p]),
     'u2mkd_l2c_keys': (C.c_int, [_p, _p, _i32, _i64, _i32, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_l2c_finish': (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
+    'u2mkd_up_bilinear_forward': (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p]),
+    'u2mkd_up_bilinear_backward': (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_maxpool3s2_forward': (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_maxpool3s2_backward': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_transpose_batched': (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),

@@ -57,8 +57,98 @@ class MaxPool3x3s2(nn.MaxPool2d):
         return super().forward(x)
 
 
-def _up(x, size):
-    return F.interpolate(x, size, mode='bilinear', align_corners=True)
+_UP_TAPS = {}
+# U2MKD_UP_BILINEAR: 1 = the decoder's up-samplings on csrc/pixhead.hip (gathering, run-to-run reproducible backward),
+# 0 = torch's kernels (backward scatters with float atomics), auto (default) = 1 exactly when
+# torch.use_deterministic_algorithms(True) is set -- torch's backward refuses to run then.  Measured on one box, three
+# pairs: the HIP kernels take 1.1 ms less kernel time per KD step (forward 135-450 us -> 14-180 us per call, backward
+# 215 -> 131 us) and the step is 0.3-0.4 ms SLOWER (74.4-74.7 vs 74.1-74.4 ms): the camera stream is not the critical
+# one and its earlier finish only moves the overlap, so the default keeps torch's kernels.
+_UP_MODE = os.environ.get('U2MKD_UP_BILINEAR', 'auto')
+_UP_HIP = None if _UP_MODE == 'auto' else _UP_MODE != '0'
+
+
+def _up_on_hip():
+    return torch.are_deterministic_algorithms_enabled() if _UP_HIP is None else _UP_HIP
+
+
+def _up_taps(n_in, n_out, device):
+    """Per input index of one axis: (first output index, number of outputs) that read it and their weights [n_in, 8], from
+    torch's index arithmetic of F.interpolate(bilinear, align_corners=True) (src = scale * dst in fp32).  None when an
+    input feeds more than 8 outputs (up-sampling factors beyond ~4: torch's kernel serves those)."""
+    key = (n_in, n_out, str(device))
+    if key not in _UP_TAPS:
+        import numpy as np
+        r = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+        src = (r * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+        i0 = src.astype(np.int64)
+        ip = (i0 < n_in - 1).astype(np.int64)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        l0 = (np.float32(1) - l1).astype(np.float32)
+        first = np.full(n_in, n_out, np.int64)
+        last = np.full(n_in, -1, np.int64)
+        for idx in (i0, i0 + ip):
+            np.minimum.at(first, idx, np.arange(n_out))
+            np.maximum.at(last, idx, np.arange(n_out))
+        cnt = np.maximum(last - first + 1, 0)
+        ok = int(cnt.max()) <= 8
+        taps = wts = span = None
+        if ok:
+            w = np.zeros((n_in, 8), np.float32)
+            for o in range(n_out):             # (sizes of a few hundred: once per size)
+                w[i0[o], o - first[i0[o]]] += l0[o]
+                w[i0[o] + ip[o], o - first[i0[o] + ip[o]]] += l1[o]
+            first = np.where(cnt > 0, first, 0)
+            # the widest window of outputs a tile of `tile` consecutive inputs reads (csrc/pixhead.hip's LDS form)
+            span = {t: 1 << 30 if int(cnt.min()) == 0 else max(int(first[min(a + t, n_in) - 1] + cnt[min(a + t, n_in) - 1] - first[a]) for a in range(0, n_in, t))
+                    for t in (16, 64)}
+            taps = torch.tensor(np.stack([first, cnt], 1), dtype=torch.int32, device=device).contiguous()
+            wts = torch.tensor(w, dtype=torch.float32, device=device).contiguous()
+        _UP_TAPS[key] = (float(r), taps, wts, span)
+    return _UP_TAPS[key]
+
+
+class _UpBilinearFunction(torch.autograd.Function):
+    """y = F.interpolate(x, size, bilinear, align_corners=True) [+ skip] on csrc/pixhead.hip (deterministic backward)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, size):
+        from . import _lib as L
+        n, c, h, w = x.shape
+        big_h, big_w = size
+        rh, ty, wy, span_y = _up_taps(h, big_h, x.device)
+        rw, tx, wx, span_x = _up_taps(w, big_w, x.device)
+        y = torch.empty(n, c, big_h, big_w, dtype=torch.float32, device=x.device)
+        L.call('u2mkd_up_bilinear_forward', L.ptr(x), L.ptr(skip), n * c, h, w, big_h, big_w, rh, rw, L.ptr(y), L.stream())
+        tiled = int(span_y[16] <= 40 and span_x[64] <= 136 and n * c <= 65535)
+        ctx.geom = (n, c, h, w, big_h, big_w, ty, wy, tx, wx, tiled)
+        ctx.has_skip = skip is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib as L
+        n, c, h, w, big_h, big_w, ty, wy, tx, wx, tiled = ctx.geom
+        g = g.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(n, c, h, w, dtype=torch.float32, device=g.device)
+            L.call('u2mkd_up_bilinear_backward', L.ptr(g), n * c, h, w, big_h, big_w, L.ptr(ty), L.ptr(wy), L.ptr(tx), L.ptr(wx),
+                   tiled, L.ptr(dx), L.stream())
+        return dx, (g if ctx.has_skip and ctx.needs_input_grad[1] else None), None
+
+
+def _up(x, size, skip=None):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) [+ skip]."""
+    size = tuple(int(v) for v in size)
+    if (_up_on_hip() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() and not torch.is_autocast_enabled()
+            and size[0] >= x.shape[2] and size[1] >= x.shape[3] and (skip is None or (skip.dtype == x.dtype and skip.is_contiguous()
+                                                                                      and skip.shape[2:] == size))):
+        if _up_taps(x.shape[2], size[0], x.device)[1] is not None and _up_taps(x.shape[3], size[1], x.device)[1] is not None:
+            return _UpBilinearFunction.apply(x, skip, size)
+    y = F.interpolate(x, size, mode='bilinear', align_corners=True)
+    return y if skip is None else y + skip
 
 
 class _BatchNorm2dFunction(torch.autograd.Function):
@@ -288,7 +378,7 @@ class _Upsample(nn.Module):
 
     def forward(self, x, skip):
         skip = self.bottleneck(skip)
-        return self.blend_conv(_up(x, skip.shape[2:4]) + skip)
+        return self.blend_conv(_up(x, skip.shape[2:4], skip))
 
 
 class SwiftNetResNet(nn.Module):

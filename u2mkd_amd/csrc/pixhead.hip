@@ -222,6 +222,108 @@ maxpool3s2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ 
     dx[e] = g;
 }
 
+// ---- F.interpolate(mode='bilinear', align_corners=True) of NCHW maps (+ the skip add that follows it in the decoder) ---
+// torch's kernels run the decoder's up-samplings at ~0.5 TB/s and their backward scatters with float atomics (run-to-run
+// differences in the camera branch's gradients).  Forward: one thread per output element, torch's fp32 index
+// arithmetic (src = scale * dst, lambda = src - floor, h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d)), optionally
+// + skip in the same pass.  Backward: a GATHER per input element over the outputs that read it -- per-axis lists
+// (taps[i] = first output, count; weight per (input, tap)) built once per size on the host from the same arithmetic --
+// summed in a fixed order: deterministic.
+// source index and fraction of one axis: the fraction is of the ROUNDED product scale * dst (torch's kernel; a fused
+// multiply-add here moves the up-sampled map by ~1e-5)
+__device__ __forceinline__ void up_source(float scale, int dst, int &i0, float &lambda1) {
+#pragma clang fp contract(off)
+    const float src = scale * (float)dst;
+    i0 = (int)src;
+    lambda1 = src - (float)i0;
+}
+
+__global__ void __launch_bounds__(256)
+up_bilinear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ skip, int64_t total, int h, int w, int H, int W,
+                       float rh, float rw, float *__restrict__ y) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int ox = (int)(e % W);
+    const int64_t r = e / W;
+    const int oy = (int)(r % H);
+    const int64_t plane = r / H;
+    int h1, w1;
+    float h1l, w1l;
+    up_source(rh, oy, h1, h1l);
+    up_source(rw, ox, w1, w1l);
+    const int h1p = h1 < h - 1 ? 1 : 0, w1p = w1 < w - 1 ? 1 : 0;
+    const float h0l = 1.f - h1l, w0l = 1.f - w1l;
+    const float *xp = x + plane * (int64_t)h * w + (int64_t)h1 * w + w1;
+    float v = h0l * (w0l * xp[0] + w1l * xp[w1p]) + h1l * (w0l * xp[(int64_t)h1p * w] + w1l * xp[(int64_t)h1p * w + w1p]);
+    if (skip) v += skip[e];
+    y[e] = v;
+}
+
+// dx[plane][i][j] = sum over outputs (oy, ox) that read (i, j) of wy * wx * g[oy][ox]; ty / tx: per input index the first
+// output index and the number of outputs (int2), wy / wx: [n_in][kUpTaps] weights (0 beyond the count)
+constexpr int kUpTaps = 8;
+__global__ void __launch_bounds__(256)
+up_bilinear_bwd_kernel(const float *__restrict__ g, int64_t total_in, int h, int w, int H, int W, const int2 *__restrict__ ty,
+                       const float *__restrict__ wy, const int2 *__restrict__ tx, const float *__restrict__ wx,
+                       float *__restrict__ dx) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total_in) return;
+    const int j = (int)(e % w);
+    const int64_t r = e / w;
+    const int i = (int)(r % h);
+    const int64_t plane = r / h;
+    const float *gp = g + plane * (int64_t)H * W;
+    const int2 ry = ty[i], rx = tx[j];
+    float acc = 0.f;
+    for (int a = 0; a < ry.y; ++a) {
+        const float *row = gp + (int64_t)(ry.x + a) * W + rx.x;
+        float t = 0.f;
+        for (int b = 0; b < rx.y; ++b) t += wx[j * kUpTaps + b] * row[b];
+        acc += wy[i * kUpTaps + a] * t;
+    }
+    dx[e] = acc;
+}
+
+// the same sum with the block's window of g staged in LDS: a tile of kUpTi x kUpTj inputs reads the output rows
+// [ty[i_first].x, ty[i_last].x + ty[i_last].y) x columns likewise (monotone lists); the caller has checked that every
+// tile's window fits kUpLr x kUpLc.  g is read from HBM once, coalesced; 256 threads = 4 row groups x 64 columns
+constexpr int kUpTi = 16, kUpTj = 64, kUpLr = 40, kUpLc = 136;
+__global__ void __launch_bounds__(256)
+up_bilinear_bwd_tiled_kernel(const float *__restrict__ g, int h, int w, int H, int W, const int2 *__restrict__ ty,
+                             const float *__restrict__ wy, const int2 *__restrict__ tx, const float *__restrict__ wx,
+                             float *__restrict__ dx) {
+    __shared__ float win[kUpLr][kUpLc + 1];
+    const int j0 = blockIdx.x * kUpTj, i0 = blockIdx.y * kUpTi;
+    const int64_t plane = blockIdx.z;
+    const int i1 = min(i0 + kUpTi, h) - 1, j1 = min(j0 + kUpTj, w) - 1;
+    const int r_lo = ty[i0].x, r_hi = ty[i1].x + ty[i1].y, c_lo = tx[j0].x, c_hi = tx[j1].x + tx[j1].y;
+    const int nr = r_hi - r_lo, nc = c_hi - c_lo;
+    const float *gp = g + plane * (int64_t)H * W;
+    for (int rr = threadIdx.x / 64; rr < nr; rr += 4)
+        for (int cc = threadIdx.x % 64; cc < nc; cc += 64) win[rr][cc] = gp[(int64_t)(r_lo + rr) * W + c_lo + cc];
+    __syncthreads();
+    const int j = j0 + threadIdx.x % 64;
+    if (j > j1) return;
+    const int2 rx = tx[j];
+    float wxj[kUpTaps];
+#pragma unroll
+    for (int b = 0; b < kUpTaps; ++b) wxj[b] = wx[j * kUpTaps + b];
+    const int cb = rx.x - c_lo;
+    for (int i = i0 + threadIdx.x / 64; i <= i1; i += 4) {
+        const int2 ry = ty[i];
+        float acc = 0.f;
+        for (int a = 0; a < ry.y; ++a) {
+            const float *row = &win[ry.x - r_lo + a][cb];
+            float t = 0.f;
+#pragma unroll
+            for (int b = 0; b < kUpTaps; ++b)
+                if (b < rx.y) t += wxj[b] * row[b];
+            acc += wy[i * kUpTaps + a] * t;
+        }
+        dx[plane * (int64_t)h * w + (int64_t)i * w + j] = acc;
+    }
+}
+
 }  // namespace u2mkd
 
 using namespace u2mkd;
@@ -294,6 +396,34 @@ int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t plan
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), dy, code, total, h,
                        w, oh, ow, dx);
     return check_launch("u2mkd_maxpool3s2_backward");
+}
+
+int u2mkd_up_bilinear_forward(const float *x, const float *skip, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W,
+                              float rh, float rw, float *y, u2mkd_stream_t s) {
+    if (planes == 0) return 0;
+    U2_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "u2mkd_up_bilinear_forward: bad arguments");
+    const int64_t total = planes * H * W;
+    hipLaunchKernelGGL(up_bilinear_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), x, skip, total, h,
+                       w, H, W, rh, rw, y);
+    return check_launch("u2mkd_up_bilinear_forward");
+}
+
+int u2mkd_up_bilinear_backward(const float *g, int64_t planes, int32_t h, int32_t w, int32_t H, int32_t W, const int32_t *taps_y,
+                               const float *wy, const int32_t *taps_x, const float *wx, int32_t tiled, float *dx, u2mkd_stream_t s) {
+    if (planes == 0) return 0;
+    U2_REQUIRE(g && taps_y && wy && taps_x && wx && dx && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0,
+               "u2mkd_up_bilinear_backward: bad arguments");
+    U2_REQUIRE(!tiled || planes <= 65535, "u2mkd_up_bilinear_backward: the tiled form takes at most 65535 planes");
+    const int64_t total = planes * h * w;
+    if (tiled) {
+        hipLaunchKernelGGL(up_bilinear_bwd_tiled_kernel, dim3((unsigned)ceil_div(w, kUpTj), (unsigned)ceil_div(h, kUpTi), (unsigned)planes),
+                           dim3(256), 0, as_stream(s), g, h, w, H, W, reinterpret_cast<const int2 *>(taps_y), wy,
+                           reinterpret_cast<const int2 *>(taps_x), wx, dx);
+        return check_launch("u2mkd_up_bilinear_backward");
+    }
+    hipLaunchKernelGGL(up_bilinear_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), g, total, h, w, H,
+                       W, reinterpret_cast<const int2 *>(taps_y), wy, reinterpret_cast<const int2 *>(taps_x), wx, dx);
+    return check_launch("u2mkd_up_bilinear_backward");
 }
 
 }  // extern "C"
