@@ -1,0 +1,165 @@
+"""u2mkd_amd.builder: the configuration container (torchpack's `configs` as the reference uses it,
+train_lc_nusc_tsd_full.py:33-35) and the make_* branches of core/builder.py the KD path uses.  The configuration trees
+below carry the VALUES of configs/nuscenes/{default,train/default,train/spformer,train/spformer_tsd_full_ours_star}.yaml
+that these branches read; they are written to a temporary directory in the reference's layout so that
+`load(recursive=True)` has defaults to find."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from u2mkd_amd import builder as B
+
+ROOT = {'data': {'num_classes': 17, 'ignore_label': 0, 'training_size': 28130},
+        'dataset': {'root': '/nowhere', 'voxel_size': 0.05},
+        'num_epochs': 25, 'batch_size': 4,
+        'optimizer': {'name': 'sgd', 'lr': 0.24, 'weight_decay': 1.0e-4, 'momentum': 0.9, 'nesterov': True},
+        'scheduler': {'name': 'cosine_warmup'}}
+TRAIN_DEFAULT = {'criterion': {'name': 'lc_lovasz', 'ignore_index': 0},
+                 'model': {'imagenet_pretrain': None, 'in_channel': 4, 'name': 'spvcnn_swiftnet18', 'cr': 0.64}}
+SPFORMER = {'criterion': {'name': 'lovasz', 'ignore_index': 0},
+            'model': {'in_channel': 4, 'name': 'spvcnn_spformer', 'quant_size_scale': 24, 'patch_size': 1, 'window_size': 6,
+                      'drop_path_rate': 0.3, 'window_size_sphere': [2, 2, 120], 'window_size_scale': [2.0, 2.0], 'a': 0.0125,
+                      'cr': 1.0},
+            'num_epochs': 25, 'batch_size': 3}
+TSD = {'criterion': {'name': ['lovasz', 'kl', 'mse'], 'w_kl': 1.0, 'w_feat': 1.0, 'ignore_index': 0, 'mse_norm_feat': False},
+       'num_epochs': 50, 'batch_size': 4,
+       'model': {'in_channel': 4, 'name': 'spvcnn_swiftnet18_spformer_tsd_full', 'cr': 1.0, 'cr_t': 2.0, 'quant_size_scale': 24,
+                 'patch_size': 1, 'window_size': 6, 'drop_path_rate': 0.3, 'window_size_sphere': [2, 2, 120],
+                 'window_size_scale': [2.0, 2.0], 'a': 0.0125, 'align_loss': 'mse'},
+       'debug': {'show_image': False, 'debug_val': True}, 'eval': {'run_pix_decoder': True, 'run_align_loss': True}}
+
+
+@pytest.fixture()
+def tree(tmp_path):
+    d = tmp_path / 'configs' / 'nuscenes' / 'train'
+    d.mkdir(parents=True)
+    for path, content in ((tmp_path / 'configs' / 'nuscenes' / 'default.yaml', ROOT), (d / 'default.yaml', TRAIN_DEFAULT),
+                          (d / 'spformer.yaml', SPFORMER), (d / 'tsd.yaml', TSD)):
+        path.write_text(yaml.safe_dump(content))
+    return str(d)
+
+
+def test_recursive_load_merges_defaults_outermost_first(tree):
+    cfg = B.Config.load(os.path.join(tree, 'tsd.yaml'), recursive=True)
+    assert cfg.data.num_classes == 17 and cfg['dataset']['voxel_size'] == 0.05          # from the outer default
+    assert cfg.model.name == 'spvcnn_swiftnet18_spformer_tsd_full' and cfg.model.cr == 1.0   # the file wins over train/default
+    assert cfg.model.imagenet_pretrain is None and 'cr_t' in cfg.model                   # merged, not replaced
+    assert cfg.criterion.name == ['lovasz', 'kl', 'mse'] and cfg.num_epochs == 50
+    flat = B.Config.load(os.path.join(tree, 'tsd.yaml'))
+    assert 'data' not in flat
+    with pytest.raises(FileNotFoundError):
+        B.Config.load(os.path.join(tree, 'missing.yaml'), recursive=True)
+    with pytest.raises(AttributeError):
+        cfg.model.no_such_key
+
+
+def test_command_line_overrides(tree):
+    cfg = B.Config.load(os.path.join(tree, 'tsd.yaml'), recursive=True)
+    cfg.update(['--model.in_channel_t', '4', '--optimizer.lr=1e-3', '--model.window_size_sphere', '[1, 1, 60]',
+                '--debug.debug_val', 'false', '--run_name', 'a-b'])
+    assert cfg.model.in_channel_t == 4 and cfg.optimizer.lr == 1e-3 and cfg.model.window_size_sphere == [1, 1, 60]
+    assert cfg.debug.debug_val is False and cfg.run_name == 'a-b' and cfg.optimizer.momentum == 0.9
+    cfg.update({'run_dir': 'x', 'model': {'cr': 2.0}})                                  # vars(args): a mapping
+    assert cfg.model.cr == 2.0 and cfg.model.cr_t == 2.0 and cfg.run_dir == 'x'
+    with pytest.raises(ValueError):
+        cfg.update(['--dangling'])
+
+
+def test_make_model_branches(tree):
+    from u2mkd_amd import kd, lidar
+    cfg = B.Config.load(os.path.join(tree, 'spformer.yaml'), recursive=True)
+    m = B.make_model(cfg)
+    assert isinstance(m, lidar.SPVCNN_SPFORMER) and m.cs[0] == 32 and m.num_classes == 17
+    twin = lidar.SPVCNN_SPFORMER(**lidar.spformer_kwargs())      # the keyword form the other tests build the model with
+    np.testing.assert_array_equal(m.window_size, twin.window_size)
+    np.testing.assert_array_equal(np.asarray(m.quant_size_sphere), np.asarray(twin.quant_size_sphere))
+    assert [k for k in m.state_dict()] == [k for k in twin.state_dict()]
+    assert all(a.shape == b.shape for a, b in zip(m.state_dict().values(), twin.state_dict().values()))
+    assert isinstance(B.make_model(cfg, 'spvcnn'), lidar.SPVCNN)
+    with pytest.raises(NotImplementedError):
+        B.make_model(cfg, 'spvcnn_swiftnet18')                   # commented out in the reference's builder too
+
+    cfg = B.Config.load(os.path.join(tree, 'tsd.yaml'), recursive=True)
+    with pytest.raises(KeyError):
+        B.make_model(cfg)                                        # model.in_channel_t comes from the command line (tsd_full.py:30)
+    cfg.update(['--model.in_channel_t', '4'])
+    m = B.make_model(cfg)
+    assert isinstance(m, kd.TSDFull) and m.debug_val is True and m.model_s.run_pix_decoder is True
+    assert m.model_s.cs[0] == 32 and m.model_t.cs[0] == 64                       # cr 1.0 / cr_t 2.0
+    assert not any(p.requires_grad for p in m.model_t.parameters())
+    # student and teacher receive separate copies of the hyper-parameters (tsd_full.py:566-569)
+    assert m.model_s.quant_size_sphere is not m.model_t.quant_size_sphere
+
+
+def test_make_criteria_optimizer_scheduler(tree):
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    cfg = B.Config.load(os.path.join(tree, 'tsd.yaml'), recursive=True)
+    crit = B.make_criterion_dict(cfg)
+    assert sorted(crit) == ['kl', 'lovasz', 'mse'] and isinstance(crit['lovasz'], MixLovaszCrossEntropy)
+    assert crit['kl'].reduction == 'batchmean' and crit['mse'].reduction == 'mean'
+    kdc = B.make_kd_criterion(cfg)
+    assert (kdc.w_kl, kdc.w_feat, kdc.mse_norm_feat) == (1.0, 1.0, False)
+    cfg.criterion.name = ['lovasz', 'huber']
+    with pytest.raises(NotImplementedError):
+        B.make_criterion_dict(cfg)
+
+    one = B.Config.load(os.path.join(tree, 'spformer.yaml'), recursive=True)
+    assert isinstance(B.make_criterion(one, device='cpu'), MixLovaszCrossEntropy)
+    one.criterion.class_weight = [1.0] * 17
+    assert B.make_criterion(one, device='cpu').ce.weight.shape == (17,)
+    one.criterion.name = 'cross_entropy'
+    assert isinstance(B.make_criterion(one), torch.nn.CrossEntropyLoss)
+    one.criterion.name = 'lc_lovasz'
+    with pytest.raises(NotImplementedError):
+        B.make_criterion(one)
+
+    net = torch.nn.ModuleDict({'stem': torch.nn.Linear(4, 4), 'transformer_block': torch.nn.Linear(4, 4)})
+    opt = B.make_optimizer(one, net)
+    assert isinstance(opt, torch.optim.SGD) and opt.defaults['nesterov'] and opt.defaults['lr'] == 0.24
+    one.optimizer.name = 'sgd_spformer'
+    opt = B.make_optimizer(one, net)
+    assert [g['lr'] for g in opt.param_groups] == [0.24, 0.24 * 0.1]
+    one.optimizer.name = 'lamb'
+    with pytest.raises(NotImplementedError):
+        B.make_optimizer(one, net)
+    one.optimizer.name = 'sgd'
+    opt = B.make_optimizer(one, net)
+
+    sch = B.make_scheduler(one, opt, world=1)                   # cosine_warmup, per iteration
+    iters = 25 * ((28130 + 2) // 3)
+    lrs = []
+    for _ in range(3):
+        opt.step(); sch.step(); lrs.append(opt.param_groups[0]['lr'])
+    assert lrs[0] == pytest.approx(0.24 * 0.5 * (1 + np.cos(np.pi * 1 / iters)))
+    sch8 = B.make_scheduler(one, B.make_optimizer(one, net), world=8)
+    assert sch8.get_last_lr()[0] == pytest.approx(0.24 / 125)   # warm-up of 1000 // 8 iterations exists for world > 1
+    one.scheduler = {'name': 'poly', 'power': 0.9}
+    poly = B.make_scheduler(one, B.make_optimizer(one, net))
+    assert poly.get_last_lr()[0] == pytest.approx(0.24)
+    one.scheduler.name = 'cosine'
+    assert isinstance(B.make_scheduler(one, B.make_optimizer(one, net)), torch.optim.lr_scheduler.CosineAnnealingLR)
+    one.scheduler.name = 'none'
+    assert B.make_scheduler(one, B.make_optimizer(one, net)).get_last_lr()[0] == pytest.approx(0.24)
+    one.scheduler.name = 'step'
+    with pytest.raises(NotImplementedError):
+        B.make_scheduler(one, opt)
+
+
+def test_make_dataset_reads_the_loader_keys(tree):
+    cfg = B.Config.load(os.path.join(tree, 'tsd.yaml'), recursive=True)
+    cfg.dataset.name = 'semantic_kitti'
+    with pytest.raises(NotImplementedError):
+        B.make_dataset(cfg, tables=object())
+
+    class Tables:                                # make_dataset only hands the tables on
+        sample = [{'token': 'a'}, {'token': 'b'}, {'token': 'c'}]
+    cfg.dataset.update({'name': 'lc_semantic_nusc_tsd_full', 'flip': True, 'im_drop': 3, 'im_cr': 0.4,
+                        'multisweeps': {'num_sweeps': 2, 'only_past': False}})
+    ds = B.make_dataset(cfg, tables=Tables())
+    assert sorted(ds) == ['train', 'val'] and len(ds['train']) == 3
+    tr = ds['train']
+    assert (tr.im_drop, tr.multisweeps, tr.only_past, tr.debug, tr.split) == (3, 2, False, True, 'train')
+    assert tr.input_image_size == [360, 640] and tr.voxel_size == 0.05 and ds['val'].split == 'val'

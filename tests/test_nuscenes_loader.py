@@ -30,6 +30,20 @@ def _cam_rotation(yaw_deg):
     return np.stack([-left, -up, fwd], axis=1)       # columns = camera axes in ego coordinates
 
 
+def _points_seen(feed_dict_s, n):
+    """Raw points inside some camera image: the voxel-level masks say so for the kept point of every voxel; a dropped
+    point projects like itself, so this helper re-derives the set from `label_fov` != ignore or label == ignore."""
+    lab, fov = feed_dict_s['targets_mapped'].F, feed_dict_s['label_fov'].F
+    assert len(lab) == n and np.all((fov == lab) | (fov == 0))
+    kept = np.zeros(n, bool)
+    kept[feed_dict_s['inds'][0]] = feed_dict_s['fov_mask'].F
+    assert np.all(fov[kept & (lab != 0)] == lab[kept & (lab != 0)])          # a seen kept point keeps its label
+    unseen_kept = np.zeros(n, bool)
+    unseen_kept[feed_dict_s['inds'][0]] = ~feed_dict_s['fov_mask'].F
+    assert np.all(fov[unseen_kept] == 0)                                        # an unseen kept point is ignored
+    return (fov != 0) | ((lab == 0) & kept)
+
+
 @pytest.fixture(scope='module')
 def tree(tmp_path_factory):
     from PIL import Image
@@ -157,6 +171,12 @@ def test_val_sample_schema_and_projection(tree):
     assert np.allclose(s['pixel_coordinates'][1][want_mask, 0], u[want_mask], atol=1e-9)
     assert np.allclose(s['pixel_coordinates'][1][want_mask, 1], v[want_mask], atol=1e-9)
     assert np.array_equal(s['fov_mask'].F, s['masks'].any(0))
+    # debug.debug_val (:137, 453-456): the labels of the points some camera sees, `ignore` elsewhere, over ALL raw points
+    assert 'label_fov' not in s
+    dbg = D.LCNuScenesDataset(tb, voxel_size=0.05, split='val', im_cr=0.1, debug=True)[0]['feed_dict_s']
+    seen = _points_seen(dbg, n)
+    assert np.array_equal(dbg['label_fov'].F, np.where(seen, dbg['targets_mapped'].F, 0))
+    assert np.array_equal(dbg['label_fov'].C, dbg['targets_mapped'].C) and seen.sum() > 10
 
 
 def test_train_sample_drops_cameras_and_multisweep_masks(tree):

@@ -120,13 +120,14 @@ class LCNuScenesDataset(torch.utils.data.Dataset):
     None = all samples.  ``rng``: numpy Generator for the augmentations (the reference uses the global numpy state)."""
 
     def __init__(self, tables: NuScenesTables, voxel_size=0.05, split='train', im_cr=0.4, im_drop=3, flip=True,
-                 multisweeps=0, only_past=False, ignore_index=0, select_idx=None, rng=None):
+                 multisweeps=0, only_past=False, ignore_index=0, select_idx=None, rng=None, debug=False):
         self.nusc = tables
         self.voxel_size, self.split = voxel_size, split
         self.input_image_size = [int(x * im_cr) for x in IMAGE_SIZE]                          # :133-134
         self.im_drop, self.flip_aug = im_drop, flip
         self.multisweeps, self.only_past = multisweeps, only_past
         self.ignored_labels = ignore_index
+        self.debug = debug                              # configs['debug']['debug_val'] (:137): adds `label_fov` (:453-456)
         self.rng = rng or np.random.default_rng()
         self.sample = tables.sample if select_idx is None else [tables.sample[int(i)] for i in select_idx]
 
@@ -291,6 +292,10 @@ class LCNuScenesDataset(torch.utils.data.Dataset):
             'targets_mapped': SparseTensor(labels_raw, voxel), 'inverse_map': SparseTensor(inverse_map, voxel),
             'images': images, 'pixel_coordinates': pixel_coordinates[:, inds, :], 'masks': masks[:, inds],
             'fov_mask': SparseTensor(pt_with_img[inds], voxel_full), 'inds': [inds], 'num_vox': voxel_full.shape[0]}
+        if self.debug:                                  # labels of the points a camera sees, `ignore` elsewhere (:453-456)
+            label_fov = np.full_like(labels_raw, fill_value=self.ignored_labels)
+            label_fov[pt_with_img] = labels_raw[pt_with_img]
+            feed_dict_s['label_fov'] = SparseTensor(label_fov, voxel)
         return {'feed_dict_s': feed_dict_s, 'feed_dict_t': feed_dict_t, 'lidar_token': lidar_token}
 
     collate_fn = staticmethod(lambda batch: collate_fn(batch))
@@ -335,4 +340,5 @@ def collated_to_kd_batch(c):
                'num_pts': list(t['num_pts']), 'num_vox': list(t['num_vox'])}
     if 'keyframe_mask_full' in t:
         teacher['keyframe_mask_full'] = npy(t['keyframe_mask_full'].F).astype(bool)
+        teacher['keyframe_mask'] = npy(t['keyframe_mask'].F).astype(bool)
     return {'student': student, 'teacher': teacher}

@@ -93,13 +93,19 @@ def _scheduler(opt, num_epochs, batch_size, dataset_size=28130):
 class LidarStep:
     """Teacher / LiDAR-only training step."""
 
-    def __init__(self, model, num_epochs=25, batch_size=1, ignore_index=0, amp=False):
+    def __init__(self, model, num_epochs=25, batch_size=1, ignore_index=0, amp=False, criterion=None, optimizer=None,
+                 scheduler=None):
+        """``criterion`` / ``optimizer`` / ``scheduler``: what the reference's trainer receives from core/builder.py
+        (train_spformer.py:84-95) -- the criterion as an object, the other two as callables of (module) and (optimizer)
+        because the module they act on is the DDP-wrapped one built here; None = the shipped configuration's (Lovasz +
+        CE, SGD nesterov 0.24, cosine_warmup)."""
         self.model = model
         self.amp = _Amp(amp)
         self.net = D.wrap_model(model, sync_bn=True)
-        self.criterion = MixLovaszCrossEntropy(ignore_index=ignore_index)
-        self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
-        self.sched = _scheduler(self.opt, num_epochs, batch_size)
+        self.criterion = criterion if criterion is not None else MixLovaszCrossEntropy(ignore_index=ignore_index)
+        self.opt = optimizer(self.net) if optimizer is not None else \
+            make_optimizer([p for p in self.net.parameters() if p.requires_grad])
+        self.sched = scheduler(self.opt) if scheduler is not None else _scheduler(self.opt, num_epochs, batch_size)
 
     def __call__(self, feats, coords, targets, keyframe_mask=None, prefetch=None):
         """One training step.  ``prefetch`` = (feats, coords) of the NEXT batch (the tensors the next call will receive):
@@ -159,6 +165,12 @@ def kd_batch_to_device(b, device='cuda'):
         'num_pts': list(t['num_pts']), 'num_vox_t': list(t['num_vox']),
         'keyframe_mask_full': f(t['keyframe_mask_full']) if 'keyframe_mask_full' in t else None,
     }
+    # the teacher-only trainer's own labels and voxel-level key-frame mask (core/spformer_trainer.py:64-68), when the
+    # batch carries them
+    if 'targets' in t:
+        out['targets_t'] = f(t['targets'])
+    if 'keyframe_mask' in t:
+        out['keyframe_mask'] = f(t['keyframe_mask'])
     return out
 
 
@@ -179,16 +191,20 @@ class KDStep:
     """Uni-to-multi-modal KD training step: frozen teacher forward (no grad, eval-mode BN),
     student forward/backward, the five loss terms."""
 
-    def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0, amp=False):
+    def __init__(self, model: KD.TSDFull, num_epochs=50, batch_size=1, w_kl=1.0, w_feat=1.0, amp=False, criterion=None,
+                 optimizer=None, scheduler=None):
+        """``criterion``: a kd.KDCriterion (builder.make_kd_criterion); ``optimizer`` / ``scheduler``: factories of
+        (module) / (optimizer), as for LidarStep (train_lc_nusc_tsd_full.py:84-93)."""
         self.model = model
         self.amp = _Amp(amp)
         if D.world() > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':      # (the knob: the N>1 code path on one GPU)
             from .lidar.point_voxel import SparseSyncBatchNorm
             model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
         self.net = D.wrap_model(model, sync_bn=False)
-        self.crit = KD.KDCriterion(ignore_index=0, w_kl=w_kl, w_feat=w_feat)
-        self.opt = make_optimizer([p for p in self.net.parameters() if p.requires_grad])
-        self.sched = _scheduler(self.opt, num_epochs, batch_size)
+        self.crit = criterion if criterion is not None else KD.KDCriterion(ignore_index=0, w_kl=w_kl, w_feat=w_feat)
+        self.opt = optimizer(self.net) if optimizer is not None else \
+            make_optimizer([p for p in self.net.parameters() if p.requires_grad])
+        self.sched = scheduler(self.opt) if scheduler is not None else _scheduler(self.opt, num_epochs, batch_size)
 
     def train_mode(self):
         self.model.train()
