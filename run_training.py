@@ -128,6 +128,7 @@ def main(argv=None):
     ap.add_argument('--non-dist', action='store_true', help='single process (the reference spells this flag inverted)')
     ap.add_argument('--max-iters', type=int, default=0, help='stop every epoch (training and validation) after K batches')
     ap.add_argument('--synthetic', type=int, default=0, metavar='N_VOXELS', help='synthetic scenes instead of dataset.root')
+    ap.add_argument('--backend', default=None, help='process-group backend (default nccl = RCCL; gloo: several ranks on one GPU, tests)')
     args, opts = ap.parse_known_args(argv)
 
     cfg = builder.Config.load(args.config, recursive=True)
@@ -136,7 +137,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise RuntimeError('run_training.py drives the HIP operators: no GPU is visible (there is no CPU fallback)')
     if not args.non_dist:
-        D.init_from_env()
+        D.init_from_env(args.backend)
     rank, world = D.rank(), D.world()
     run_dir = args.run_dir or os.path.join('runs', time.strftime('run-%Y%m%d-%H%M%S'))
     if rank == 0:

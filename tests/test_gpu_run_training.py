@@ -1,7 +1,11 @@
 """run_training.py end to end on the GPU: the two stages of the reference's pipeline (README: train_spformer.py, then
 train_lc_nusc_tsd_full.py with `model.teacher_pretrain` = the first stage's best checkpoint), from configuration files in
 the reference's layout -- once on synthetic scenes, once on the synthetic on-disk nuScenes tree of the loader's tests."""
+import json
 import os
+import socket
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -76,3 +80,28 @@ def test_kd_trainer_on_the_on_disk_tree(hip, tmp_path, tree):  # noqa: F811
     assert len(h) == 1 and h[0]['loss'] == h[0]['loss']
     assert all(0.0 <= h[0][k] <= 1.0 for k in ('iou-vox/val', 'iou-pix/val', 'iou-vox-t/val'))
     assert os.path.isfile(tmp_path / 'run' / 'checkpoints' / 'step-1.pt') and os.path.isfile(tmp_path / 'run' / 'history.json')
+
+
+def test_two_ranks_on_one_gpu_train_the_kd_student(hip, tmp_path):
+    """The launcher contract of the reference (torchrun, one rank per GPU) with two ranks: SyncBatchNorm conversion of
+    the student + DDP inside train.KDStep, a DistributedSampler shard per rank, the all-reduced MeanIoU, rank 0 alone
+    writing the checkpoints.  RCCL refuses two ranks on one device, so the group is gloo (`--backend gloo`): the kernels
+    are the product's, the collectives travel through host memory."""
+    cfgs = _configs(tmp_path, im_cr=0.08)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    run = str(tmp_path / 'kd_ddp')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(repo, 'run_training.py'), os.path.join(cfgs, 'tsd.yaml'), '--run-dir', run,
+           '--backend', 'gloo', '--synthetic', '2000', '--max-iters', '2', '--model.in_channel_t', '4', '--optimizer.lr', '0.01']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    p = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert 'world 2' in p.stdout
+    hist = json.load(open(os.path.join(run, 'history.json')))
+    assert len(hist) == 1 and hist[0]['loss'] == hist[0]['loss'] and 0.0 <= hist[0]['iou-vox/val'] <= 1.0
+    ck = torch.load(os.path.join(run, 'checkpoints', 'step-2.pt'), map_location='cpu', weights_only=False)
+    assert all(k.startswith('module.') for k in ck['model'])                   # saved from the DDP wrapper, as the reference does
+    assert any('model_s' in k and k.endswith('.kernel') for k in ck['model'])

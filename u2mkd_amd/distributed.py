@@ -25,6 +25,8 @@ def init_from_env(backend: str | None = None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        # (more local ranks than devices: only a gloo group can share a card -- tests on a one-GPU box; RCCL refuses)
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     force = os.environ.get('U2MKD_FORCE_DDP') == '1'     # measure the N>1 code path on one GPU
     if (world_size > 1 or force) and not dist.is_initialized():
