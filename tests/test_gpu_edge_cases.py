@@ -194,3 +194,41 @@ def test_csr_build_equals_a_stable_argsort(hip, e, nv, drop):
     n_live = int(want_seg[-1])
     assert torch.equal(order.cpu().long()[:n_live], want)
     assert bool((order.cpu()[n_live:] == 0).all())
+
+
+def test_batched_geometry_pass_equals_the_level_by_level_one_in_two_round_trips(hip, monkeypatch):
+    """point_voxel.prepare_geometry_many (the KD step's student + teacher): the same voxel sets, coordinates of every
+    level and kernel maps as the level-by-level form (one torch.unique per set), with two host round trips in total and
+    no torch.unique at all."""
+    import numpy as np
+    from u2mkd_amd import torchsparse as ts
+    from u2mkd_amd.lidar import point_voxel as PV
+    from u2mkd_amd.synth import synth_batch
+    from u2mkd_amd.torchsparse.nn import functional as spf
+    scenes = [synth_batch(6000, 2, seed=5), synth_batch(9000, 1, seed=6, sweeps=3)]
+    mk = lambda b: ts.SparseTensor(torch.from_numpy(b['feats']).cuda(), torch.from_numpy(b['coords']).cuda())
+    want = [PV._prepare_geometry_level_by_level(mk(b), 0.05, 0.05) for b in scenes]
+    trips = []
+    real = spf.read_counts
+    monkeypatch.setattr(spf, 'read_counts', lambda t: (trips.append(len(t)), real(t))[1])
+    monkeypatch.setattr(torch, 'unique', lambda *a, **k: (_ for _ in ()).throw(AssertionError('torch.unique in the batched pass')))
+    got = PV.prepare_geometry_many([(mk(b), 0.05, 0.05) for b in scenes])
+    assert trips == [2, 2 * 5]                       # sizes of the two voxel sets; 4 levels + the range flag per network
+    for (zw, xw), (zg, xg) in zip(want, got):
+        assert torch.equal(xw.C, xg.C) and torch.equal(xw.F, xg.F) and torch.equal(zw.C, zg.C)
+        assert list(xw.cmaps) == list(xg.cmaps) and list(xw.kmaps) == list(xg.kmaps) and len(xw.kmaps) == 9
+        for key in xw.cmaps:
+            assert torch.equal(xw.cmaps[key], xg.cmaps[key]), key
+        for key in xw.kmaps:
+            a, b = xw.kmaps[key], xg.kmaps[key]
+            assert (a.n_in, a.n_out) == (b.n_in, b.n_out) and torch.equal(a.nbr, b.nbr), key
+            assert (a.nbr_inv is None) == (b.nbr_inv is None) and (a.nbr_inv is None or torch.equal(a.nbr_inv, b.nbr_inv))
+        assert torch.equal(zw.additional_features['idx_query'][1], zg.additional_features['idx_query'][1])
+    # an out-of-range coordinate is still reported (the flag travels with the sizes)
+    bad = torch.from_numpy(scenes[0]['coords']).cuda().clone()
+    bad[7, 0] = 140000 * 16
+    monkeypatch.undo()
+    with pytest.raises(ValueError, match='packed key range'):
+        spf.DownsamplePyramid(bad, [2, 4]).finish(spf.read_counts(spf.DownsamplePyramid(bad, [2, 4]).counts()))
+    ok = spf.DownsamplePyramid(torch.from_numpy(scenes[0]['coords']).cuda(), [2])
+    assert ok.finish(spf.read_counts(ok.counts()))[(2, 2, 2)].shape[1] == 4          # the flag was cleared

@@ -21,7 +21,7 @@ from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c
 from .pixel_head import sampled_head_applies, sampled_pixel_logits
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
-from .lidar.point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, voxel_to_point
+from .lidar.point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, prepare_geometry_many, voxel_to_point
 from .torchsparse.nn import functional as spf
 from .lidar.sphereformer import SphereFormer
 from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
@@ -292,8 +292,8 @@ class TSDFull(nn.Module):
         forward while step k's backward -- ~30 ms of queued kernels -- drains, instead of sitting in the next
         forward's first synchronisation for as long."""
         with torch.no_grad():
-            g_s = prepare_geometry(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres)
-            g_t = prepare_geometry(in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)
+            g_s, g_t = prepare_geometry_many([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres),
+                                              (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)])
         in_mod['student']['_geometry'] = g_s
         in_mod['teacher']['_geometry'] = g_t
         return in_mod

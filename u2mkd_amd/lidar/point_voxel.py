@@ -7,6 +7,8 @@ each step is one HIP launch: the 8-corner hash + probe is fused with the
 trilinear weights and the [8,N]->[N,8] transposes, and index tensors are kept
 in the int32 form the kernels consume.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -31,15 +33,20 @@ def _floor_coords(pc, stride):
     return torch.cat([xyz, pc[:, -1].int().view(-1, 1)], 1)
 
 
-def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
-    """Points -> stride-1 voxels (mean of coords and feats per voxel); voxel
-    order = ascending FNV hash (torch.unique), as core/models/utils.py:15-35."""
+def _voxelize_issue(z: PointTensor, init_res, after_res):
+    """First half of initial_voxelize: everything up to the (deferred) unique of the point hashes."""
     new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
     floor_c = torch.floor(new_float_coord)
     pc_hash = spf.sphash(floor_c.int())
-    sparse_hash = torch.unique(pc_hash)
-    idx_query = spf.sphashquery(pc_hash, sparse_hash)
-    counts = spf.spcount(idx_query.int(), len(sparse_hash))
+    buf, cnt = spf.unique_sorted_deferred(pc_hash)
+    return dict(z=z, coord=new_float_coord, floor_c=floor_c, pc_hash=pc_hash, buf=buf, cnt=cnt)
+
+
+def _voxelize_finish(st, n_vox) -> SparseTensor:
+    z, floor_c = st['z'], st['floor_c']
+    sparse_hash = st['buf'][:n_vox]
+    idx_query = spf.sphashquery(st['pc_hash'], sparse_hash)
+    counts = spf.spcount(idx_query.int(), n_vox)
 
     inserted_coords = spf.spvoxelize(floor_c, idx_query, counts)
     inserted_coords = torch.round(inserted_coords).int()
@@ -49,25 +56,77 @@ def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
     new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     z.additional_features['idx_query'][1] = idx_query
     z.additional_features['counts'][1] = counts
-    z.C = new_float_coord
+    z.C = st['coord']
     return new_tensor
+
+
+def initial_voxelize(z: PointTensor, init_res, after_res) -> SparseTensor:
+    """Points -> stride-1 voxels (mean of coords and feats per voxel); voxel
+    order = ascending FNV hash (the sorted unique hashes), as core/models/utils.py:15-35."""
+    st = _voxelize_issue(z, init_res, after_res)
+    return _voxelize_finish(st, spf.read_counts([st['cnt']])[0])
 
 
 KMAP_SPECS = [(3, 1)] + [(2, 2), (3, 1)] * 4       # the maps an SPVCNN-shaped encoder creates, in forward order
 
 
-def prepare_geometry(x: SparseTensor, pres, vres):
-    """The part of a forward pass that depends on the INPUT BATCH only and needs the host: points -> stride-1 voxels
-    (``initial_voxelize``: a ``torch.unique`` sizes the voxel set) and the kernel maps of the whole encoder
-    (``prefetch_kmaps``: one ``torch.unique`` per down-sampling) -- every host synchronisation of a training step is
-    in here.  Returns ``(z, x0)`` exactly as the first lines of the model's forward leave them; a forward that is
-    handed the pair (``in_mod['_geometry']``) queues its launches without ever waiting for the GPU, so a trainer can
-    prepare batch k+1 while step k's backward drains (train.KDStep ``prefetch=``)."""
+def _level_strides(specs):
+    out, t = [], 1
+    for _, stride in specs:
+        if stride != 1:
+            t *= stride
+            out.append(t)
+    return out
+
+
+# U2MKD_GEOMETRY_BATCHED=0: the level-by-level form (one torch.unique per voxel set and per down-sampling: 6 host round
+# trips per network) for A/B runs
+_BATCHED = os.environ.get('U2MKD_GEOMETRY_BATCHED', '1') != '0'
+
+
+def _prepare_geometry_level_by_level(x: SparseTensor, pres, vres):
     z = PointTensor(x.F, x.C.float())
-    x0 = initial_voxelize(z, pres, vres)
+    st = _voxelize_issue(z, pres, vres)
+    x0 = _voxelize_finish(st, int(torch.unique(st['pc_hash']).shape[0]))
     with spf.deferred_range_check():          # the four down-samplings' out-of-range flag: one read instead of four
         spf.prefetch_kmaps(x0, KMAP_SPECS)
     return z, x0
+
+
+def prepare_geometry_many(items):
+    """prepare_geometry for several networks' inputs (``items`` = [(SparseTensor, pres, vres)]: the KD step's student and
+    teacher) with TWO host round trips in total: the sizes of all stride-1 voxel sets are read together, then the sizes
+    of every down-sampled level of every network (spf.DownsamplePyramid) together with the out-of-range flags -- where
+    the one-network-at-a-time, one-level-at-a-time form stopped the host 6 times per network.  The work queued to the
+    GPU and every result (voxel order, coordinates, kernel maps) are the same."""
+    if not _BATCHED:
+        return [_prepare_geometry_level_by_level(x, pres, vres) for x, pres, vres in items]
+    states = [_voxelize_issue(PointTensor(x.F, x.C.float()), pres, vres) for x, pres, vres in items]
+    sizes = spf.read_counts([st['cnt'] for st in states])                      # round trip 1
+    x0s = [_voxelize_finish(st, n) for st, n in zip(states, sizes)]
+    totals = _level_strides(KMAP_SPECS)
+    pyramids = [spf.DownsamplePyramid(x0.C, totals) if x0.C.shape[0] else None for x0 in x0s]
+    values = spf.read_counts([c for p in pyramids if p is not None for c in p.counts()])   # round trip 2
+    out, at = [], 0
+    for st, x0, pyr in zip(states, x0s, pyramids):
+        if pyr is None:
+            spf.prefetch_kmaps(x0, KMAP_SPECS)
+        else:
+            k = len(totals) + 1
+            spf.prefetch_kmaps(x0, KMAP_SPECS, level_coords=pyr.finish(values[at:at + k]))
+            at += k
+        out.append((st['z'], x0))
+    return out
+
+
+def prepare_geometry(x: SparseTensor, pres, vres):
+    """The part of a forward pass that depends on the INPUT BATCH only and needs the host: points -> stride-1 voxels
+    (``initial_voxelize``: the size of the voxel set) and the kernel maps of the whole encoder (``prefetch_kmaps``: the
+    sizes of the four down-sampled levels) -- every host synchronisation of a training step is in here, two round trips
+    (prepare_geometry_many).  Returns ``(z, x0)`` exactly as the first lines of the model's forward leave them; a
+    forward that is handed the pair (``in_mod['_geometry']``) queues its launches without ever waiting for the GPU, so
+    a trainer can prepare batch k+1 while step k's backward drains (train.KDStep ``prefetch=``)."""
+    return prepare_geometry_many([(x, pres, vres)])[0]
 
 
 def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:

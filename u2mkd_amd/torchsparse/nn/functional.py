@@ -282,6 +282,68 @@ def spdownsample(coords, stride=2, kernel_size=2, tensor_stride=1):
     return out
 
 
+def unique_sorted_deferred(keys):
+    """The sorted unique values of an int64 vector WITHOUT reading their number back (``torch.unique`` stops the host for
+    it): returns (buffer [n] whose first ``count`` entries are the unique values in ascending order, ``count`` as a 0-d
+    int64 device tensor).  A caller that needs several such sets issues them all and reads the counts in ONE round trip
+    (:func:`read_counts`)."""
+    n = keys.shape[0]
+    srt = torch.sort(keys).values
+    head = torch.ones(n, dtype=torch.bool, device=keys.device)
+    if n > 1:
+        torch.ne(srt[1:], srt[:-1], out=head[1:])
+    pos = torch.cumsum(head, 0)
+    buf = torch.empty_like(srt)
+    buf.scatter_(0, pos - 1, srt)                      # equal keys write the same value to the same slot
+    return buf, (pos[-1] if n else torch.zeros((), dtype=torch.int64, device=keys.device))
+
+
+def read_counts(tensors):
+    """One host round trip for a list of 0-d / 1-element device integers."""
+    if not tensors:
+        return []
+    return torch.stack([t.reshape(()).to(torch.int64) for t in tensors]).tolist()
+
+
+class DownsamplePyramid:
+    """Output coordinates of a CHAIN of k = 2, s = 2 down-samplings (the encoder's four levels) from the stride-1
+    coordinates, with one host round trip for all of them instead of one ``torch.unique`` per level: level l of the
+    chain is unique(floor(c / 2^l) * 2^l) of the level below, which equals the same expression applied to the base
+    coordinates, so every level's key set is issued from the base (keys -> sort -> deferred unique) and the sizes are
+    read together with the out-of-range flag.  ``issue`` queues the kernels, ``counts`` lists the device integers the
+    caller reads (read_counts), ``finish`` takes their values and returns {total stride: coords [n_l, 4] int32} in the
+    order spdownsample leaves them (sorted by (b, x, y, z))."""
+
+    def __init__(self, coords, totals):
+        L.require_cuda(coords)
+        self.coords = _i32(coords).contiguous()
+        self.totals = [make_ntuple(t, ndim=3) for t in totals]
+        n = self.coords.shape[0]
+        self.flag = _range_flag(self.coords.device)
+        self.sets = []
+        for ss in self.totals:
+            keys = torch.empty(n, dtype=torch.int64, device=self.coords.device)
+            L.call('u2mkd_downsample_keys_checked', L.ptr(self.coords), n, ss[0], ss[1], ss[2], L.ptr(keys), L.ptr(self.flag), L.stream())
+            self.sets.append(unique_sorted_deferred(keys))
+
+    def counts(self):
+        return [c for _, c in self.sets] + [self.flag]
+
+    def finish(self, values):
+        assert len(values) == len(self.sets) + 1
+        if values[-1] != 0:
+            self.flag.zero_()
+            raise ValueError(_RANGE_MESSAGE)
+        out = {}
+        for ss, (buf, _), cnt in zip(self.totals, self.sets, values):
+            c = torch.empty(cnt, 4, dtype=torch.int32, device=buf.device)
+            L.call('u2mkd_unpack_keys', L.ptr(buf), cnt, L.ptr(c), L.stream())
+            out[ss] = c
+        return out
+
+
+_RANGE_MESSAGE = ('spdownsample: coordinates outside the packed key range (|x|, |y|, |z| < 131072 voxels, '
+                  '0 <= batch index < 512)')
 _RANGE_FLAGS = {}
 _DEFERRED_RANGE_CHECK = threading.local()      # .state = [active, flag, flag, ...], one per host thread
 
@@ -296,8 +358,7 @@ def _deferred():
 def _check_range_flag(flag):
     if int(flag) != 0:
         flag.zero_()
-        raise ValueError('spdownsample: coordinates outside the packed key range (|x|, |y|, |z| < 131072 voxels, '
-                         '0 <= batch index < 512)')
+        raise ValueError(_RANGE_MESSAGE)
 
 
 class deferred_range_check:
@@ -577,9 +638,10 @@ class KernelMap:
         return iter((self[0], self[1], self[2]))
 
 
-def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> KernelMap:
+def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride, out_coords=None) -> KernelMap:
     """Hash the input coordinates, probe every (output, offset) and fill the
-    neighbour table (v1.4.0 conv3d kmap build, fused)."""
+    neighbour table (v1.4.0 conv3d kmap build, fused).  ``out_coords``: the strided map's output coordinates when the
+    caller already holds them (DownsamplePyramid); default: spdownsample."""
     coords = _i32(coords).contiguous()
     L.require_cuda(coords)
     dev = coords.device
@@ -588,7 +650,10 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> Kern
     k = offsets.shape[0]
     table = HashTable(sphash(coords))
     strided = any(s > 1 for s in stride)
-    out_coords = spdownsample(coords, stride, kernel_size, tensor_stride) if strided else coords
+    if not strided:
+        out_coords = coords
+    elif out_coords is None:
+        out_coords = spdownsample(coords, stride, kernel_size, tensor_stride)
     n_out = out_coords.shape[0]
     nbr = torch.empty(k, n_out, dtype=torch.int32, device=dev)
     L.call('u2mkd_kmap_build_table', L.ptr(table.buf), n_in, L.ptr(out_coords), n_out, L.ptr(offsets), k,
@@ -601,7 +666,7 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride) -> Kern
     return KernelMap(nbr, nbr_inv, n_in, n_out, symmetric, out_coords)
 
 
-def prefetch_kmaps(x: SparseTensor, specs) -> None:
+def prefetch_kmaps(x: SparseTensor, specs, level_coords=None) -> None:
     """Build the kernel maps a network is about to ask for, in one go.
 
     ``specs`` lists (kernel_size, stride) of the convs that create maps, in forward order.
@@ -611,7 +676,8 @@ def prefetch_kmaps(x: SparseTensor, specs) -> None:
     four times in the middle of the encoder and cannot queue work ahead of the GPU there.
     Prefetching moves those stops to the start of the step, where the GPU queue is empty
     anyway; everything after is queued without waiting.  Results land in ``x.kmaps`` /
-    ``x.cmaps`` exactly as the lazy path would leave them."""
+    ``x.cmaps`` exactly as the lazy path would leave them.  ``level_coords`` = {total stride: coords} from a
+    DownsamplePyramid: the strided maps then take their output coordinates from it and the loop never waits."""
     coords, ts = x.coords, x.stride
     x.cmaps.setdefault(ts, coords)
     one = (1, 1, 1)
@@ -620,7 +686,10 @@ def prefetch_kmaps(x: SparseTensor, specs) -> None:
         key = (ts, kernel_size, stride, one)
         kmap = x.kmaps.get(key)
         if kmap is None:
-            kmap = x.kmaps[key] = build_kmap(coords, ts, kernel_size, stride)
+            nxt = None
+            if level_coords is not None and stride != one:
+                nxt = level_coords.get(tuple(ts[k] * stride[k] for k in range(3)))
+            kmap = x.kmaps[key] = build_kmap(coords, ts, kernel_size, stride, out_coords=nxt)
         if stride != one:
             coords, ts = kmap.out_coords, tuple(ts[k] * stride[k] for k in range(3))
             x.cmaps.setdefault(ts, coords)
