@@ -32,6 +32,8 @@
 // image, no split, ONE v_mfma_f32_16x16x32_bf16 per 32 channels, fp32 accumulators -- with 64-channel steps where
 // cin allows (a row's step is again one full 128-byte line), weights = the one-plane fragments of
 // u2mkd_weight_fragments(arith 3), scratch rows y / outputs in bf16 (rounded once from the fp32 accumulator).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_internal.h"
@@ -271,12 +273,34 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 // (cin, cout) the kernel takes: whole 32-channel steps and fragment-layout weights (multiples of 32)
 bool conv_px3_supported(int cin, int cout) { return cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0; }
 
+// column tile: 128 (4 waves x 2 column blocks), 96 (3 waves x 2: the 96- and 192-column layers exactly) or 256 (4 waves x 4:
+// layers whose columns are a multiple of 256 -- every row fragment read from LDS feeds twice the MFMAs: 512 -> 512 at stride
+// 8 498 -> 405 us, 256 -> 256 at stride 4 198 -> 184 us; 232 VGPRs = 2 workgroups per CU; U2MKD_PX3_WIDE=0 keeps the 128-column
+// tile there.  The same 4 blocks per wave on TWO waves for the 128-column layers was measured slower: 109 -> 129 us)
+static bool px3_wide(int cout) {
+    static const bool on = !(getenv("U2MKD_PX3_WIDE") && atoi(getenv("U2MKD_PX3_WIDE")) == 0);
+    return on && cout % 256 == 0;
+}
+
+// 192 columns per tile (3 waves x 4 blocks) for the 192-column layers, same switch: 192 -> 192 at stride 1 234 -> 225 us,
+// 256 -> 192 at stride 2 215 -> 204 us
+static bool px3_wide3(int cout) {
+    static const bool on = !(getenv("U2MKD_PX3_WIDE") && atoi(getenv("U2MKD_PX3_WIDE")) == 0);
+    return on && cout % 192 == 0;
+}
+
 template <bool DENSE, bool B16, int SC>
 static void px3_launch(bool w3, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
                        const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y, const float *bias,
                        int n_rows) {
     const size_t lds = (size_t)2 * 64 * 208;
-    if (w3)
+    if (!w3 && px3_wide(cout))
+        hipLaunchKernelGGL((conv_px3_kernel<4, 4, DENSE, B16, SC>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k,
+                           n_tiles, y, bias, n_rows);
+    else if (w3 && px3_wide3(cout))
+        hipLaunchKernelGGL((conv_px3_kernel<3, 4, DENSE, B16, SC>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k,
+                           n_tiles, y, bias, n_rows);
+    else if (w3)
         hipLaunchKernelGGL((conv_px3_kernel<3, 2, DENSE, B16, SC>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k,
                            n_tiles, y, bias, n_rows);
     else
@@ -290,9 +314,11 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
     if (!conv_px3_supported(cin, cout)) return -1;
     // column tiles: 128 (4 waves x 2 blocks) or 96 (3 waves x 2 blocks: 96- and 192-column layers exactly)
     const bool w3 = cout % 96 == 0 && cout % 128 != 0;
-    const int tn = w3 ? 96 : 128;
+    const bool wide = !w3 && px3_wide(cout);
+    const bool wide3 = w3 && px3_wide3(cout);
+    const int tn = wide3 ? 192 : w3 ? 96 : wide ? 256 : 128;
     int64_t gx = capacity / 64;
-    const int64_t cap_x = 3 * 256;            // 3 workgroups per CU, each a contiguous run of tiles
+    const int64_t cap_x = ((wide || wide3) ? 2 : 3) * 256;   // workgroups per CU (registers), each a contiguous run of tiles
     const int gy = (int)ceil_div(cout, tn);
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
     if (gx < 1) gx = 1;
@@ -308,10 +334,12 @@ int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin,
                       const float *bias, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
     const bool w3 = cout % 96 == 0 && cout % 128 != 0;
-    const int tn = w3 ? 96 : 128;
+    const bool wide = !w3 && px3_wide(cout);
+    const bool wide3 = w3 && px3_wide3(cout);
+    const int tn = wide3 ? 192 : w3 ? 96 : wide ? 256 : 128;
     const int gy = (int)ceil_div(cout, tn);
     int64_t gx = ceil_div(n_rows, 64);
-    const int64_t cap_x = 3 * 256;
+    const int64_t cap_x = ((wide || wide3) ? 2 : 3) * 256;
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
     dim3 grid((unsigned)gx, (unsigned)gy);
     if (!b16) px3_launch<true, false, 32>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
