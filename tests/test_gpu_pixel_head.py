@@ -200,7 +200,7 @@ def test_student_uses_the_sampled_head_and_matches_the_dense_path(hip, monkeypat
         assert err < max(5e-3 if name == 'stem conv' else 1e-4, 10.0 * floor), (name, err, floor)
 
 
-@pytest.mark.parametrize('shape', [(2, 5, 37, 52), (3, 8, 64, 112), (1, 3, 7, 9), (1, 2, 2, 2)])
+@pytest.mark.parametrize('shape', [(2, 5, 37, 52), (3, 8, 64, 112), (1, 3, 7, 9), (1, 2, 2, 2), (1, 4, 9, 16), (2, 2, 5, 4)])
 def test_maxpool_3x3_s2_equals_torch_including_ties(hip, shape):
     """camera.MaxPool3x3s2 (one byte per output instead of an int64 index, gathering backward) against nn.MaxPool2d(3, 2, 1):
     outputs and input gradients EQUAL, also on maps full of ties (the zeros a ReLU leaves: the first maximum in row-major

@@ -163,14 +163,15 @@ transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows
 // go to the same element), and the backward gathers: every input pixel sums the gradients of the <= 4 windows that
 // selected it.
 __global__ void __launch_bounds__(256)
-maxpool3s2_fwd_kernel(const float *__restrict__ x, int64_t total_out, int h, int w, int oh, int ow, float *__restrict__ y,
+maxpool3s2_fwd_kernel(const float *__restrict__ x, int h, int w, int oh, int ow, float *__restrict__ y,
                       uint8_t *__restrict__ code) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total_out) return;
-    const int ox = (int)(e % ow);
-    const int64_t r = e / ow;
-    const int oy = (int)(r % oh);
-    const int64_t plane = r / oh;
+    // grid (pixels of a plane / 256, planes): 32-bit index arithmetic (a 64-bit division per thread cost more than the
+    // kernel's memory traffic)
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (uint32_t)(oh * ow)) return;
+    const int oy = (int)(pix / (uint32_t)ow), ox = (int)(pix - (uint32_t)oy * (uint32_t)ow);
+    const int64_t plane = blockIdx.y;
+    const int64_t e = plane * oh * ow + pix;
     const float *xp = x + plane * (int64_t)h * w;
     const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
     float best = -INFINITY;
@@ -193,14 +194,13 @@ maxpool3s2_fwd_kernel(const float *__restrict__ x, int64_t total_out, int h, int
 }
 
 __global__ void __launch_bounds__(256)
-maxpool3s2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ code, int64_t total_in, int h, int w, int oh,
-                      int ow, float *__restrict__ dx) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total_in) return;
-    const int xx = (int)(e % w);
-    const int64_t r = e / w;
-    const int yy = (int)(r % h);
-    const int64_t plane = r / h;
+maxpool3s2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ code, int h, int w, int oh, int ow,
+                      float *__restrict__ dx) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (uint32_t)(h * w)) return;
+    const int yy = (int)(pix / (uint32_t)w), xx = (int)(pix - (uint32_t)yy * (uint32_t)w);
+    const int64_t plane = blockIdx.y;
+    const int64_t e = plane * h * w + pix;
     const float *gp = dy + plane * (int64_t)oh * ow;
     const uint8_t *cp = code + plane * (int64_t)oh * ow;
     // windows (oy, ox) with 2 oy - 1 <= yy <= 2 oy + 1: oy in {yy / 2, (yy + 1) / 2}
@@ -220,6 +220,39 @@ maxpool3s2_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ 
         }
     }
     dx[e] = g;
+}
+
+// the same for 4 consecutive columns per thread (w % 4 == 0): the 2 x 3 windows that can have selected them are read once
+// (6 code bytes, 6 gradients, unconditionally) and the four sums leave as one 16-byte store
+__global__ void __launch_bounds__(256)
+maxpool3s2_bwd4_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ code, int h, int w, int oh, int ow,
+                       float *__restrict__ dx) {
+    const int w4 = w >> 2;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (uint32_t)(h * w4)) return;
+    const int yy = (int)(q / (uint32_t)w4), x0 = 4 * (int)(q - (uint32_t)yy * (uint32_t)w4);
+    const int64_t plane = blockIdx.y;
+    const float *gp = dy + plane * (int64_t)oh * ow;
+    const uint8_t *cp = code + plane * (int64_t)oh * ow;
+    const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1, oxb = x0 >> 1;          // windows oxb .. oxb + 2 touch columns x0 .. x0 + 3
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = a ? oy1 : oy0;
+        if ((a && oy1 == oy0) || oy >= oh) continue;
+        const int dyw = yy - (2 * oy - 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ox = oxb + b;
+            if (ox >= ow) continue;
+            const int sel = (int)cp[(int64_t)oy * ow + ox] - 3 * dyw;     // the selected column of the window's row dyw: 0, 1 or 2
+            const float v = gp[(int64_t)oy * ow + ox];
+            const int col = 2 * ox - 1 + sel - x0;                         // as an offset into this thread's four columns
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] += (sel >= 0 && sel < 3 && col == i) ? v : 0.f;
+        }
+    }
+    *reinterpret_cast<float4 *>(dx + plane * (int64_t)h * w + (int64_t)yy * w + x0) = make_float4(g[0], g[1], g[2], g[3]);
 }
 
 // ---- F.interpolate(mode='bilinear', align_corners=True) of NCHW maps (+ the skip add that follows it in the decoder) ---
@@ -381,9 +414,9 @@ int u2mkd_maxpool3s2_forward(const float *x, int64_t planes, int32_t h, int32_t 
     if (planes == 0) return 0;
     U2_REQUIRE(x && y && code && planes > 0 && h > 0 && w > 0, "u2mkd_maxpool3s2_forward: bad arguments");
     const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
-    const int64_t total = planes * oh * ow;
-    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), x, total, h, w, oh,
-                       ow, y, code);
+    U2_REQUIRE(planes <= 65535 && (int64_t)h * w < ((int64_t)1 << 31), "u2mkd_maxpool3s2_forward: at most 65535 planes of < 2^31 pixels");
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)ceil_div((int64_t)oh * ow, 256), (unsigned)planes), dim3(256), 0,
+                       as_stream(s), x, h, w, oh, ow, y, code);
     return check_launch("u2mkd_maxpool3s2_forward");
 }
 
@@ -392,9 +425,13 @@ int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t plan
     if (planes == 0) return 0;
     U2_REQUIRE(dy && code && dx && planes > 0 && h > 0 && w > 0, "u2mkd_maxpool3s2_backward: bad arguments");
     const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
-    const int64_t total = planes * h * w;
-    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), dy, code, total, h,
-                       w, oh, ow, dx);
+    U2_REQUIRE(planes <= 65535 && (int64_t)h * w < ((int64_t)1 << 31), "u2mkd_maxpool3s2_backward: at most 65535 planes of < 2^31 pixels");
+    if (w % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0)
+        hipLaunchKernelGGL(maxpool3s2_bwd4_kernel, dim3((unsigned)ceil_div((int64_t)h * (w / 4), 256), (unsigned)planes), dim3(256), 0,
+                           as_stream(s), dy, code, h, w, oh, ow, dx);
+    else
+        hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)ceil_div((int64_t)h * w, 256), (unsigned)planes), dim3(256), 0,
+                           as_stream(s), dy, code, h, w, oh, ow, dx);
     return check_launch("u2mkd_maxpool3s2_backward");
 }
 
