@@ -105,3 +105,20 @@ def test_two_ranks_on_one_gpu_train_the_kd_student(hip, tmp_path):
     ck = torch.load(os.path.join(run, 'checkpoints', 'step-2.pt'), map_location='cpu', weights_only=False)
     assert all(k.startswith('module.') for k in ck['model'])                   # saved from the DDP wrapper, as the reference does
     assert any('model_s' in k and k.endswith('.kernel') for k in ck['model'])
+
+
+def test_teacher_trainer_on_the_on_disk_tree_with_multisweep_masks(hip, tmp_path, tree):  # noqa: F811
+    """Stage 1 on the loader's output: the teacher half of every sample (3 aggregated sweeps -> `keyframe_mask` for the
+    loss, `keyframe_mask_full` for the evaluation, core/spformer_trainer.py:64-68,95-117)."""
+    import run_training
+    root, ver = tree
+    cfgs = _configs(tmp_path, root=root, version=ver, im_cr=0.08)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        h = run_training.main([os.path.join(cfgs, 'spformer.yaml'), '--run-dir', str(tmp_path / 'teacher'), '--non-dist',
+                               '--optimizer.lr', '0.01'])
+    finally:
+        os.chdir(cwd)
+    assert len(h) == 1 and h[0]['loss'] == h[0]['loss'] and 0.0 <= h[0]['iou/val/vox'] <= 1.0
+    assert sorted(os.listdir(tmp_path / 'teacher' / 'checkpoints')) == ['max-iou-val-vox.pt', 'step-1.pt']
