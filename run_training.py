@@ -92,6 +92,18 @@ def teacher_view(d, ev):
                 inverse_batch=ev['t_inverse_batch'], targets_mapped=ev['targets_mapped_t'], keyframe_mask_full=kf)
 
 
+def seed_worker(dataset, seed, epoch, workers, worker_id):
+    """The reference's `worker_init_fn` (core/nusc_trainers.py:210-211, re-installed before every epoch): loader worker
+    `worker_id` of epoch `epoch` draws its augmentations from seed + (epoch - 1) * workers + worker_id -- there through
+    numpy's global state, here through the dataset copy's own generator (without it every worker would replay the parent's
+    stream)."""
+    s = seed + (epoch - 1) * workers + worker_id
+    np.random.seed(s % (2 ** 32))
+    if hasattr(dataset, 'rng'):
+        dataset.rng = np.random.default_rng(s)
+    return s
+
+
 # ------------------------------------------------------------------------------------------------- savers
 class Savers:
     """torchpack's `Saver(max_to_keep=1)` + `MaxSaver(metric)` as the reference configures them
@@ -164,10 +176,12 @@ def main(argv=None):
     else:
         dataset = builder.make_dataset(cfg, rng=np.random.default_rng(seed))
     flow = {}
+    epoch_box = [1]                       # read by the workers when an epoch's iterator starts them
     for split, ds in dataset.items():
         sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=(split == 'train'))
-        flow[split] = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, sampler=sampler, num_workers=workers,
-                                                  pin_memory=True, collate_fn=ds.collate_fn)
+        flow[split] = torch.utils.data.DataLoader(
+            ds, batch_size=cfg.batch_size, sampler=sampler, num_workers=workers, pin_memory=True, collate_fn=ds.collate_fn,
+            worker_init_fn=lambda wid: seed_worker(torch.utils.data.get_worker_info().dataset, seed, epoch_box[0], workers, wid))
 
     # model, weights, trainer (:78-99)
     model = builder.make_model(cfg).cuda()
@@ -190,7 +204,8 @@ def main(argv=None):
     metrics = [MeanIoU(cfg.data.num_classes, cfg.data.ignore_label, out, tgt, name=n) for n, out, tgt in names]
 
     def batches(split, epoch):
-        flow[split].sampler.set_epoch(epoch)
+        flow[split].sampler.set_epoch(epoch - 1)          # core/nusc_trainers.py:209
+        epoch_box[0] = epoch
         for i, c in enumerate(flow[split]):
             if args.max_iters and i >= args.max_iters:
                 break

@@ -163,3 +163,21 @@ def test_make_dataset_reads_the_loader_keys(tree):
     tr = ds['train']
     assert (tr.im_drop, tr.multisweeps, tr.only_past, tr.debug, tr.split) == (3, 2, False, True, 'train')
     assert tr.input_image_size == [360, 640] and tr.voxel_size == 0.05 and ds['val'].split == 'val'
+
+
+def test_loader_workers_get_the_references_seeds():
+    """run_training.seed_worker = the reference trainer's worker_init_fn (core/nusc_trainers.py:210-211)."""
+    import run_training
+
+    class DS:
+        rng = np.random.default_rng(0)
+    seen = set()
+    for epoch in (1, 2):
+        for wid in range(4):
+            ds = DS()
+            s = run_training.seed_worker(ds, 1000, epoch, 4, wid)
+            assert s == 1000 + (epoch - 1) * 4 + wid
+            assert ds.rng.integers(0, 2 ** 31) == np.random.default_rng(s).integers(0, 2 ** 31)
+            assert np.random.get_state()[1][0] == s
+            seen.add(s)
+    assert len(seen) == 8
