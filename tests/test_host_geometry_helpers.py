@@ -55,3 +55,20 @@ def test_up_taps_are_the_transpose_of_torchs_interpolation(n_in, n_out):
 def test_up_taps_refuse_large_factors():
     from u2mkd_amd import camera
     assert camera._up_taps(3, 64, 'cpu')[1] is None          # more than 8 outputs per input: torch's kernel serves those
+
+
+def test_every_level_of_the_chain_can_be_taken_from_the_base_coordinates():
+    """What spf.DownsamplePyramid relies on: level l of a chain of k = 2, s = 2 down-samplings (the oracle's spdownsample
+    applied level by level, as torchsparse does) equals ONE down-sampling of the stride-1 coordinates by 2^l -- same set,
+    same (b, x, y, z) order -- also for negative coordinates (floor division)."""
+    from oracle import ts_ref as R
+    rng = np.random.default_rng(3)
+    base = np.concatenate([rng.integers(-300, 300, (4000, 3)), rng.integers(0, 3, (4000, 1))], 1).astype(np.int32)
+    base = np.unique(base, axis=0)
+    level, ts = base, 1
+    for _ in range(4):
+        level = R.spdownsample(level, 2, 2, ts)
+        ts *= 2
+        direct = R.spdownsample(base, ts, ts, 1)
+        assert np.array_equal(level, direct), ts
+        assert np.all(level[:, :3] % ts == 0)
