@@ -365,7 +365,8 @@ int u2mkd_up_bilinear_backward(const float *g, int64_t planes, int32_t h, int32_
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the SwiftNet stem (core/models/image_branch/swiftnet.py): x
  * [planes, h, w] -> y [planes, oh, ow] with oh = (h - 1) / 2 + 1; `code` = one byte per output, the position of the
- * maximum inside its 3 x 3 window (first maximum in row-major order, as torch); backward: dx [planes, h, w]            */
+ * maximum inside its 3 x 3 window (first maximum in row-major order, as torch); backward: dx [planes, h, w], a gather
+ * (no atomics).  planes <= 65535 (one grid row per plane), h * w < 2^31.                                              */
 int u2mkd_maxpool3s2_forward(const float *x, int64_t planes, int32_t h, int32_t w, float *y, uint8_t *code, u2mkd_stream_t s);
 int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t planes, int32_t h, int32_t w, float *dx,
                               u2mkd_stream_t s);
