@@ -185,7 +185,7 @@ def main(argv=None):
 
     # model, weights, trainer (:78-99)
     model = builder.make_model(cfg).cuda()
-    used = T.load_weights(model, weight_path=args.weight_path, pretrain_weight=cfg.model.get('pretrain'),
+    used = T.load_weights(model, weight_path=args.weight_path, pretrain_weight=cfg.model.get('pretrain_weight'),
                           teacher_pretrain_weight=cfg.model.get('teacher_pretrain') if is_kd else None)
     log('weights:', used or 'random initialisation')
     make_opt = lambda net: builder.make_optimizer(cfg, net)
@@ -219,9 +219,16 @@ def main(argv=None):
         kf = d.get('keyframe_mask')
         return runner(tv['feats'], tv['coords'], tv['targets'], keyframe_mask=kf)
 
-    global_step = 0
+    global_step, first_epoch = 0, 1
+    if used == 'weight_path' and not args.non_dist:
+        # a distributed run resumes the whole trainer from `--weight-path` (model, loss scaler, optimizer, LR schedule:
+        # core/nusc_trainers.py:174-177, 431-435); `--non-dist` takes the model weights only (:178-180), done above
+        ckpt = torch.load(args.weight_path, map_location='cpu', weights_only=False)
+        T.load_state_dict(runner, ckpt)
+        global_step, first_epoch = int(ckpt.get('global_step', 0)), int(ckpt.get('epoch', 0)) + 1
+        log('resumed the trainer state at epoch %d, step %d' % (first_epoch, global_step))
     history = []
-    for epoch in range(1, cfg.num_epochs + 1):
+    for epoch in range(first_epoch, cfg.num_epochs + 1):
         runner.train_mode() if is_kd else model.train()
         t0, losses = time.time(), []
         it = batches('train', epoch)

@@ -122,3 +122,24 @@ def test_teacher_trainer_on_the_on_disk_tree_with_multisweep_masks(hip, tmp_path
         os.chdir(cwd)
     assert len(h) == 1 and h[0]['loss'] == h[0]['loss'] and 0.0 <= h[0]['iou/val/vox'] <= 1.0
     assert sorted(os.listdir(tmp_path / 'teacher' / 'checkpoints')) == ['max-iou-val-vox.pt', 'step-1.pt']
+
+
+def test_without_non_dist_a_weight_path_resumes_the_whole_trainer(hip, tmp_path, capsys):
+    """core/nusc_trainers.py:174-177: in the (default) distributed mode `--weight-path` restores model, optimizer, LR
+    schedule and loss scaler; the run continues with the epoch after the checkpoint's."""
+    import run_training
+    cfgs = _configs(tmp_path, im_cr=0.08)
+    common = ['--synthetic', '2000', '--max-iters', '2', '--model.in_channel_t', '4', '--optimizer.lr', '0.01']
+    run1 = str(tmp_path / 'a')
+    run_training.main([os.path.join(cfgs, 'tsd.yaml'), '--run-dir', run1] + common)
+    ck = os.path.join(run1, 'checkpoints', 'step-2.pt')
+    saved = torch.load(ck, map_location='cpu', weights_only=False)
+    assert saved['epoch'] == 1 and saved['scheduler']['last_epoch'] == 2
+    capsys.readouterr()
+    h = run_training.main([os.path.join(cfgs, 'tsd.yaml'), '--run-dir', str(tmp_path / 'b'), '--weight-path', ck, '--num_epochs', '2'] + common)
+    out = capsys.readouterr().out
+    assert 'resumed the trainer state at epoch 2, step 2' in out and [r['epoch'] for r in h] == [2]
+    again = torch.load(os.path.join(tmp_path, 'b', 'checkpoints', 'step-4.pt'), map_location='cpu', weights_only=False)
+    assert again['epoch'] == 2 and again['global_step'] == 4 and again['scheduler']['last_epoch'] == 4
+    mom = [s for s in again['optimizer']['state'].values() if 'momentum_buffer' in s]
+    assert mom and all(torch.isfinite(s['momentum_buffer']).all() for s in mom)
