@@ -190,11 +190,12 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
              # private copies of the map structures, so a cold launch also misses on the indices
              'nbr_s': sch.nbr_s.clone(), 'order': sch.order.clone(), 'pairs': pairs.clone()}
 
-        # forward = the weight re-layout into MFMA fragment order (442 KB -> both orientations, ONE small launch per
-        # weight per training step: the input gradient of the same step reads the second half) + the conv kernel
+        # the weight's MFMA-fragment images (both orientations) exist before the step's convolutions run: the product re-lays
+        # ALL trainable weights in one launch behind the optimizer step (functional.refresh_weight_fragments); that
+        # launch is timed below (`fragments`) and this weight's share of it is added to the group
+        L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, 2, 0, L.ptr(s['wf']), st)
+
         def conv(s, a, frag, flip, o):
-            if not flip:
-                L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, 2, 0, L.ptr(s['wf']), st)
             L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf'][frag]), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
                    L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, 0, L.ptr(o), st)
         s['fwd'] = lambda s=s: conv(s, s['x'], 0, 0, s['out'])
@@ -215,9 +216,9 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
         dw = torch.empty_like(w)
         ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
 
+        L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, 2, 3, L.ptr(wf), st)
+
         def conv(a, frag, flip, o):
-            if not flip:
-                L.call('u2mkd_weight_fragments', L.ptr(w), 27, cin, cout, 2, 3, L.ptr(wf), st)
             L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(a), n, cin, L.ptr(wf[frag]), cout, L.ptr(sch.nbr_s), L.ptr(sch.order),
                    L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, L.ptr(o), st)
         t = {'fwd': time_events([lambda: conv(x, 0, 0, out)], iters), 'dgrad': time_events([lambda: conv(gy, 1, 1, dx)], iters),
@@ -229,6 +230,21 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
                 'ms': dict({k: round(v, 4) for k, v in t.items()}, total=round(tt, 4)),
                 'achieved': round(bb / (tt * 1e-3) / 1e9, 1), 'frac': round(bb / (tt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+    def fragments_share(n_weights=64, arith=0):
+        """One u2mkd_weight_fragments_batch launch over n_weights [27, 64, 64] kernels (a KD student holds ~100 conv /
+        linear weights): the per-step price of the fragment order, and one weight's share of it."""
+        nb = lib.u2mkd_weight_fragments_bytes(27, cin, cout, arith)
+        planes = nb // (27 * cin * cout * 2)
+        wsrc = torch.randn(n_weights, 27, cin, cout, device='cuda', generator=g)
+        dst = torch.empty(n_weights, 2, nb, dtype=torch.uint8, device='cuda')
+        per = 2 * (27 * cin * cout // 512)
+        table = torch.tensor([[wsrc[i].data_ptr(), dst[i].data_ptr(), i * per, 27, cin, cout, planes, 0] for i in range(n_weights)],
+                             dtype=torch.int64).cuda()
+        ms = time_events([lambda: L.call('u2mkd_weight_fragments_batch', L.ptr(table), n_weights, n_weights * per, st)], iters)
+        return {'weights_per_launch': n_weights, 'launch_ms': round(ms, 4), 'share_ms': round(ms / n_weights, 5),
+                'note': 'the fragment images of every trainable weight are rebuilt by ONE launch behind the optimizer step; '
+                        'share_ms = this launch / weights is added to the group total'}
+
     sets = [make_set() for _ in range(cold_sets)]
     set_bytes = sum(t.numel() * t.element_size() for t in sets[0].values() if torch.is_tensor(t))
     warm = {k: time_events([sets[0][k]], iters) for k in ('fwd', 'dgrad', 'wgrad')}
@@ -236,12 +252,13 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
     b_f, b_d, b_w = subm_algorithmic_bytes(n, p, cin, cout)
     total_b = b_f + b_d + b_w
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
-    t_warm, t_cold = sum(warm.values()), sum(cold.values())
+    frag = fragments_share()
+    t_warm, t_cold = sum(warm.values()) + frag['share_ms'], sum(cold.values()) + frag['share_ms']
     flops = 6.0 * p * cin * cout
     # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
     # only quoted when it was taken on the same map (same N and P)
     traffic = None
-    for name in ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
+    for name in ('r4_traffic.json',):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 tj = json.load(f)
@@ -254,9 +271,10 @@ def roofline_leg(coords_dev, iters=60, cold_sets=8):
     return {
         'bound': 'hbm', 'achieved': round(gbs(total_b, t_warm), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4), 'traffic': traffic,
-        'kernel': 'SubMConv3d fwd+dgrad+wgrad (weight_fragments_kernel for both orientations + conv_tp_kernel x2 + conv_wgrad_x3_kernel incl. its slab reduce), N=%d Cin=Cout=64 K=27' % n,
+        'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_tp_kernel x2 + conv_wgrad_x3_kernel incl. its slab reduce + this weight\'s share of the per-step weight_fragments_batch launch), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
-        'ms': dict(r3(warm), total=round(t_warm, 4)),
+        'ms': dict(r3(warm), fragments_share=frag['share_ms'], total=round(t_warm, 4)),
+        'fragments': frag,
         'GBps': {'fwd': round(gbs(b_f, warm['fwd']), 1), 'dgrad': round(gbs(b_d, warm['dgrad']), 1),
                  'wgrad': round(gbs(b_w, warm['wgrad']), 1)},
         'cold': {'ms': dict(r3(cold), total=round(t_cold, 4)), 'achieved': round(gbs(total_b, t_cold), 1),

@@ -149,6 +149,15 @@ int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k);
 size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32_t arith);
 int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
                            void *wf, u2mkd_stream_t s);
+/* The same re-layout for MANY weights in ONE launch: a training step changes every trainable weight at once, so the
+ * host side (torchsparse/nn/functional.py: refresh_weight_fragments, an optimizer-step post hook) re-lays all of them
+ * behind the optimizer instead of one latency-bound launch per weight in front of its first convolution.
+ * jobs: DEVICE int64 [n_jobs][8] = {w (device address of the fp32 [k,rows,cols] weight), wf (device address of
+ * 2 x u2mkd_weight_fragments_bytes(k, rows, cols, arith) bytes: [transpose = 1 | transpose = 0]), first unit, k, rows,
+ * cols, planes (3 for arith 2 = bf16x3, 1 for arith 3 = one bf16 plane), 0}; job j owns the units
+ * [first_j, first_j + 2 k rows cols / 512), consecutive from 0; total_units = their sum.  Replaces nothing in the
+ * reference (torchsparse reads `kernel` as it is); it is the price of the MFMA fragment order.            */
+int u2mkd_weight_fragments_batch(const int64_t *jobs, int32_t n_jobs, int64_t total_units, u2mkd_stream_t s);
 int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
                              const int32_t *nbr_sorted /*[k,n_out]*/, const int32_t *order /*[n_out] or NULL*/,
                              const int32_t *items /*[<= 4 ceil(n_out/64)] or NULL*/,

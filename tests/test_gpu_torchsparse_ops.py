@@ -605,3 +605,95 @@ def test_bf16_storage_conv_group_matches_fp32_kernels_on_rounded_inputs(F, cin, 
     L.call('u2mkd_conv_wgrad_pairs', L.ptr(xf), cin, L.ptr(gf), cout, L.ptr(pairs), L.ptr(plan), n, k, 0,
            L.ptr(ws), nbytes, L.ptr(dwf), st)
     assert torch.equal(dwb, dwf)
+
+
+def test_batched_weight_fragments_equal_the_per_weight_launches(F):
+    """u2mkd_weight_fragments_batch (one launch for every trainable weight, behind the optimizer step) writes the same
+    bytes as one u2mkd_weight_fragments(transpose = 2) launch per weight: conv kernels [27, cin, cout], a strided
+    [8, ..], nn.Linear [1, out, in]; bf16x3 (3 planes) and bf16 storage (1 plane) mixed in one table."""
+    from u2mkd_amd import _lib as L
+    lib = L.load()
+    st = L.stream()
+    torch.manual_seed(11)
+    shapes = [(27, 64, 64, 2), (27, 32, 96, 2), (8, 64, 128, 2), (1, 256, 128, 2), (27, 64, 64, 3), (1, 96, 32, 3), (27, 128, 256, 2)]
+    ws, ref, bufs, rows, first = [], [], [], [], 0
+    for k, r, c, arith in shapes:
+        w = torch.randn(k, r, c, device='cuda')
+        nbytes = lib.u2mkd_weight_fragments_bytes(k, r, c, arith)
+        a = torch.empty(2, nbytes, dtype=torch.uint8, device='cuda')
+        L.call('u2mkd_weight_fragments', L.ptr(w), k, r, c, 2, arith, L.ptr(a), st)
+        b = torch.full((2, nbytes), 0xA5, dtype=torch.uint8, device='cuda')
+        rows.append([w.data_ptr(), b.data_ptr(), first, k, r, c, 3 if arith == 2 else 1, 0])
+        first += 2 * (k * r * c // 512)
+        ws.append(w); ref.append(a); bufs.append(b)
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    L.call('u2mkd_weight_fragments_batch', L.ptr(table), len(rows), first, st)
+    for a, b, sh in zip(ref, bufs, shapes):
+        assert torch.equal(a, b), sh
+
+
+def test_optimizer_step_refreshes_every_fragment_image_in_one_launch(F, monkeypatch):
+    """The product flow: the first forward + backward lay each weight out once (per-weight launch, registers the image);
+    every optimizer step afterwards re-lays ALL registered weights by ONE u2mkd_weight_fragments_batch launch, the next
+    step issues no per-weight launch, and its outputs equal a from-scratch evaluation with the updated weights."""
+    from u2mkd_amd import _lib as L
+    from u2mkd_amd import torchsparse
+    import u2mkd_amd.torchsparse.nn as spnn
+    coords, feats = _scene(4000, 1, seed=5)
+    torch.manual_seed(2)
+    net = torch.nn.ModuleList([spnn.Conv3d(32, 64, 3), spnn.Conv3d(64, 64, 3), spnn.Conv3d(64, 32, 3)]).cuda()
+    x0 = torchsparse.SparseTensor(torch.randn(len(coords), 32, device='cuda'), _dev(coords))
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    calls = []
+    real = L.call
+
+    def counting(name, *a):
+        if name.startswith('u2mkd_weight_fragments'):
+            calls.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(L, 'call', counting)
+
+    def step():
+        y = x0
+        for m in net:
+            y = m(y)
+        loss = (y.F ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return y.F.detach().clone()
+    step()
+    assert calls.count('u2mkd_weight_fragments') == 3 and calls.count('u2mkd_weight_fragments_batch') == 1
+    del calls[:]
+    y2 = step()
+    assert calls == ['u2mkd_weight_fragments_batch'], calls
+    # the same second forward from scratch: fresh modules holding the weights as they were before the second update
+    del calls[:]
+    y3 = step()
+    assert calls == ['u2mkd_weight_fragments_batch']
+    F.invalidate_weight_caches()                 # forces the per-weight path on the current weights
+    with torch.no_grad():
+        y = x0
+        for m in net:
+            y = m(y)
+    assert calls.count('u2mkd_weight_fragments') == 3
+    del calls[:]
+    with torch.no_grad():
+        z = x0
+        for m in net:
+            z = m(z)
+    assert calls == [] and torch.equal(y.F, z.F)
+    assert not torch.equal(y2, y3)
+    # batched images == per-weight images: run one more step, then compare a forward on the batch-refreshed images with one
+    # on images rebuilt per weight
+    step()
+    with torch.no_grad():
+        a = x0
+        for m in net:
+            a = m(a)
+    F.invalidate_weight_caches()
+    with torch.no_grad():
+        b = x0
+        for m in net:
+            b = m(b)
+    assert torch.equal(a.F, b.F)

@@ -2,6 +2,8 @@
 import sys; sys.path.insert(0, '.')
 import numpy as np, torch
 from u2mkd_amd import _lib as L
+import os
+L.LIB_PATH = L.LIB_PATH.replace('libu2mkd_hip.so', 'libu2mkd_hip%s.so' % os.environ.get('AB_SUFFIX', ''))
 from u2mkd_amd.torchsparse.nn import functional as F
 from u2mkd_amd.synth import synth_batch
 

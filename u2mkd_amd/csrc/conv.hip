@@ -1080,6 +1080,12 @@ int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols
     return launch_weight_fragments(w, k, rows, cols, transpose, arith, reinterpret_cast<float *>(wf), as_stream(s));
 }
 
+int u2mkd_weight_fragments_batch(const int64_t *jobs, int32_t n_jobs, int64_t total_units, u2mkd_stream_t s) {
+    if (n_jobs == 0) return 0;
+    U2_REQUIRE(jobs && n_jobs > 0 && total_units > 0 && total_units < (1LL << 31), "u2mkd_weight_fragments_batch: bad job table");
+    return launch_weight_fragments_batch(jobs, n_jobs, total_units, as_stream(s));
+}
+
 int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
                              const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
                              const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, int32_t arith, float *out,
@@ -1089,6 +1095,7 @@ int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const v
     U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles: kflip must be 0 or 1");
     U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_conv_forward_tiles: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
     U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles: empty input");
+    U2_REQUIRE(n_in <= (1 << 25), "u2mkd_conv_forward_tiles: %lld input rows, the tile kernel packs row indices into 25 bits", (long long)n_in);
     U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles: items and n_items go together");
     int rc = launch_conv_tp("u2mkd_conv_forward_tiles", in, cin, reinterpret_cast<const float *>(wf), cout, nbr_sorted, order,
                             RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, kflip, arith, out, as_stream(s));
@@ -1101,6 +1108,7 @@ int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const void
                                        const int32_t *order, const int32_t *items, const int32_t *n_items, int64_t n_out,
                                        int32_t k, int32_t arith, float *out, uint64_t *stamps, u2mkd_stream_t s) {
     U2_REQUIRE(in && wf && nbr_sorted && out && stamps && n_out > 0, "u2mkd_debug_conv_tile_pairs_stamps: null pointer");
+    U2_REQUIRE(n_in <= (1 << 25), "u2mkd_debug_conv_tile_pairs_stamps: too many input rows");
     int rc = launch_conv_tp("u2mkd_debug_conv_tile_pairs_stamps", in, 64, reinterpret_cast<const float *>(wf), 64, nbr_sorted,
                             order, RowRange{n_out, 0, n_out, nullptr}, items, n_items, k, 0, arith, out, as_stream(s),
                             reinterpret_cast<unsigned long long *>(stamps));
@@ -1358,6 +1366,7 @@ int u2mkd_conv_forward_tiles_bf16(const void *in, int64_t n_in, int32_t cin, con
     U2_REQUIRE(in && wf && nbr_sorted && out, "u2mkd_conv_forward_tiles_bf16: null pointer");
     U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles_bf16: kflip must be 0 or 1");
     U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles_bf16: empty input");
+    U2_REQUIRE(n_in <= (1 << 25), "u2mkd_conv_forward_tiles_bf16: %lld input rows, the tile kernel packs row indices into 25 bits", (long long)n_in);
     U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles_bf16: items and n_items go together");
     int rc = launch_conv_tp("u2mkd_conv_forward_tiles_bf16", reinterpret_cast<const float *>(in), cin,
                             reinterpret_cast<const float *>(wf), cout, nbr_sorted, order, RowRange{n_out, 0, n_out, nullptr},

@@ -22,6 +22,7 @@ bool conv_tp_supported(int cin, int cout, int k);
 int conv_tp_arith(int arith);
 size_t weight_fragments_bytes(int k, int rows, int cols, int arith);
 int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st);
+int launch_weight_fragments_batch(const int64_t *jobs, int n_jobs, int64_t total_units, hipStream_t st);
 
 // Global pair schedule in bf16x3 arithmetic (conv_px3.hip); wf = arith-2 fragments.  -1 = shape not supported.
 bool conv_px3_supported(int cin, int cout);

@@ -43,6 +43,9 @@
 
 namespace u2mkd {
 
+constexpr int kTpPad = 8;             // row pad of the LDS row image (dwords), see AS below
+constexpr int kTpRowShift = 25;       // s_idx word of a pair = input row | tile row << 25 (input rows < 2^25, launch_conv_tp checks)
+
 // Weight fragments: B_k = the [ncol x nred] matrix whose row `col` holds the reduction channels of output
 // column `col` (forward: B_k[col][ci] = kernel[k][ci][col], transpose = 1; input gradient: B_k[ci][co] =
 // kernel[k][ci][co], transpose = 0).  Fragment layout: wf[k][cb][j][lane][4] = B_k[16 cb + r][16 j + 4 q .. +3],
@@ -134,6 +137,62 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
     }
 }
 
+// The same re-layout for MANY weights in one launch (u2mkd_weight_fragments_batch): a training step changes every
+// trainable weight at once (the optimizer step), and one latency-bound launch per weight -- ~5 us each, ~100 per step,
+// each in front of the first convolution that needs it -- becomes one launch behind the optimizer.  jobs[j] =
+// {w, wf, first unit, k, rows, cols, planes (3 = bf16x3, 1 = one bf16 plane), 0} as int64; a unit = one wave = 64 lanes
+// x 8 reduction channels; job j owns units [first_j, first_j+1): 2 orientations x k rows cols / 512, transpose = 1 first
+// (the layout of u2mkd_weight_fragments with transpose = 2).
+__global__ void __launch_bounds__(64)
+weight_fragments_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs) {
+    const int lane = threadIdx.x;
+    const int64_t unit = blockIdx.x;
+    int job = -1;                                            // last job whose first unit is <= unit
+    for (int j0 = 0; j0 < n_jobs; j0 += 64) {
+        const int j = j0 + lane;
+        const bool le = j < n_jobs && jobs[(size_t)j * 8 + 2] <= unit;
+        job += __popcll(__ballot(le));
+    }
+    job = __builtin_amdgcn_readfirstlane(job);
+    const int64_t *jb = jobs + (size_t)job * 8;
+    const float *w = reinterpret_cast<const float *>(jb[0]);
+    bf16x8 *wf = reinterpret_cast<bf16x8 *>(jb[1]);
+    const int rows = (int)jb[4], cols = (int)jb[5], planes = (int)jb[6];
+    const int64_t per = jb[3] * rows * cols / 512;           // units per orientation
+    int64_t u = unit - jb[2];
+    const int transpose = u < per ? 1 : 0;
+    if (!transpose) { u -= per; wf += (size_t)per * 64 * planes; }
+    const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
+    const int ns = nred / 32, ncb = ncol / 16;
+    const int sstep = (int)(u % ns);
+    u /= ns;
+    const int cb = (int)(u % ncb);
+    const int64_t k = u / ncb;
+    const int col = 16 * cb + (lane & 15), red0 = 32 * sstep + 8 * (lane >> 4);
+    float x[8];
+    if (transpose) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = w[((size_t)k * rows + red0 + i) * cols + col];
+    } else {
+        const float4 *p = reinterpret_cast<const float4 *>(w + ((size_t)k * rows + col) * cols + red0);
+        const float4 a = p[0], b = p[1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+    bf16x8 vh, vm, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h, m, l;
+        split3(x[i], h, m, l);
+        vh[i] = h; vm[i] = m; vl[i] = l;
+    }
+    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * planes * 64 + lane;
+    o[0] = vh;
+    if (planes == 3) {
+        o[64] = vm;
+        o[128] = vl;
+    }
+}
+
 __device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
     f32x4 v = (f32x4){x.x, x.y, x.z, x.w};
     return __builtin_bit_cast(bf16x8, v);
@@ -157,7 +216,11 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     constexpr int T = 64, NT = 64 * NW, TN = 16 * NW * NBW, NJ = CIN / 16;
     constexpr int OS = TN + 4;                    // output tile row stride (floats)
     // gathered-row image: fp32 rows, or (X3) three bf16 planes h | m | l of CIN elements per row; + 16 B pad
-    constexpr int AS = X3 ? (6 * CIN + 16) / 4 : B16 ? (2 * CIN + 16) / 4 : CIN + 4;   // row stride (floats)
+    // row stride (dwords) = data + 8: lane (r, q) of a ds_read_b128 reads dwords AS r + 4 q .. +3 (+ the fragment's offset), the
+    // hardware serves the 16-lane groups {r in 0-3 | 12-15 at q, r in 4-11 at q + 1} and {the complement} in one cycle each only
+    // if their 16 x 4 dwords hit 64 different banks: AS / 4 even and = 2 (mod 4).  (Rounds 2-3 ran data + 4: every fragment read
+    // was a 2-way conflict, 96 of the ~400 LDS cycles of a block.)
+    constexpr int AS = (X3 ? 6 * CIN / 4 : B16 ? 2 * CIN / 4 : CIN) + kTpPad;
     constexpr int NF = X3 ? CIN / 32 * 3 : B16 ? CIN / 32 : CIN / 16;   // 16-byte operand fragments per lane per block
     constexpr int CPR = B16 ? CIN / 8 : CIN / 4;  // 16-byte chunks per gathered row
     constexpr int LPT = (16 * CPR + NT - 1) / NT; // chunks a thread moves per block
@@ -165,11 +228,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_out = reinterpret_cast<float *>(smem);                           // [T][OS]
     float *s_a = s_out + T * OS;                                              // [2][16][AS] gathered rows of blocks t, t+1
-    int *s_idx = reinterpret_cast<int *>(s_a + 2 * 16 * AS);                  // [K+1][T] compacted input rows (+ sentinel row)
+    int *s_idx = reinterpret_cast<int *>(s_a + 2 * 16 * AS);                  // [K+1][T] compacted (input row | tile row << 25) (+ sentinel row)
     int *s_cnt = s_idx + (K + 1) * T;                                         // [32] pairs per offset
     int *s_rid = s_cnt + 32;                                                  // [T] original output row
     int *s_blk = s_rid + T;                                                   // [4K + 8] block descriptors
-    unsigned char *s_row = reinterpret_cast<unsigned char *>(s_blk + 4 * K + 8);   // [K+1][T] tile row of each entry
 
     const int col0 = blockIdx.y * TN;
     const int64_t n_out = rr_.end, ld = rr_.ld;
@@ -247,7 +309,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         s_rid[e] = (e < R && row < n_out) ? (order ? order[row] : (int)row) : -1;
     }
     if (tid >= K && tid < 32) s_cnt[tid] = 0;            // (entries < K are written by the compaction below)
-    if (tid < T) { s_idx[K * T + tid] = -1; s_row[K * T + tid] = 0; }
+    if (tid < T) s_idx[K * T + tid] = -1;
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
         int kk = wave + i * NW;
@@ -256,14 +318,8 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             const unsigned long long bal = __ballot(valid);
             const int cnt = __popcll(bal);
             const int rank = __popcll(bal & ((1ULL << lane) - 1ULL));
-            if (valid) {
-                s_idx[kk * T + rank] = v[i];
-                s_row[kk * T + rank] = (unsigned char)lane;
-            }
-            if (lane >= cnt && lane < ((cnt + 15) & ~15)) {   // pad the last block
-                s_idx[kk * T + lane] = -1;
-                s_row[kk * T + lane] = 0;
-            }
+            if (valid) s_idx[kk * T + rank] = v[i] | (lane << kTpRowShift);
+            if (lane >= cnt && lane < ((cnt + 15) & ~15)) s_idx[kk * T + lane] = -1;   // pad the last block
             if (lane == 0) s_cnt[kk] = cnt;
         }
     }
@@ -356,7 +412,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         for (int i = 0; i < LPT; ++i) {
             const int e = tid + i * NT;
             const int ch = e % CPR;
-            const int ix = gix[i] >= 0 ? gix[i] : 0;
+            const int ix = gix[i] >= 0 ? (gix[i] & ((1 << kTpRowShift) - 1)) : 0;
             gg[i] = *reinterpret_cast<const f32x4 *>(in + (B16 ? (size_t)ix * (CIN / 2) : (size_t)ix * CIN) + 4 * ch);
         }
     };
@@ -416,7 +472,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             store_G(g[0], 0);
             read_gix(desc(3));
             pidx[0] = s_idx[dbase(d0) + r];
-            prow[0] = s_row[dbase(d0) + r];
+            prow[0] = (pidx[0] >> kTpRowShift) & 63;
             __syncthreads();
         }
         // one step, `u` = t mod 6 as a compile-time constant (ring positions are static register names)
@@ -428,7 +484,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             issue_G(g[u % 3]);                                       // block t+3 (block t left these registers at step t-1)
             read_gix(d4);                                            // block t+4
             pidx[(u + 1) & 1] = s_idx[dbase(d1) + r];                // block t+1
-            prow[(u + 1) & 1] = s_row[dbase(d1) + r];
+            prow[(u + 1) & 1] = (pidx[(u + 1) & 1] >> kTpRowShift) & 63;
             const int d5 = desc(t + 5);
             // -- block t: the old output values first (in flight under the MFMAs), then the products
             const bool live = pidx[u & 1] >= 0;
@@ -473,6 +529,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                     }
                 }
                 // D^T: lane (r, q) holds columns 4q .. 4q+3 of pair r
+                // (the opaque use keeps the read of the old values where it was written, in flight under the MFMAs: its only
+                // other use is inside the branch, and hipcc sinks it there -- an LDS round trip between the last MFMA and
+                // the store, every step)
+                asm volatile("" : "+v"(o[n].x), "+v"(o[n].y), "+v"(o[n].z), "+v"(o[n].w));
                 if (live) {
                     o[n].x += acc0[0] + acc1[0];
                     o[n].y += acc0[1] + acc1[1];
@@ -564,8 +624,8 @@ static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const f
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
-    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * (AR == 2 ? 6 * CIN + 16 : AR == 3 ? 2 * CIN + 16 : 4 * CIN + 16) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
-                       (size_t)(4 * K + 8) * 4 + (size_t)(K + 1) * 64;
+    const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * ((AR == 2 ? 6 * CIN : AR == 3 ? 2 * CIN : 4 * CIN) + 4 * kTpPad) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
+                       (size_t)(4 * K + 8) * 4;
     const int n_tiles = (int)ceil_div(rr.end - rr.begin, 64);
     // one resident wave of workgroups at most (they deal the items among themselves, lightest first)
     static int occ_by_k[33];                         // resident workgroups per CU of THIS instantiation at kernel volume K
@@ -674,6 +734,12 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
                            transpose, wf, elems);
     }
     return check_launch("u2mkd_weight_fragments");
+}
+
+int launch_weight_fragments_batch(const int64_t *jobs, int n_jobs, int64_t total_units, hipStream_t st) {
+    if (n_jobs == 0 || total_units == 0) return 0;
+    hipLaunchKernelGGL(weight_fragments_batch_kernel, dim3((unsigned)total_units), dim3(64), 0, st, jobs, n_jobs);
+    return check_launch("u2mkd_weight_fragments_batch");
 }
 
 }  // namespace u2mkd

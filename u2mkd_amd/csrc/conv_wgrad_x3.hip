@@ -28,7 +28,11 @@ namespace u2mkd {
 typedef short wx_s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kWxRow = 144;                    // bytes per (plane, pair) row: 64 bf16 channels + 16 pad (2-way at worst)
+// bytes per (plane, pair) row.  128 = the 64 bf16 channels, no pad, the four 32-byte windows (16 channels) of pair-row p stored at
+// window (c ^ h(p)), h(p) = bit 1 of p | bit 3 of p << 1: a ds_read_b64_tr_b16 is served in two 32-lane halves, each reading rows
+// {0..3, 8..11} (+4, +16, +20) x one 32-byte window -- with that swizzle the 8 rows land on 8 different 8-bank groups (rows p and
+// p+1 are the two halves of a 256-byte bank line).  (Rounds 2-3: 144-byte rows, every transposing read a 2-way conflict.)
+constexpr int kWxRow = 128;
 constexpr int kWxCP = 32;                      // pairs per step = the K of one MFMA
 constexpr int kWxOperand = 3 * kWxCP * kWxRow; // bytes of one operand's image: [3 planes][32 pairs][row]
 
@@ -122,6 +126,7 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             }
         }
     };
+    const int hs = ((tid >> 5) & 1) | (((tid >> 7) & 1) << 1);       // h(pair row) of this thread's stores (rows tid >> 4, + 16)
     auto store_impl = [&](auto FULL, int p0, const f32x4 (&va)[2], const f32x4 (&vb)[2]) __attribute__((always_inline)) {
         constexpr bool kFull = decltype(FULL)::value;          // a whole chunk inside the range and whole tiles: no masks
         const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -131,7 +136,8 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             const int pr = f >> 4, c = (f & 15) * 4;
             const bool live = kFull || p0 + pr < p_end;
             const f32x4 xa = (kFull || (live && a0 + c < ca)) ? va[i] : zero, xb = (kFull || (live && b0 + c < cb)) ? vb[i] : zero;
-            char *da = smem + pr * kWxRow + c * 2, *db = smem + OPB + pr * kWxRow + c * 2;
+            const int cofs = ((((f & 15) >> 2) ^ hs) << 5) | ((f & 3) << 3);
+            char *da = smem + pr * kWxRow + cofs, *db = smem + OPB + pr * kWxRow + cofs;
             if (B16) {
                 *reinterpret_cast<uint2 *>(da) = make_uint2(__float_as_uint(xa[0]), __float_as_uint(xa[1]));
                 *reinterpret_cast<uint2 *>(db) = make_uint2(__float_as_uint(xb[0]), __float_as_uint(xb[1]));
@@ -154,18 +160,19 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
     // transposing read: lane 4q+p of a 16-lane group supplies row q (of 4 pairs), channels 4p .. 4p+3; lane i receives
     // channel i's 4 pairs.  Group gq covers pairs 8 gq .. 8 gq + 7 (two reads).
     const int tq = li >> 2, tp = li & 3;
+    const int hr = ((tq >> 1) & 1) | ((gq & 1) << 1);                // h(row) of this lane's reads (rows 8 gq + tq, + 4)
     auto multiply = [&]() __attribute__((always_inline)) {
         wx_bf16x8 fa[2][NPL], fb[2][NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const char *base = smem + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wy + m) + 4 * tp) * 2;
+                const char *base = smem + (pl * kWxCP + 8 * gq + tq) * kWxRow + ((((2 * wy + m) ^ hr) << 5) | (tp << 3));
                 fa[m][pl] = wx_frag(base, base + 4 * kWxRow);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const char *base = smem + OPB + (pl * kWxCP + 8 * gq + tq) * kWxRow + (16 * (2 * wx + n) + 4 * tp) * 2;
+                const char *base = smem + OPB + (pl * kWxCP + 8 * gq + tq) * kWxRow + ((((2 * wx + n) ^ hr) << 5) | (tp << 3));
                 fb[n][pl] = wx_frag(base, base + 4 * kWxRow);
             }
         }

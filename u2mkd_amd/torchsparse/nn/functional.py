@@ -16,6 +16,8 @@ from __future__ import annotations
 import os
 import threading
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -729,9 +731,56 @@ def invalidate_weight_caches(*_):
     _WEIGHT_EPOCH[0] += 1
 
 
+# Trainable weights whose MFMA-fragment images are live: (id(weight), slot) -> [weakref, slot, both, k, r, c, planes, data_ptr].
+# After an optimizer step ALL of them are re-laid by ONE launch (u2mkd_weight_fragments_batch) instead of one ~5 us
+# latency-bound launch per weight in front of its first convolution of the next step (~100 per KD step).
+_FRAG_JOBS = {}
+_FRAG_TABLE = [None, 0]            # (device job table int64 [n, 8] or None = rebuild, total units)
+
+
+def _register_fragments(weight, slot, both, k, r, c, arith):
+    planes = L.load().u2mkd_weight_fragments_bytes(1, 32, 32, arith) // (32 * 32 * 2)
+    if planes not in (1, 3):       # f32 fragments (U2MKD_CONV_ARITH=f32): per-weight launches only
+        return
+    _FRAG_JOBS[(id(weight), slot)] = [weakref.ref(weight), slot, both, k, r, c, planes, weight.data_ptr()]
+    _FRAG_TABLE[0] = None
+
+
+def refresh_weight_fragments(*_):
+    """Optimizer-step post hook: new epoch (see ``invalidate_weight_caches``), then every registered trainable weight's
+    fragments of both orientations are rebuilt from the updated values in one launch and re-stamped, so the next
+    step's convolutions find them current.  A weight that died, moved, was frozen or whose cache entry was replaced
+    drops out (it re-registers through the per-weight path on its next use)."""
+    _WEIGHT_EPOCH[0] += 1
+    if not _FRAG_JOBS:
+        return
+    live = []
+    for key, job in list(_FRAG_JOBS.items()):
+        w = job[0]()
+        hit = None if w is None else w.__dict__.get(job[1])
+        if w is None or not w.requires_grad or w.data_ptr() != job[7] or hit is None or hit[1] is not job[2]:
+            del _FRAG_JOBS[key]
+            _FRAG_TABLE[0] = None
+        else:
+            live.append((w, job))
+    if not live:
+        return
+    if _FRAG_TABLE[0] is None:
+        rows, first = [], 0
+        for w, (_, _, both, k, r, c, planes, ptr) in live:
+            rows.append([ptr, both.data_ptr(), first, k, r, c, planes, 0])
+            first += 2 * (k * r * c // 512)
+        _FRAG_TABLE[0] = torch.tensor(rows, dtype=torch.int64).to(live[0][0].device, non_blocking=False)
+        _FRAG_TABLE[1] = first
+    L.call('u2mkd_weight_fragments_batch', L.ptr(_FRAG_TABLE[0]), len(live), _FRAG_TABLE[1], L.stream())
+    epoch = _WEIGHT_EPOCH[0]
+    for w, job in live:
+        w.__dict__[job[1]] = ((w._version, job[7], epoch), job[2])
+
+
 try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
-    _reg_post(invalidate_weight_caches)
+    _reg_post(refresh_weight_fragments)
 except ImportError:                                  # pragma: no cover -- torch < 2.0 has no global hook
     pass
 
@@ -761,10 +810,16 @@ def _weight_layout(weight, transpose, fragments, arith=0):
         hit = weight.__dict__.get(slot)
         if hit is None or hit[0] != stamp:
             nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, arith)
-            both = torch.empty(2, nbytes, dtype=torch.uint8, device=weight.device)
+            fresh = hit is None or hit[1].shape[1] != nbytes or hit[1].device != weight.device
+            # (a stale image is overwritten in place: every reader is ordered on the launch stream, and the buffer's
+            # address is what the batched refresh table holds)
+            both = torch.empty(2, nbytes, dtype=torch.uint8, device=weight.device) if fresh else hit[1]
             L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, 2, arith, L.ptr(both), L.stream())
             hit = (stamp, both)
             weight.__dict__[slot] = hit
+            job = _FRAG_JOBS.get((id(weight), slot))
+            if not frozen and (fresh or job is None or job[0]() is not weight or job[7] != stamp[1] or job[2] is not both):
+                _register_fragments(weight, slot, both, k, r, c, arith)
         return hit[1][0 if transpose else 1]
     key = '_u2mkd_wt'
     if frozen:
