@@ -119,16 +119,18 @@ class Savers:
     def after_epoch(self, runner, global_step, values, extra):
         if D.rank() != 0:
             return
-        state = dict(T.state_dict(runner), **extra)
+        improved = [m for m, best in self.best.items() if m in values and (best is None or values[m] > best)]
+        for m in improved:
+            self.best[m] = values[m]
+        # the best values travel with the state, so a resumed run does not overwrite max-*.pt with a worse epoch
+        state = dict(T.state_dict(runner), best_metrics=dict(self.best), **extra)
         path = os.path.join(self.dir, 'step-%d.pt' % global_step)
         torch.save(state, path)
         if self.last and self.last != path and os.path.exists(self.last):
             os.remove(self.last)
         self.last = path
-        for m, best in self.best.items():
-            if m in values and (best is None or values[m] > best):
-                self.best[m] = values[m]
-                torch.save(state, os.path.join(self.dir, 'max-%s.pt' % m.replace('/', '-')))
+        for m in improved:
+            torch.save(state, os.path.join(self.dir, 'max-%s.pt' % m.replace('/', '-')))
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -225,7 +227,13 @@ def main(argv=None):
         # core/nusc_trainers.py:174-177, 431-435); `--non-dist` takes the model weights only (:178-180), done above
         ckpt = torch.load(args.weight_path, map_location='cpu', weights_only=False)
         T.load_state_dict(runner, ckpt)
-        global_step, first_epoch = int(ckpt.get('global_step', 0)), int(ckpt.get('epoch', 0)) + 1
+        # position: our key 'epoch' or torchpack's Trainer.state_dict() name 'epoch_num' (an upstream step-*.pt); without
+        # either the run would silently restart at epoch 1 on an already-advanced LR schedule -- refuse that
+        if 'epoch' not in ckpt and 'epoch_num' not in ckpt:
+            raise KeyError('%s holds no epoch position (epoch / epoch_num): cannot resume the schedule' % args.weight_path)
+        global_step = int(ckpt.get('global_step', 0))
+        first_epoch = int(ckpt.get('epoch', ckpt.get('epoch_num', 0))) + 1
+        savers.best.update({m: v for m, v in (ckpt.get('best_metrics') or {}).items() if m in savers.best})
         log('resumed the trainer state at epoch %d, step %d' % (first_epoch, global_step))
     history = []
     for epoch in range(first_epoch, cfg.num_epochs + 1):
@@ -257,7 +265,8 @@ def main(argv=None):
         values = {m.name: m.after_epoch()[0] for m in metrics}
         log('epoch %d:' % epoch, '  '.join('%s %.3f' % kv for kv in values.items()))
         history.append(dict(epoch=epoch, loss=mean_loss, **values))
-        savers.after_epoch(runner, global_step, values, {'epoch': epoch, 'global_step': global_step})
+        savers.after_epoch(runner, global_step, values, {'epoch': epoch, 'epoch_num': epoch, 'local_step': len(losses),
+                                                         'global_step': global_step})
         if rank == 0:
             with open(os.path.join(run_dir, 'history.json'), 'w') as f:
                 json.dump(history, f, indent=1)

@@ -25,9 +25,11 @@ def _run_three(n_vox, batch, cr, seed, monkeypatch):
 
     crit = MixLovaszCrossEntropy(ignore_index=0)
 
-    def run_cpu(dtype, record):
+    def run_cpu(dtype, record, masks=None):
         m = O.fill_state_by_name(O.SPVCNN(**kw)).train().to(dtype)
         m.dropout.p = 0.0            # random masks differ across implementations (SURVEY 8d "Weights")
+        if masks is not None:        # the arbiter evaluated on the HIP run's side of every ReLU (grad_arbiter.force_relu_masks)
+            GA.force_relu_masks(m, masks)
         rec, remove = GA.record_oracle_relus(m) if record else ({}, lambda: None)
         out = m({'lidar': ots.SparseTensor(feats.to(dtype), coords)})['x_vox']
         remove()
@@ -46,13 +48,13 @@ def _run_three(n_vox, batch, cr, seed, monkeypatch):
     out = mg({'lidar': ts.SparseTensor(feats.cuda(), coords.cuda())})['x_vox']
     loss = crit(out, labels.cuda())
     loss.backward()
-    return m64, m32, out32, loss32, mg, out, loss, rec64, rec_hip
+    return m64, m32, out32, loss32, mg, out, loss, rec64, rec_hip, lambda masks: run_cpu(torch.float64, False, masks)[0]
 
 
 @pytest.mark.parametrize('n_vox,batch,cr', [(3000, 2, 0.5), (30000, 1, 0.5), (6000, 1, 1.0)])
 def test_spvcnn_logits_and_grads(hip, monkeypatch, n_vox, batch, cr):
     import grad_arbiter as GA
-    m64, m32, out_ref, loss_ref, model, out, loss, rec64, rec_hip = _run_three(n_vox, batch, cr, 11, monkeypatch)
+    m64, m32, out_ref, loss_ref, model, out, loss, rec64, rec_hip, rerun64 = _run_three(n_vox, batch, cr, 11, monkeypatch)
     err = float((out.detach().cpu() - out_ref).abs().max())
     assert err < 1e-3, f'logit max abs err {err}'
     assert abs(float(loss) - float(loss_ref)) < 1e-3
@@ -61,7 +63,7 @@ def test_spvcnn_logits_and_grads(hip, monkeypatch, n_vox, batch, cr):
     # flipped element can carry a visible share of a layer's gradient -- such a scene passes only with the flipped
     # elements found and named (grad_arbiter.assert_grads_within_fp64_gate); smooth operators are held to 1e-4 in
     # test_gpu_torchsparse_ops.py.
-    GA.assert_grads_within_fp64_gate('scene 11 (%d voxels x %d, cr %.1f)' % (n_vox, batch, cr), model, m64, m32, rec64, rec_hip)
+    GA.assert_grads_within_fp64_gate('scene 11 (%d voxels x %d, cr %.1f)' % (n_vox, batch, cr), model, m64, m32, rec64, rec_hip, rerun64)
     ref_grads = dict(m32.named_parameters())
     for name, p in model.named_parameters():
         if float(ref_grads[name].grad.abs().max()) < 1e-7:
@@ -78,10 +80,13 @@ def test_kernel_grads_are_as_close_to_fp64_as_the_fp32_reference_is(hip, monkeyp
     import grad_arbiter as GA
     strict = []
     for seed in (12, 13, 14):
-        m64, m32, _, _, mg, _, _, rec64, rec_hip = _run_three(3000, 2, 0.5, seed, monkeypatch)
-        strict.append(GA.assert_grads_within_fp64_gate('scene %d' % seed, mg, m64, m32, rec64, rec_hip))
+        m64, m32, _, _, mg, _, _, rec64, rec_hip, rerun64 = _run_three(3000, 2, 0.5, seed, monkeypatch)
+        strict.append(GA.assert_grads_within_fp64_gate('scene %d' % seed, mg, m64, m32, rec64, rec_hip, rerun64))
         monkeypatch.undo()
     print('GRAD-FP64 strict on', strict)
+    # a scene that is not strict has passed the causal form (fp64 re-evaluated with the HIP masks, 1e-3); flips are rare
+    # events, so most scenes must be strict outright
+    assert sum(strict) >= 2, strict
 
 
 def test_ddp_syncbn_path_on_gpu_single_rank(hip):

@@ -5,6 +5,7 @@ import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from oracle import ts_ref as R
 from u2mkd_amd import _lib as L
+L.LIB_PATH = L.LIB_PATH.replace('libu2mkd_hip.so', 'libu2mkd_hip%s.so' % os.environ.get('AB_SUFFIX', ''))
 from u2mkd_amd.torchsparse.nn import functional as F
 from u2mkd_amd.synth import synth_batch
 from tools.ab_conv import ev

@@ -52,7 +52,9 @@ class MaxPool3x3s2(nn.MaxPool2d):
         super().__init__(kernel_size=3, stride=2, padding=1)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() and not torch.is_autocast_enabled():
+        # (the kernels take planes = n * c <= 65535 and h * w < 2^31: include/u2mkd_hip.h; larger maps stay on torch's)
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() and not torch.is_autocast_enabled()
+                and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] * x.shape[3] < 2 ** 31):
             return _MaxPool3s2Function.apply(x)
         return super().forward(x)
 
@@ -143,7 +145,7 @@ def _up(x, size, skip=None):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) [+ skip]."""
     size = tuple(int(v) for v in size)
     if (_up_on_hip() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() and not torch.is_autocast_enabled()
-            and size[0] >= x.shape[2] and size[1] >= x.shape[3] and (skip is None or (skip.dtype == x.dtype and skip.is_contiguous()
+            and x.shape[0] * x.shape[1] <= 65535 and size[0] >= x.shape[2] and size[1] >= x.shape[3] and (skip is None or (skip.dtype == x.dtype and skip.is_contiguous()
                                                                                       and skip.shape[2:] == size))):
         if _up_taps(x.shape[2], size[0], x.device)[1] is not None and _up_taps(x.shape[3], size[1], x.device)[1] is not None:
             return _UpBilinearFunction.apply(x, skip, size)

@@ -18,7 +18,7 @@
 //     per 32-channel step, each weight fragment used 4 times from registers;
 //   * the 64 gathered rows of a step (32 channels = one full 128-byte line per row, 8 lanes per row) are
 //     split into the h | m | l planes at the LDS store and read back as ready MFMA operand fragments
-//     (ds_read_b128, conflict-free: row stride 208 B);
+//     (ds_read_b128 and the plane stores conflict-free: 192-byte rows, chunks swizzled by bit 3 of the row, see RS);
 //   * weights come in the MFMA-fragment order of u2mkd_weight_fragments (arith = 2), 1 KiB contiguous per
 //     wave load instruction, straight from L2 into registers;
 //   * (tile, 32-channel step) pairs form ONE software pipeline over the workgroup's contiguous run of tiles:
@@ -68,7 +68,14 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 int n_rows = 0) {
     static_assert(B16 ? (SC == 32 || SC == 64) : SC == 32, "step width");
     constexpr int NT = 64 * NW, TN = 16 * NW * NBW;
-    constexpr int RS = 208;                       // bytes per row of the LDS image: 3 planes x 32 bf16 (or 64 bf16) + pad
+    // bytes per row of the LDS image: 3 planes x 32 bf16 (or up to 64 bf16), NO pad; the 16-byte chunk c of a 64-byte plane
+    // segment of tile row `row` sits at chunk c ^ 2 * bit 3 of row.  A ds_read_b128 is served in four 16-lane groups (rows
+    // 0-3 | 12-15 at chunk q with rows 4-11 at chunk q ^ 1, and the complement): 192-byte rows put rows r, r + 4, r + 8, r + 12
+    // on the same 64-byte quarter of the 256-byte bank line, the swizzle spreads those four over its four chunks -- every
+    // group hits 64 different banks; the 8-byte plane stores (16 lanes = 2 rows x 64 bytes) fall on two different halves of
+    // the 128-byte store line.  (Rounds 2-3 ran 208-byte rows: every fragment read and every plane store a 2-way conflict;
+    // removing them is worth 1-3 % -- the kernel is not LDS-bound, see DESIGN.md.)
+    constexpr int RS = 192;
     constexpr int CH = B16 ? SC / 8 : 8;          // 16-byte chunks of a row's step (fp32: 4 channels each, bf16: 8)
     constexpr int NCH = 64 * CH;                  // chunks per step
     constexpr int LPT = (NCH + NT - 1) / NT;      // 16-byte chunks a thread gathers per step
@@ -141,7 +148,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         for (int l = 0; l < LPT; ++l) {
             if (B16) {
                 if (tid + l * NT < NCH)
-                    *reinterpret_cast<f32x4 *>(smem + (slot * 64 + crow[l]) * RS + 16 * cch[l]) = gg[l];
+                    *reinterpret_cast<f32x4 *>(smem + (slot * 64 + crow[l]) * RS + 16 * (cch[l] ^ ((crow[l] >> 2) & 2))) = gg[l];
             } else if (tid + l * NT < NCH) {
                 // split by truncation (x & 0xffff0000; exact residuals), two bf16 packed per dword by a byte permute
                 uint32_t hb[4], mb[4], lb[4];
@@ -153,7 +160,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                     mb[c] = __float_as_uint(r1) & 0xffff0000u;
                     lb[c] = __float_as_uint(r1 - __uint_as_float(mb[c]));
                 }
-                char *row = smem + (slot * 64 + crow[l]) * RS + 8 * cch[l];
+                char *row = smem + (slot * 64 + crow[l]) * RS + 8 * (cch[l] ^ ((crow[l] >> 1) & 4));
                 *reinterpret_cast<uint2 *>(row) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
                 *reinterpret_cast<uint2 *>(row + 64) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
                 *reinterpret_cast<uint2 *>(row + 128) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
@@ -161,7 +168,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         }
     };
     auto read_frag = [&](int slot, int rb, float4 (&aa)[NWF]) __attribute__((always_inline)) {
-        const char *row = smem + (slot * 64 + 16 * rb + r) * RS + 16 * q;
+        const char *row = smem + (slot * 64 + 16 * rb + r) * RS + 16 * (q ^ ((r >> 2) & 2));
 #pragma unroll
         for (int p = 0; p < NWF; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
     };
@@ -293,7 +300,7 @@ template <bool DENSE, bool B16, int SC>
 static void px3_launch(bool w3, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
                        const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y, const float *bias,
                        int n_rows) {
-    const size_t lds = (size_t)2 * 64 * 208;
+    const size_t lds = (size_t)2 * 64 * 192;
     if (!w3 && px3_wide(cout))
         hipLaunchKernelGGL((conv_px3_kernel<4, 4, DENSE, B16, SC>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k,
                            n_tiles, y, bias, n_rows);

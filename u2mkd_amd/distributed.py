@@ -54,6 +54,11 @@ def scene_seed(base: int, step: int = 0) -> int:
     return base + step * world() + rank()
 
 
+def _is_sync_bn(m) -> bool:
+    """a BatchNorm whose batch statistics are merged over the ranks (torch's, or one of this package's forms)"""
+    return isinstance(m, torch.nn.SyncBatchNorm) or 'Sync' in type(m).__name__ or bool(getattr(m, 'synchronised', False))
+
+
 def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int = 25):
     """DDP + (on GPU) SyncBatchNorm, as train_spformer.py:79-83.  Gradient buckets are
     all-reduced while backward is still running; ``gradient_as_bucket_view`` avoids a
@@ -69,9 +74,15 @@ def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int 
     # buffers here are BatchNorm running statistics and step counters, and with every BatchNorm synchronised (or frozen:
     # the teacher) each rank computes the same values from the same all-gathered statistics in the same order, so the
     # broadcast would move hundreds of small tensors per step to overwrite them with themselves.
+    # That argument needs EVERY train-mode BatchNorm under the wrap to be a synchronising one: a plain one (a custom
+    # submodule, a torch fallback path) would let the ranks' running statistics drift apart -- then keep DDP's default.
+    from torch.nn.modules.batchnorm import _BatchNorm
+    plain = [n for n, m in model.named_modules()
+             if isinstance(m, _BatchNorm) and m.training and m.track_running_stats and not _is_sync_bn(m)
+             and any(p.requires_grad for p in m.parameters())]
     ddp = torch.nn.parallel.DistributedDataParallel(
         model, device_ids=ids, find_unused_parameters=False, gradient_as_bucket_view=True,
-        bucket_cap_mb=bucket_cap_mb, broadcast_buffers=False)
+        bucket_cap_mb=bucket_cap_mb, broadcast_buffers=bool(plain))
     # The built-in reduction divides every parameter's gradient view by the world size as it becomes ready: one tiny
     # kernel per parameter per step (485 for the KD student, on the backward's stream).  The stock all-reduce hook does
     # the same division once per BUCKET before the same all-reduce.

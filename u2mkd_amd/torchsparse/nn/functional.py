@@ -804,10 +804,17 @@ def _weight_layout(weight, transpose, fragments, arith=0):
     k, r, c = weight.shape if weight.dim() == 3 else (1,) + tuple(weight.shape)     # 2-D: nn.Linear's [out, in], one offset
     frozen = not weight.requires_grad
     stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0] if not frozen else -1)
+    # the cache lives on the parameter: a reshaping view of it made per call (`conv.weight.squeeze(-1)` of a k = 1 Conv1d,
+    # `.view(cout, cin)` of a 1x1 Conv2d) is a new tensor object every time and would re-lay the weight on every use
+    holder, tag = weight, ''
+    base = weight._base
+    if base is not None and base.numel() == weight.numel() and base.data_ptr() == weight.data_ptr() and base.is_contiguous() \
+            and weight.is_contiguous() and base.requires_grad == weight.requires_grad:
+        holder, tag = base, ':%dx%dx%d' % (k, r, c)
     if fragments:
         # arith 0 = the library's fp32-row arithmetic (bf16x3 / f32), 3 = ONE bf16 plane (bf16 storage)
-        slot = '_u2mkd_wfrag3' if arith == 3 else '_u2mkd_wfrag'
-        hit = weight.__dict__.get(slot)
+        slot = ('_u2mkd_wfrag3' if arith == 3 else '_u2mkd_wfrag') + tag
+        hit = holder.__dict__.get(slot)
         if hit is None or hit[0] != stamp:
             nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, arith)
             fresh = hit is None or hit[1].shape[1] != nbytes or hit[1].device != weight.device
@@ -816,20 +823,20 @@ def _weight_layout(weight, transpose, fragments, arith=0):
             both = torch.empty(2, nbytes, dtype=torch.uint8, device=weight.device) if fresh else hit[1]
             L.call('u2mkd_weight_fragments', L.ptr(weight), k, r, c, 2, arith, L.ptr(both), L.stream())
             hit = (stamp, both)
-            weight.__dict__[slot] = hit
-            job = _FRAG_JOBS.get((id(weight), slot))
-            if not frozen and (fresh or job is None or job[0]() is not weight or job[7] != stamp[1] or job[2] is not both):
-                _register_fragments(weight, slot, both, k, r, c, arith)
+            holder.__dict__[slot] = hit
+            job = _FRAG_JOBS.get((id(holder), slot))
+            if not frozen and (fresh or job is None or job[0]() is not holder or job[7] != stamp[1] or job[2] is not both):
+                _register_fragments(holder, slot, both, k, r, c, arith)
         return hit[1][0 if transpose else 1]
-    key = '_u2mkd_wt'
+    key = '_u2mkd_wt' + tag
     if frozen:
-        hit = weight.__dict__.get(key)
+        hit = holder.__dict__.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
     out = torch.empty(k, c, r, dtype=torch.float32, device=weight.device)
     L.call('u2mkd_transpose_weights', L.ptr(weight), k, r, c, L.ptr(out), L.stream())
     if frozen:
-        weight.__dict__[key] = (stamp, out)
+        holder.__dict__[key] = (stamp, out)
     return out
 
 
