@@ -411,7 +411,7 @@ def child_leg(args, extra_argv, extra_env, workload_note):
         o = json.loads(r.stdout.strip().splitlines()[-1])
         return {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
                 'warmup': o['warmup'], 'batches_rotated': o['config'].get('batches_rotated'),
-                'env': extra_env, 'leg_wall_s': round(time.perf_counter() - t0, 1),
+                'env': extra_env, 'leg_wall_s': round(time.perf_counter() - t0, 1), 'distributed': o.get('distributed'),
                 'workload': o['config']['workload'] + ' -- ' + workload_note}
     except Exception as e:      # timeout / crash: report it, never block the judged line
         return {'error': '%s after %.0f s' % (type(e).__name__, time.perf_counter() - t0), 'env': extra_env,
@@ -517,7 +517,8 @@ def timed_run(step, warmup, steps, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    return D.max_over_ranks(dt), float(loss.detach())
+    timed_run.per_rank = (D.min_over_ranks(dt), D.max_over_ranks(dt))     # fastest / slowest rank of this timed region
+    return timed_run.per_rank[1], float(loss.detach())
 
 
 def run_rank(args):
@@ -560,6 +561,13 @@ def run_rank(args):
                                                  'region (the voxel sets / kernel maps of batch i+1 during step i, between '
                                                  'its forward and backward: one geometry pass per step)' % args.batches,
                        'final_loss': round(loss, 5)},
+            # what the N > 1 path actually ran on: the process group the gradient buckets and the BatchNorm statistics were
+            # reduced over, and the spread of the ranks' own clocks over the same timed region
+            'distributed': {'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                            'rccl_world_size': (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+                            'gradient_reducer': 'u2mkd_amd.distributed.BucketedGradientAverage' if (world > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1') else None,
+                            'ms_per_step_min_rank': round(timed_run.per_rank[0] / args.steps * 1e3, 3),
+                            'ms_per_step_max_rank': round(timed_run.per_rank[1] / args.steps * 1e3, 3)},
         })
         del step
         if world == 1 and not args.no_secondary:
@@ -591,7 +599,7 @@ def run_rank(args):
                     log('secondary kd_6cam_900x1600 done')
                 sec['kd_ddp_path_1rank'] = child_leg(
                     args, ['--steps', '10', '--warmup', '3'], {'U2MKD_FORCE_DDP': '1'},
-                    'the default KD step on the N>1 code path (DistributedDataParallel + SyncBatchNorm conversion over a '
+                    'the default KD step on the N>1 code path (bucketed gradient averaging + SyncBatchNorm conversion over a '
                     'ONE-rank RCCL group, U2MKD_FORCE_DDP=1): its price at N = 1, no communication partner')
                 log('secondary kd_ddp_path_1rank done')
             result['secondary'] = sec

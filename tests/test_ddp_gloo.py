@@ -45,7 +45,7 @@ def _worker(rank, world, port, out_dir):
     assert (r, w) == (rank, world) and D.world() == 2
     seed = D.scene_seed(100)
     assert seed == 100 + rank
-    grads = _scene_grads(seed, lambda m: D.wrap_model(m, sync_bn=False))
+    grads = _scene_grads(seed, lambda m: D.wrap_model(m, sync_bn=False, bucket_cap_mb=0.02))      # (many buckets)
     assert D.max_over_ranks(float(rank)) == 1.0
     torch.save(grads, os.path.join(out_dir, f'g{rank}.pt'))
     D.shutdown()
@@ -63,6 +63,45 @@ def test_two_rank_gradients_are_the_mean(tmp_path):
         assert torch.equal(g0[name], g1[name]), name          # all-reduced: identical on both ranks
         want = (s0[name] + s1[name]) / 2
         assert torch.allclose(g0[name], want, rtol=1e-4, atol=1e-6), name
+
+
+def test_bucketed_gradient_average_mechanics():
+    """BucketedGradientAverage on one process (no collective): several buckets, two backward passes, a parameter that
+    receives no gradient, zero_grad with and without set_to_none -- the gradients equal the bare module's, every p.grad is
+    a slice of its bucket, the state dict carries DDP's `module.` prefix."""
+    from u2mkd_amd import distributed as D
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 16)
+            self.b = torch.nn.Linear(16, 16)
+            self.unused = torch.nn.Linear(4, 4)
+            self.c = torch.nn.Linear(16, 3)
+
+        def forward(self, x):
+            return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+    ref = Net()
+    net = Net()
+    net.load_state_dict(ref.state_dict())
+    wrapped = D.BucketedGradientAverage(net, bucket_cap_mb=0.0005)
+    assert len(wrapped._buckets) >= 3
+    assert set(wrapped.state_dict()) == {'module.' + k for k in ref.state_dict()}
+    x = torch.randn(5, 8)
+    for step, set_none in enumerate((True, False, True)):
+        ref.zero_grad(set_to_none=True)
+        wrapped.zero_grad(set_to_none=set_none)
+        ref(x * (step + 1)).square().mean().backward()
+        wrapped(x * (step + 1)).square().mean().backward()
+        for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+            if p.grad is None:
+                assert float(q.grad.abs().max()) == 0.0, n          # zeros, so that every rank issues the same collectives
+            else:
+                assert torch.equal(p.grad, q.grad), (step, n)
+            b = wrapped._bucket_of[q]
+            i = [j for j, t in enumerate(b['params']) if t is q][0]
+            assert q.grad.data_ptr() == b['views'][i].data_ptr()
 
 
 @pytest.mark.timeout(300)

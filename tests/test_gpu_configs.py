@@ -47,7 +47,8 @@ def test_configs3_cr2_student_batch2_under_ddp_and_syncbn(hip):
     os.environ['U2MKD_FORCE_SYNC_BN'] = '1'
     try:
         run = _runner(2.0, 2.0)
-        assert isinstance(run.net, torch.nn.parallel.DistributedDataParallel)
+        from u2mkd_amd import distributed as D
+        assert isinstance(run.net, D.BucketedGradientAverage)
         assert any(type(m).__name__.endswith('SyncBatchNorm') or 'Sync' in type(m).__name__ for m in run.model.model_s.modules())
         losses = [float(run(d)) for _ in range(3)]
         assert abs(losses[0] - want) < 2e-3 * abs(want), (losses[0], want)

@@ -161,7 +161,7 @@ torch.manual_seed(0)
 model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
 model.dropout.p = 0.0
 net = D.wrap_model(model, sync_bn=True)
-assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+assert isinstance(net, D.BucketedGradientAverage)
 assert any(isinstance(m, lidar.SparseSyncBatchNorm) for m in net.modules())
 b = synth_batch(1500 + 300 * rank, 1, seed=D.scene_seed(100))          # unequal scenes
 feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))

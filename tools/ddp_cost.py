@@ -21,7 +21,7 @@ run = T.KDStep(model, num_epochs=50, batch_size=1)
 run.train_mode()
 if ddp:
     net = run.net
-    print('DDP: broadcast_buffers', net.broadcast_buffers, 'buckets', len(net.reducer._get_zeros_like_grad_buckets()) if hasattr(net.reducer, '_get_zeros_like_grad_buckets') else '?',
+    print('DDP: broadcast_buffers', net.broadcast_buffers, 'buckets', len(net._buckets),
           'params', sum(1 for p in net.parameters() if p.requires_grad))
 res = [T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234 + i, image_hw=(360, 640))) for i in range(4)]
 calls = collections.Counter()

@@ -14,7 +14,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'world', 'rank', 'wrap_model', 'max_over_ranks', 'scene_seed', 'shutdown']
+__all__ = ['init_from_env', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
 
 
 def init_from_env(backend: str | None = None):
@@ -56,39 +56,150 @@ def scene_seed(base: int, step: int = 0) -> int:
 
 def _is_sync_bn(m) -> bool:
     """a BatchNorm whose batch statistics are merged over the ranks (torch's, or one of this package's forms)"""
-    return isinstance(m, torch.nn.SyncBatchNorm) or 'Sync' in type(m).__name__ or bool(getattr(m, 'synchronised', False))
+    return isinstance(m, torch.nn.SyncBatchNorm)
+
+
+class BucketedGradientAverage(torch.nn.Module):
+    """Data-parallel gradient averaging, the role DistributedDataParallel plays in train_lc_nusc_tsd_full.py:80-84: the
+    parameters are cut into buckets in reverse registration order (~ the order their gradients appear), and as soon as
+    the last gradient of a bucket has been accumulated the bucket is flattened and all-reduced (average) on a side
+    stream while the backward keeps running; when the backward ends every ``p.grad`` IS its slice of the reduced buffer.
+
+    Why not torch's DDP: with ``gradient_as_bucket_view`` every parameter's gradient is COPIED into its bucket slice as
+    it is produced -- one copy kernel per parameter per step, 485 for the KD student: +515 launches and +3.2 ms of kernel
+    time per step at ONE rank (profiles/r4: the N>1 path cost 86 ms against 80 ms before any byte moved).  Here a bucket is
+    flattened by one multi-tensor copy, the division by the world size is the collective's own (ReduceOp.AVG on RCCL), and
+    the module's buffers are not re-broadcast (see ``wrap_model``).  Same keys as DDP in ``state_dict()`` (`module.`
+    prefix: the reference's checkpoints, core/nusc_trainers.py:180,198)."""
+
+    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 25.0, broadcast_buffers: bool = False):
+        super().__init__()
+        self.module = module
+        self.broadcast_buffers = bool(broadcast_buffers)
+        self._world = world()
+        params = [p for p in module.parameters() if p.requires_grad]
+        self._on_gpu = bool(params) and params[0].is_cuda
+        self._avg = dist.is_initialized() and dist.get_backend() == 'nccl'
+        # every rank starts from rank 0's values (DDP's constructor does the same)
+        if self._world > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, 0)
+        self._buckets = []
+        self._bucket_of = {}
+        cap = int(bucket_cap_mb * 2 ** 20)
+        cur, size = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > cap or cur[0].dtype != p.dtype):
+                self._add_bucket(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self._add_bucket(cur)
+        self._comm = torch.cuda.Stream() if self._on_gpu else None
+        self._armed = False
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _add_bucket(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        views, o = [], 0
+        for p in plist:
+            views.append(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        b = {'params': list(plist), 'flat': flat, 'views': views, 'pending': len(plist), 'work': None, 'streams': {}}
+        for p in plist:
+            self._bucket_of[p] = b
+        self._buckets.append(b)
+
+    def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self._world > 1 and self.training:
+            with torch.no_grad():
+                for t in self.module.buffers():
+                    dist.broadcast(t, 0)
+        return self.module(*args, **kwargs)
+
+    # ---- backward side
+    def _on_grad(self, p):
+        if not self._armed:                       # first gradient of this backward: finish when the engine is done
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        b = self._bucket_of[p]
+        if self._on_gpu:                          # (gradients come from several streams: camera branch, weight-gradient stream)
+            st = torch.cuda.current_stream()
+            b['streams'][st.stream_id] = st
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            self._reduce(b)
+
+    def _reduce(self, b):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
+        if self._on_gpu:
+            # one event per producing stream, recorded now: it covers every gradient that stream has produced so far
+            for st in b['streams'].values():
+                self._comm.wait_event(st.record_event())
+            if not b['streams']:
+                self._comm.wait_stream(torch.cuda.current_stream())
+            ctx = torch.cuda.stream(self._comm)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx, torch.no_grad():
+            torch._foreach_copy_(b['views'], grads)
+            if self._world > 1:
+                if self._avg:
+                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG, async_op=True)
+                else:
+                    b['work'] = dist.all_reduce(b['flat'], async_op=True)
+        b['pending'] = -1                         # launched
+
+    def _finish(self):
+        """End of the backward: buckets with a parameter that received no gradient go now (zeros for the missing ones, so
+        every rank issues the same collectives), then the caller's stream waits for the side stream and every ``p.grad``
+        becomes its slice of the reduced bucket."""
+        for b in self._buckets:
+            if b['pending'] >= 0:
+                self._reduce(b)
+        import contextlib
+        with (torch.cuda.stream(self._comm) if self._on_gpu else contextlib.nullcontext()), torch.no_grad():
+            for b in self._buckets:
+                if b['work'] is not None:
+                    b['work'].wait()              # (RCCL: orders the side stream behind the collective, no host wait)
+                    b['work'] = None
+                    if not self._avg:             # gloo has no averaging reduction
+                        b['flat'].div_(self._world)
+        if self._on_gpu:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        for b in self._buckets:
+            for p, v in zip(b['params'], b['views']):
+                p.grad = v
+            b['pending'] = len(b['params'])
+            b['streams'] = {}
+        self._armed = False
 
 
 def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int = 25):
-    """DDP + (on GPU) SyncBatchNorm, as train_spformer.py:79-83.  Gradient buckets are
-    all-reduced while backward is still running; ``gradient_as_bucket_view`` avoids a
-    copy per bucket."""
+    """Data-parallel wrap + (on GPU) SyncBatchNorm, as train_spformer.py:79-83: ``BucketedGradientAverage`` above in
+    DistributedDataParallel's place (gradient buckets all-reduced while the backward is still running)."""
     if world() == 1 and os.environ.get('U2MKD_FORCE_DDP') != '1':
         return model
     on_gpu = next(model.parameters()).is_cuda
     if sync_bn and on_gpu:
         from .lidar.point_voxel import SparseSyncBatchNorm
         model = SparseSyncBatchNorm.convert_sync_batchnorm(model)
-    ids = [torch.cuda.current_device()] if on_gpu else None
-    # broadcast_buffers=False: DDP's default re-broadcasts every buffer from rank 0 before each forward.  The only
-    # buffers here are BatchNorm running statistics and step counters, and with every BatchNorm synchronised (or frozen:
-    # the teacher) each rank computes the same values from the same all-gathered statistics in the same order, so the
-    # broadcast would move hundreds of small tensors per step to overwrite them with themselves.
-    # That argument needs EVERY train-mode BatchNorm under the wrap to be a synchronising one: a plain one (a custom
-    # submodule, a torch fallback path) would let the ranks' running statistics drift apart -- then keep DDP's default.
+    # Buffers are NOT re-broadcast before every forward (DDP's default does): the only buffers here are BatchNorm running
+    # statistics and step counters, and with every BatchNorm synchronised (or frozen: the teacher) each rank computes the
+    # same values from the same all-gathered statistics in the same order -- the broadcast would move hundreds of small
+    # tensors per step to overwrite them with themselves.  That argument needs EVERY train-mode BatchNorm under the wrap
+    # to be a synchronising one: a plain one (a custom submodule, a torch fallback path, the CPU path) would let the
+    # ranks' running statistics drift apart -- then the buffers are broadcast as DDP would.
     from torch.nn.modules.batchnorm import _BatchNorm
     plain = [n for n, m in model.named_modules()
              if isinstance(m, _BatchNorm) and m.training and m.track_running_stats and not _is_sync_bn(m)
              and any(p.requires_grad for p in m.parameters())]
-    ddp = torch.nn.parallel.DistributedDataParallel(
-        model, device_ids=ids, find_unused_parameters=False, gradient_as_bucket_view=True,
-        bucket_cap_mb=bucket_cap_mb, broadcast_buffers=bool(plain))
-    # The built-in reduction divides every parameter's gradient view by the world size as it becomes ready: one tiny
-    # kernel per parameter per step (485 for the KD student, on the backward's stream).  The stock all-reduce hook does
-    # the same division once per BUCKET before the same all-reduce.
-    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-    ddp.register_comm_hook(state=None, hook=default_hooks.allreduce_hook)
-    return ddp
+    return BucketedGradientAverage(model, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=bool(plain))
 
 
 def max_over_ranks(value: float) -> float:
@@ -97,6 +208,15 @@ def max_over_ranks(value: float) -> float:
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def min_over_ranks(value: float) -> float:
+    if world() == 1:
+        return float(value)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return float(t.item())
 
 
