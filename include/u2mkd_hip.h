@@ -524,6 +524,15 @@ int u2mkd_bn_backward_apply_bf16(const void *dy, const void *x, int64_t n, int32
  * split + clamp to [0, 2*qgl-1]).                                                         */
 int u2mkd_sptr_window_keys(const float *xyz /*[n,3]*/, const int32_t *batch /*[n]*/, int64_t n, const float *lo4,
                            const float *hi4, float sx, float sy, float sz, int64_t *keys /*[n]*/, u2mkd_stream_t s);
+/* Both window plans of one SphereFormer block from one pass: the spherical coordinates of cart2sphere
+ * (spherical_transformer.py:31-36, torch's fp32 arithmetic operation by operation), the bounds of both coordinate systems
+ * and the grid_cluster keys of the cubic (windows cx, cy, cz) and the spherical (sx, sy, sz) branch (:206-213), two launches
+ * instead of ~28 torch operators.  sphere [n,3]; bounds [16] = lo4 | hi4 of (x, y, z, batch), lo4 | hi4 of
+ * (theta, beta, r, batch); keys as u2mkd_sptr_window_keys; workspace of u2mkd_sptr_plan_prepare_workspace_bytes().   */
+size_t u2mkd_sptr_plan_prepare_workspace_bytes(void);
+int u2mkd_sptr_plan_prepare(const float *xyz /*[n,3]*/, const int32_t *batch /*[n]*/, int64_t n, float cx, float cy, float cz,
+                            float sx, float sy, float sz, float *sphere, float *bounds, int64_t *keys_cubic,
+                            int64_t *keys_sphere, void *workspace, u2mkd_stream_t s);
 int u2mkd_sptr_window_ranges(const int64_t *sorted_keys, int64_t n, int32_t *wstart /*[n]*/, int32_t *wlen /*[n]*/,
                              u2mkd_stream_t s);
 int u2mkd_sptr_quant_coords(const float *xyz /*[n,3]*/, const int32_t *sort_idx /*[n]*/, int64_t n, const float *lo,

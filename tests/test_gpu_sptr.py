@@ -170,3 +170,25 @@ def test_packed_attention_layer_equals_slice_scale_concat_form(hip, monkeypatch,
     names = ['out', 'dx'] + [n for n, _ in layer.named_parameters()]
     for n, a, c in zip(names, res[True], res[False]):
         assert torch.equal(a, c), (n, float((a - c).abs().max()))
+
+
+def test_window_plan_pair_equals_the_two_torch_built_plans(hip):
+    """WindowPlan.pair (u2mkd_sptr_plan_prepare: spherical coordinates, bounds and both key arrays in two launches)
+    against cart2sphere + two WindowPlan constructions out of torch operators: the spherical coordinates, the bounds,
+    the sort permutations and the window ranges are EQUAL, bit for bit (the window a point falls into is a decision)."""
+    from u2mkd_amd import sptr
+    from u2mkd_amd.lidar.sphereformer import cart2sphere
+    g = torch.Generator().manual_seed(5)
+    for n, scale in ((54321, 50.0), (6000, 12.0), (77, 3.0), (1, 1.0)):
+        xyz = ((torch.rand(n, 3, generator=g) - 0.5) * 2 * scale).cuda()
+        xyz[:, 2] *= 0.1
+        batch = (torch.rand(n, generator=g) < 0.4).long().cuda()
+        wc, ws = np.array([0.6, 0.6, 0.6]), np.array([2.0, 2.0, 120.0])
+        sph = cart2sphere(xyz)
+        a, b = sptr.WindowPlan(xyz, batch, wc), sptr.WindowPlan(sph, batch, ws)
+        p, q, sph2 = sptr.WindowPlan.pair(xyz, batch, wc, ws)
+        assert torch.equal(sph, sph2), float((sph - sph2).abs().max())
+        for ref, got in ((a, p), (b, q)):
+            assert torch.equal(ref.lo, got.lo)
+            assert torch.equal(ref.sort_idx, got.sort_idx) and torch.equal(ref.wstart, got.wstart) and torch.equal(ref.wlen, got.wlen)
+            assert ref.window_size == got.window_size and ref.n == got.n

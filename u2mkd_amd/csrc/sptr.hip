@@ -60,6 +60,99 @@ __global__ void window_keys_kernel(const float *__restrict__ xyz, const int32_t 
     keys[i] = c;
 }
 
+// ---- both window plans of a SphereFormer block from one pass over the points (u2mkd_sptr_plan_prepare) -----------
+// spherical_transformer.py:31-36 (cart2sphere) + the two grid_cluster calls (:206-213) issue, as torch operators, 16
+// element-wise launches for the spherical coordinates and per branch a cat, two reductions and the key kernel: ~28
+// launches per block, 8 blocks per KD step.  Here: kernel 1 writes the spherical coordinates and per-workgroup
+// minima / maxima of (x, y, z, batch, theta, beta, r); kernel 2 merges those (<= 256 workgroups) and writes both key
+// arrays.  The arithmetic is torch's, operation by operation (fp32, no contraction): theta = (atan2(y, x) + pi) * 180 *
+// (1 / pi) -- a division by a Python scalar is a multiplication by its fp32 reciprocal in ATen --, beta =
+// atan2(sqrt(x * x + y * y), z) * 180 * (1 / pi), r = sqrt(x * x + y * y + z * z).
+constexpr int kPrepWg = 256;     // workgroups of kernel 1 at most (= partial rows kernel 2 merges)
+
+__global__ void __launch_bounds__(256)
+sptr_prep_sphere_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ batch, int64_t n,
+                        float *__restrict__ sphere, float *__restrict__ partial /*[gridDim.x][14]*/) {
+#pragma clang fp contract(off)
+    const float pi = 3.14159265358979323846f, inv_pi = 1.0f / pi;
+    float lo[7], hi[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        float v[7];
+        v[0] = x; v[1] = y; v[2] = z; v[3] = (float)batch[i];
+        v[4] = ((atan2f(y, x) + pi) * 180.0f) * inv_pi;
+        v[5] = (atan2f(sqrtf(x2 + y2), z) * 180.0f) * inv_pi;
+        v[6] = sqrtf((x2 + y2) + z2);
+        sphere[i * 3] = v[4]; sphere[i * 3 + 1] = v[5]; sphere[i * 3 + 2] = v[6];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]); }
+    }
+    __shared__ float red[4][14];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
+        }
+        if (lane == 0) { red[wave][d] = lo[d]; red[wave][7 + d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int w = 1; w < 4; ++w) v = d < 7 ? fminf(v, red[w][d]) : fmaxf(v, red[w][d]);
+        partial[(size_t)blockIdx.x * 14 + d] = v;
+    }
+}
+
+// bounds[16] = lo4 | hi4 of (x, y, z, batch), lo4 | hi4 of (theta, beta, r, batch); keys as window_keys_kernel
+__global__ void __launch_bounds__(256)
+sptr_prep_keys_kernel(const float *__restrict__ xyz, const float *__restrict__ sphere, const int32_t *__restrict__ batch,
+                      int64_t n, const float *__restrict__ partial, int n_partial, float cx, float cy, float cz, float sx,
+                      float sy, float sz, float *__restrict__ bounds, int64_t *__restrict__ keys_c,
+                      int64_t *__restrict__ keys_s) {
+    __shared__ float b[14];
+    if (threadIdx.x < 14) {
+        const int d = threadIdx.x;
+        float v = partial[d];
+        for (int w = 1; w < n_partial; ++w) v = d < 7 ? fminf(v, partial[(size_t)w * 14 + d]) : fmaxf(v, partial[(size_t)w * 14 + d]);
+        b[d] = v;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        const int t = threadIdx.x, d = t & 3, hi = (t >> 2) & 1, sph = t >> 3;
+        bounds[t] = b[(hi ? 7 : 0) + (d == 3 ? 3 : (sph ? 4 + d : d))];
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float bf = ((float)batch[i] - b[3]) / 1.f;
+    {
+        const float size[3] = {cx, cy, cz};
+        int64_t c = 0, k = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c += (int64_t)((xyz[i * 3 + d] - b[d]) / size[d]) * k;
+            k *= (int64_t)((b[7 + d] - b[d]) / size[d]) + 1;
+        }
+        keys_c[i] = c + (int64_t)bf * k;
+    }
+    {
+        const float size[3] = {sx, sy, sz};
+        int64_t c = 0, k = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c += (int64_t)((sphere[i * 3 + d] - b[4 + d]) / size[d]) * k;
+            k *= (int64_t)((b[11 + d] - b[4 + d]) / size[d]) + 1;
+        }
+        keys_s[i] = c + (int64_t)bf * k;
+    }
+}
+
 // sorted keys -> (first sorted position, length) of the window of every sorted position
 __global__ void window_ranges_kernel(const int64_t *__restrict__ keys, int64_t n, int32_t *__restrict__ wstart,
                                      int32_t *__restrict__ wlen) {
@@ -700,6 +793,22 @@ int u2mkd_sptr_window_keys(const float *xyz, const int32_t *batch, int64_t n, co
     hipLaunchKernelGGL(window_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), xyz, batch, n,
                        lo4, hi4, (const int32_t *)nullptr, sx, sy, sz, keys);
     return check_launch("u2mkd_sptr_window_keys");
+}
+
+size_t u2mkd_sptr_plan_prepare_workspace_bytes() { return (size_t)kPrepWg * 14 * sizeof(float); }
+
+int u2mkd_sptr_plan_prepare(const float *xyz, const int32_t *batch, int64_t n, float cx, float cy, float cz, float sx,
+                            float sy, float sz, float *sphere, float *bounds, int64_t *keys_cubic, int64_t *keys_sphere,
+                            void *workspace, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(xyz && batch && sphere && bounds && keys_cubic && keys_sphere && workspace, "u2mkd_sptr_plan_prepare: null pointer");
+    U2_REQUIRE(cx > 0 && cy > 0 && cz > 0 && sx > 0 && sy > 0 && sz > 0, "u2mkd_sptr_plan_prepare: window sizes must be positive");
+    const int g1 = (int)(ceil_div(n, 256) < kPrepWg ? ceil_div(n, 256) : kPrepWg);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(sptr_prep_sphere_kernel, dim3(g1), dim3(256), 0, as_stream(s), xyz, batch, n, sphere, partial);
+    hipLaunchKernelGGL(sptr_prep_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), xyz, sphere, batch, n,
+                       partial, g1, cx, cy, cz, sx, sy, sz, bounds, keys_cubic, keys_sphere);
+    return check_launch("u2mkd_sptr_plan_prepare");
 }
 
 int u2mkd_sptr_window_ranges(const int64_t *sorted_keys, int64_t n, int32_t *wstart, int32_t *wlen,

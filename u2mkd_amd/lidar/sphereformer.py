@@ -103,9 +103,12 @@ class SparseMultiheadSASphereConcat(nn.Module):
         qkv = self.qkv(feats).reshape(N, 3, self.num_heads, C // self.num_heads)
         h1 = self.num_heads_brc1
         xyz = xyz.float()
-        xyz_sphere = cart2sphere(xyz)
-        plan = sptr.WindowPlan(xyz, batch, self.window_size)
-        plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
+        if xyz.is_cuda:
+            plan, plan_s, xyz_sphere = sptr.WindowPlan.pair(xyz, batch, self.window_size, self.window_size_sphere)
+        else:
+            xyz_sphere = cart2sphere(xyz)
+            plan = sptr.WindowPlan(xyz, batch, self.window_size)
+            plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
         cubic = (0, h1, xyz, plan, self.quant_size, self.quant_grid_length,
                  (self.relative_pos_query_table, self.relative_pos_key_table, self.relative_pos_value_table), None)
         sphere = (h1, self.num_heads - h1, xyz_sphere, plan_s, self.quant_size_sphere, self.quant_grid_length_sphere,

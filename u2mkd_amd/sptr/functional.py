@@ -38,6 +38,10 @@ class WindowPlan:
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         L.call('u2mkd_sptr_window_keys', L.ptr(xyz), L.ptr(b32), n, L.ptr(lo4), L.ptr(hi4), w[0], w[1], w[2],
                L.ptr(keys), L.stream())
+        self._finish(n, keys, lo4, w)
+
+    def _finish(self, n, keys, lo4, w):
+        dev = keys.device
         skeys, sort_idx = torch.sort(keys, stable=True)
         self.sort_idx = sort_idx.int().contiguous()
         self.wstart = torch.empty(n, dtype=torch.int32, device=dev)
@@ -47,6 +51,34 @@ class WindowPlan:
         self.window_size = w
         self.lo = lo4
         self._qc = {}
+
+    @classmethod
+    def pair(cls, xyz: torch.Tensor, batch: torch.Tensor, window_size, window_size_sphere):
+        """(cubic plan, spherical plan, spherical coordinates [n, 3]) of one SphereFormer block: ``cart2sphere`` and both
+        ``WindowPlan`` constructions (spherical_transformer.py:31-36, 206-213) from ONE pass over the points
+        (u2mkd_sptr_plan_prepare: two launches for the coordinates, the bounds and both key arrays)."""
+        L.require_cuda(xyz, batch)
+        xyz = xyz.contiguous().float()
+        n = xyz.shape[0]
+        dev = xyz.device
+        wc = [float(v) for v in np.asarray(window_size, dtype=np.float64).reshape(-1)]
+        ws = [float(v) for v in np.asarray(window_size_sphere, dtype=np.float64).reshape(-1)]
+        if len(wc) == 1:
+            wc = wc * 3
+        b32 = batch.int().contiguous()
+        sphere = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        bounds = torch.empty(16, dtype=torch.float32, device=dev)
+        keys = torch.empty(2, n, dtype=torch.int64, device=dev)
+        ws_bytes = L.load().u2mkd_sptr_plan_prepare_workspace_bytes()
+        work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.call('u2mkd_sptr_plan_prepare', L.ptr(xyz), L.ptr(b32), n, wc[0], wc[1], wc[2], ws[0], ws[1], ws[2], L.ptr(sphere),
+               L.ptr(bounds), L.ptr(keys[0]), L.ptr(keys[1]), L.ptr(work), L.stream())
+        plans = []
+        for i, w in enumerate((wc, ws)):
+            p = cls.__new__(cls)
+            p._finish(n, keys[i], bounds[8 * i:8 * i + 4], w)
+            plans.append(p)
+        return plans[0], plans[1], sphere
 
     def int(self):
         return self
