@@ -537,9 +537,10 @@ def run_rank(args):
             print(json.dumps({'dryrun': True, 'n_gpus': world, 'max_rank': top}), flush=True)
         D.shutdown()
         return
+    from u2mkd_amd import distributed as D
+    D.configure_runtime()                      # (before the first HIP call: the hardware-queue count of a multi-rank process)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    from u2mkd_amd import distributed as D
     rank, world, local_rank = D.init_from_env('nccl')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')

@@ -6,18 +6,27 @@ Prints the wall time per step, the launches a step issues (C-ABI calls + aten op
 tools/op_census.py; here only the collectives) and what wrap_model decided."""
 import collections, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-ddp = 'ddp' in sys.argv[1:]
-if ddp:
+mode = (sys.argv[1:] or ['plain'])[0]        # plain | ddp | pg (process group only) | wrap (reducer only, no group)
+ddp = mode == 'ddp'
+if mode in ('ddp', 'pg'):
     os.environ['U2MKD_FORCE_DDP'] = '1'
 import torch
 import torch.distributed as dist
 from u2mkd_amd import distributed as D, lidar, train as T, kd as KD
 from u2mkd_amd.synth import synth_kd_batch
-D.init_from_env()
+if mode == 'pglazy':                        # a group without an eagerly created communicator (no device_id): RCCL stays asleep
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29534')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+else:
+    D.init_from_env()
+if mode == 'pg':
+    os.environ.pop('U2MKD_FORCE_DDP')       # the group exists, the model stays unwrapped
 torch.manual_seed(0)
 sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
 model = KD.TSDFull(cr=1.0, cr_t=2.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
 run = T.KDStep(model, num_epochs=50, batch_size=1)
+if mode == 'wrap':
+    run.net = D.BucketedGradientAverage(model)
 run.train_mode()
 if ddp:
     net = run.net
@@ -49,7 +58,7 @@ calls.clear()
 t0 = time.perf_counter()
 loop(16)
 torch.cuda.synchronize()
-print('VARIANT %-8s %.2f ms/step  collectives per step: %s' % ('ddp' if ddp else 'plain', (time.perf_counter() - t0) / 16 * 1e3,
+print('VARIANT %-8s %.2f ms/step  collectives per step: %s' % (mode, (time.perf_counter() - t0) / 16 * 1e3,
                                                               {k: v / 16 for k, v in calls.items()}), flush=True)
-if ddp:
+if mode in ('ddp', 'pg', 'pglazy'):
     D.shutdown()

@@ -14,7 +14,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
+__all__ = ['init_from_env', 'configure_runtime', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
 
 
 def init_from_env(backend: str | None = None):
@@ -23,6 +23,7 @@ def init_from_env(backend: str | None = None):
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     rnk = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    configure_runtime()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         # (more local ranks than devices: only a gloo group can share a card -- tests on a one-GPU box; RCCL refuses)
@@ -38,6 +39,19 @@ def init_from_env(backend: str | None = None):
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'))
         dist.init_process_group(backend, rank=rnk, world_size=world_size, **kwargs)
     return rnk, world_size, local
+
+
+def configure_runtime():
+    """Process-level HIP settings of a multi-rank run; must run before the process's first HIP call (a launcher's first
+    line: ``torch.cuda.is_available()`` already initialises the runtime)."""
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':
+        # RCCL's communicator brings streams of its own.  The step keeps four streams busy (student LiDAR, frozen teacher,
+        # camera branch, weight gradients) and the HIP runtime maps streams onto 4 hardware queues by default: with the
+        # communicator alive two of the working streams share a queue and serialise -- measured +10.5 ms per KD step
+        # (76.0 -> 86.5 ms) at ONE rank, before a single byte moves (tools/ddp_cost.py: `pg` against `pglazy`); with 8
+        # queues the same run takes 76.3-76.8 ms.  The runtime reads the variable when it initialises, i.e. at the first
+        # HIP call of the process: this has to run before anything touches the GPU (the launchers call it first).
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 def world() -> int:
@@ -98,7 +112,6 @@ class BucketedGradientAverage(torch.nn.Module):
             size += nbytes
         if cur:
             self._add_bucket(cur)
-        self._comm = torch.cuda.Stream() if self._on_gpu else None
         self._armed = False
         for p in params:
             p.register_post_accumulate_grad_hook(self._on_grad)
@@ -135,43 +148,41 @@ class BucketedGradientAverage(torch.nn.Module):
             self._reduce(b)
 
     def _reduce(self, b):
+        """Flatten the bucket and start its all-reduce from the stream the completing gradient arrived on (no stream of
+        our own: the step already keeps the GPU's hardware queues busy with its four streams, a fifth one shares a queue
+        with one of them and serialises it -- measured +10 ms per step).  The other producing streams are joined by one
+        event each, recorded now: it covers every gradient that stream has produced so far."""
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
-        if self._on_gpu:
-            # one event per producing stream, recorded now: it covers every gradient that stream has produced so far
-            for st in b['streams'].values():
-                self._comm.wait_event(st.record_event())
-            if not b['streams']:
-                self._comm.wait_stream(torch.cuda.current_stream())
-            ctx = torch.cuda.stream(self._comm)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx, torch.no_grad():
+        with torch.no_grad():
+            if self._on_gpu:
+                cur = torch.cuda.current_stream()
+                for sid, st in b['streams'].items():
+                    if sid != cur.stream_id:
+                        cur.wait_event(st.record_event())
             torch._foreach_copy_(b['views'], grads)
             if self._world > 1:
-                if self._avg:
-                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG, async_op=True)
-                else:
-                    b['work'] = dist.all_reduce(b['flat'], async_op=True)
+                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
+            if self._on_gpu:
+                b['done'] = cur.record_event()
         b['pending'] = -1                         # launched
 
     def _finish(self):
         """End of the backward: buckets with a parameter that received no gradient go now (zeros for the missing ones, so
-        every rank issues the same collectives), then the caller's stream waits for the side stream and every ``p.grad``
-        becomes its slice of the reduced bucket."""
+        every rank issues the same collectives), the caller's stream joins every bucket's copy / collective, and every
+        ``p.grad`` becomes its slice of the reduced bucket."""
         for b in self._buckets:
             if b['pending'] >= 0:
                 self._reduce(b)
-        import contextlib
-        with (torch.cuda.stream(self._comm) if self._on_gpu else contextlib.nullcontext()), torch.no_grad():
+        with torch.no_grad():
             for b in self._buckets:
+                if self._on_gpu and b.get('done') is not None:
+                    torch.cuda.current_stream().wait_event(b['done'])
+                    b['done'] = None
                 if b['work'] is not None:
-                    b['work'].wait()              # (RCCL: orders the side stream behind the collective, no host wait)
+                    b['work'].wait()              # (RCCL: orders the current stream behind the collective, no host wait)
                     b['work'] = None
                     if not self._avg:             # gloo has no averaging reduction
                         b['flat'].div_(self._world)
-        if self._on_gpu:
-            torch.cuda.current_stream().wait_stream(self._comm)
         for b in self._buckets:
             for p, v in zip(b['params'], b['views']):
                 p.grad = v
