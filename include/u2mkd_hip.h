@@ -73,7 +73,8 @@ int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32
 
 /* The PAIR SCHEDULE of a map (what torchsparse keeps as nbmaps/nbsizes, laid out for dense
  * MFMA tiles): all (input i, output j) pairs grouped by offset, every offset's group padded
- * with -1 to a multiple of 64 entries so that a 64-entry tile belongs to ONE offset.
+ * with -1 to a multiple of 128 entries so that TWO consecutive 64-entry tiles belong to ONE offset (conv_px3.hip multiplies
+ * two tiles per step by one set of weight fragments).
  *   pair_in / pair_out [u2mkd_pairs_capacity]  rows of the pair in slot p (or -1)
  *   pos_out [n_out, k]   slot of the pair (k, j), -1 if none       (written completely)
  *   pos_in  [n_in,  k]   slot of the pair (k, i), -1 if none       (caller pre-fills -1)

@@ -254,14 +254,14 @@ def test_both_conv_schedules_match_oracle(F, cin, cout, kind):
 
 def test_pair_schedule_is_the_padded_rulebook(F):
     """u2mkd_pairs_build: the valid slots, in order, are exactly torchsparse's nbmaps (grouped by
-    offset, ascending output); groups are padded to 64; pos_in / pos_out invert the list."""
+    offset, ascending output); groups are padded to 128 (two 64-entry tiles of one offset); pos_in / pos_out invert the list."""
     coords, _ = _scene(3000, 2)
     for ks, st_ in ((3, 1), (2, 2)):
         nbmaps, nbsizes, oc, res = R.build_kmap(coords, 1, ks, st_)
         km = F.build_kmap(_dev(coords), (1,) * 3, (ks,) * 3, (st_,) * 3)
         ps = km.pair_schedule()
         p_pad, n_tiles = ps.meta.cpu().tolist()
-        pad = (nbsizes + 63) // 64 * 64
+        pad = (nbsizes + 127) // 128 * 128
         assert p_pad == int(pad.sum()) and n_tiles == p_pad // 64 and p_pad <= ps.cap
         pi, po = ps.pair_in.cpu().numpy()[:p_pad], ps.pair_out.cpu().numpy()[:p_pad]
         assert ((pi >= 0) == (po >= 0)).all()

@@ -60,7 +60,12 @@ __device__ __forceinline__ px_bf16x8 px_bf8(const float4 &x) {
 // "pair list" is the identity -- tile t = rows 64 t .. 64 t + 63 of `in`, one offset -- the bias is added at the
 // store and rows past n_rows are not written (y = the [n_rows, cout] output itself, no scratch rows).
 // B16: bf16 rows in / out (see the header); SC = channels per pipeline step (fp32 rows: 32; bf16 rows: 64 or 32)
-template <int NW, int NBW, bool DENSE = false, bool B16 = false, int SC = 32>
+// TL: 64-pair tiles a workgroup multiplies per step against ONE set of weight fragments (a "unit" = TL consecutive tiles of
+// one offset: the pair schedule pads every offset's group to 128 entries).  The wide layers are bound by the bytes a step pulls
+// through the vector L1 (weight fragments from L2 / Infinity Cache + gathered rows: ~7 TB/s chip-wide at 512 -> 512), and
+// per 128 pairs x 256 columns x 32 channels those are 2 x (48 KB weights + 8 KB rows) = 112 KB with TL = 1 and 256-column
+// tiles (NBW = 4), 2 x (24 + 16) = 80 KB with TL = 2 and 128-column tiles (NBW = 2) at the same 64 accumulator registers.
+template <int NW, int NBW, bool DENSE = false, bool B16 = false, int SC = 32, int TL = 1>
 __global__ void __launch_bounds__(64 * NW)
 conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wf, int cout,
                 const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
@@ -77,14 +82,16 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     // removing them is worth 1-3 % -- the kernel is not LDS-bound, see DESIGN.md.)
     constexpr int RS = 192;
     constexpr int CH = B16 ? SC / 8 : 8;          // 16-byte chunks of a row's step (fp32: 4 channels each, bf16: 8)
-    constexpr int NCH = 64 * CH;                  // chunks per step
+    constexpr int RU = 64 * TL, RB = 4 * TL;      // rows / 16-row blocks of a unit
+    constexpr int NCH = RU * CH;                  // chunks per step
     constexpr int LPT = (NCH + NT - 1) / NT;      // 16-byte chunks a thread gathers per step
     constexpr int NWF = B16 ? SC / 32 : 3;        // weight / row fragments per (column block, step): k-steps or planes
     const int esz = B16 ? 2 : 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64][RS]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][RU][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int ntile = DENSE ? (n_rows + 63) / 64 : *n_tiles;
+    const int ntile64 = DENSE ? (n_rows + 63) / 64 : *n_tiles;
+    const int ntile = (ntile64 + TL - 1) / TL;                    // units
     const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntile);
     if (t0 >= t1) return;
@@ -102,9 +109,9 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         cch[l] = e % CH;
     }
 
-    f32x4 acc[4][NBW];
+    f32x4 acc[RB][NBW];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
         for (int n = 0; n < NBW; ++n) acc[b][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 bw[2][NWF * NBW];
@@ -117,10 +124,10 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             if (DENSE) {
-                const int row = tt * 64 + crow[l];
+                const int row = tt * RU + crow[l];
                 ix[l] = row < n_rows ? row : 0;
             } else {
-                ix[l] = pair_idx[(size_t)tt * 64 + crow[l]];
+                ix[l] = pair_idx[(size_t)tt * RU + crow[l]];
             }
         }
     };
@@ -148,7 +155,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         for (int l = 0; l < LPT; ++l) {
             if (B16) {
                 if (tid + l * NT < NCH)
-                    *reinterpret_cast<f32x4 *>(smem + (slot * 64 + crow[l]) * RS + 16 * (cch[l] ^ ((crow[l] >> 2) & 2))) = gg[l];
+                    *reinterpret_cast<f32x4 *>(smem + (slot * RU + crow[l]) * RS + 16 * (cch[l] ^ ((crow[l] >> 2) & 2))) = gg[l];
             } else if (tid + l * NT < NCH) {
                 // split by truncation (x & 0xffff0000; exact residuals), two bf16 packed per dword by a byte permute
                 uint32_t hb[4], mb[4], lb[4];
@@ -160,7 +167,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                     mb[c] = __float_as_uint(r1) & 0xffff0000u;
                     lb[c] = __float_as_uint(r1 - __uint_as_float(mb[c]));
                 }
-                char *row = smem + (slot * 64 + crow[l]) * RS + 8 * (cch[l] ^ ((crow[l] >> 1) & 4));
+                char *row = smem + (slot * RU + crow[l]) * RS + 8 * (cch[l] ^ ((crow[l] >> 1) & 4));
                 *reinterpret_cast<uint2 *>(row) = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
                 *reinterpret_cast<uint2 *>(row + 64) = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
                 *reinterpret_cast<uint2 *>(row + 128) = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
@@ -168,12 +175,12 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         }
     };
     auto read_frag = [&](int slot, int rb, float4 (&aa)[NWF]) __attribute__((always_inline)) {
-        const char *row = smem + (slot * 64 + 16 * rb + r) * RS + 16 * (q ^ ((r >> 2) & 2));
+        const char *row = smem + (slot * RU + 16 * rb + r) * RS + 16 * (q ^ ((r >> 2) & 2));
 #pragma unroll
         for (int p = 0; p < NWF; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[min(t, t1 - 1)]; };
+    auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[TL * min(t, t1 - 1)]; };
 
     // positions (tile, step) of flattened step i + d; advance = next 32-channel step, then next tile
     int tc = t0, sc = 0;                 // step i   (multiplied)
@@ -214,8 +221,8 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         float4 a[2][NWF];
         read_frag(u, 0, a[0]);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            if (rb < 3) read_frag(u, rb + 1, a[(rb + 1) & 1]);
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb < RB - 1) read_frag(u, rb + 1, a[(rb + 1) & 1]);
             if (B16) {      // one plane: one MFMA per 32 channels; weights = A operand: D[col][pair]
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
@@ -245,11 +252,11 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         // -- last channel step of a tile: lane (r, q) holds columns 4q .. 4q+3 of pair r of every row block
         if (sc + 1 == ns) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const int col = 16 * (cbw + n) + 4 * q;
-                    const int row = tc * 64 + 16 * rb + r;
+                    const int row = tc * RU + 16 * rb + r;
                     if (cbw + n < ncb && (!DENSE || row < n_rows)) {
                         f32x4 o = acc[rb][n];
                         if (DENSE && bias) o += *reinterpret_cast<const f32x4 *>(bias + col);
@@ -296,43 +303,54 @@ static bool px3_wide3(int cout) {
     return on && cout % 192 == 0;
 }
 
+// Tile shape by layer.  Two 64-pair tiles per step on 128- / 96-column tiles (TL = 2) where the weight fragments dominate
+// what a step pulls through the vector L1 -- measured (MI355X, 80k scene, tools/ab_px3.py, TL 1 -> 2): 512 -> 512 at stride 8
+// 431 -> 406 us, at stride 16 231 -> 204 us, 512 -> 768 (the input gradient of 768 -> 512) 735 -> 617 us, 256 -> 384 206 ->
+// 189 us; the narrower layers lose 3-10 % (256 -> 256 183 -> 189 us, 128 -> 128 85 -> 89 us, 96 -> 96 77 -> 86 us: more rows
+// gathered per weight byte saved than their weights cost) and keep one tile per step on the 256- / 192- / 128- / 96-column tile.
+struct Px3Shape { bool w3; int nbw, tl, tn; };
+static Px3Shape px3_shape(int cin, int cout) {
+    Px3Shape p;
+    p.w3 = cout % 96 == 0 && cout % 128 != 0;
+    p.tl = (cin >= 512 || cout >= 384) ? 2 : 1;
+    if (p.tl == 2) p.nbw = 2;
+    else p.nbw = (!p.w3 && px3_wide(cout)) || (p.w3 && px3_wide3(cout)) ? 4 : 2;
+    p.tn = 16 * (p.w3 ? 3 : 4) * p.nbw;
+    return p;
+}
+
 template <bool DENSE, bool B16, int SC>
-static void px3_launch(bool w3, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
+static void px3_launch(const Px3Shape &p, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
                        const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y, const float *bias,
                        int n_rows) {
-    const size_t lds = (size_t)2 * 64 * 192;
-    if (!w3 && px3_wide(cout))
-        hipLaunchKernelGGL((conv_px3_kernel<4, 4, DENSE, B16, SC>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k,
-                           n_tiles, y, bias, n_rows);
-    else if (w3 && px3_wide3(cout))
-        hipLaunchKernelGGL((conv_px3_kernel<3, 4, DENSE, B16, SC>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k,
-                           n_tiles, y, bias, n_rows);
-    else if (w3)
-        hipLaunchKernelGGL((conv_px3_kernel<3, 2, DENSE, B16, SC>), grid, dim3(192), lds, st, in, cin, wf, cout, pair_idx, tile_k,
-                           n_tiles, y, bias, n_rows);
-    else
-        hipLaunchKernelGGL((conv_px3_kernel<4, 2, DENSE, B16, SC>), grid, dim3(256), lds, st, in, cin, wf, cout, pair_idx, tile_k,
-                           n_tiles, y, bias, n_rows);
+    const size_t lds = (size_t)2 * 64 * p.tl * 192;
+#define U2_PX3(NW_, NBW_, TL_)                                                                                                  \
+    hipLaunchKernelGGL((conv_px3_kernel<NW_, NBW_, DENSE, B16, SC, TL_>), grid, dim3(64 * NW_), lds, st, in, cin, wf, cout, pair_idx, \
+                       tile_k, n_tiles, y, bias, n_rows)
+    if (p.tl == 2) {
+        if (p.w3) U2_PX3(3, 2, 2); else U2_PX3(4, 2, 2);
+    } else if (p.nbw == 4) {
+        if (p.w3) U2_PX3(3, 4, 1); else U2_PX3(4, 4, 1);
+    } else {
+        if (p.w3) U2_PX3(3, 2, 1); else U2_PX3(4, 2, 1);
+    }
+#undef U2_PX3
 }
 
 // b16: `in` and `y` are bf16 rows, wf = the arith-3 (one bf16 plane) fragments
 int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
                     const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
-    // column tiles: 128 (4 waves x 2 blocks) or 96 (3 waves x 2 blocks: 96- and 192-column layers exactly)
-    const bool w3 = cout % 96 == 0 && cout % 128 != 0;
-    const bool wide = !w3 && px3_wide(cout);
-    const bool wide3 = w3 && px3_wide3(cout);
-    const int tn = wide3 ? 192 : w3 ? 96 : wide ? 256 : 128;
-    int64_t gx = capacity / 64;
-    const int64_t cap_x = ((wide || wide3) ? 2 : 3) * 256;   // workgroups per CU (registers), each a contiguous run of tiles
-    const int gy = (int)ceil_div(cout, tn);
+    const Px3Shape p = px3_shape(cin, cout);
+    int64_t gx = capacity / (64 * p.tl);
+    const int64_t cap_x = (p.tl == 1 && p.nbw == 2 ? 3 : 2) * 256;   // workgroups per CU (registers), each a contiguous run of units
+    const int gy = (int)ceil_div(cout, p.tn);
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (!b16) px3_launch<false, false, 32>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
-    else if (cin % 64 == 0) px3_launch<false, true, 64>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
-    else px3_launch<false, true, 32>(w3, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    if (!b16) px3_launch<false, false, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    else if (cin % 64 == 0) px3_launch<false, true, 64>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    else px3_launch<false, true, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     return check_launch(who);
 }
 
@@ -340,18 +358,15 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
 int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
                       const float *bias, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
-    const bool w3 = cout % 96 == 0 && cout % 128 != 0;
-    const bool wide = !w3 && px3_wide(cout);
-    const bool wide3 = w3 && px3_wide3(cout);
-    const int tn = wide3 ? 192 : w3 ? 96 : wide ? 256 : 128;
-    const int gy = (int)ceil_div(cout, tn);
-    int64_t gx = ceil_div(n_rows, 64);
-    const int64_t cap_x = ((wide || wide3) ? 2 : 3) * 256;
+    const Px3Shape p = px3_shape(cin, cout);
+    const int gy = (int)ceil_div(cout, p.tn);
+    int64_t gx = ceil_div(n_rows, 64 * p.tl);
+    const int64_t cap_x = (p.tl == 1 && p.nbw == 2 ? 3 : 2) * 256;
     if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (!b16) px3_launch<true, false, 32>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
-    else if (cin % 64 == 0) px3_launch<true, true, 64>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
-    else px3_launch<true, true, 32>(w3, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    if (!b16) px3_launch<true, false, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    else if (cin % 64 == 0) px3_launch<true, true, 64>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    else px3_launch<true, true, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     return check_launch(who);
 }
 

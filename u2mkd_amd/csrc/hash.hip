@@ -156,8 +156,9 @@ kmap_compact_kernel(const int32_t *__restrict__ nbr, int64_t n_out, const int32_
 }
 
 
-// ---- pair schedule: offset-grouped, 64-padded pair list + slot tables ------------------
-// One block: kbase[k] = padded prefix (each offset's pair count rounded up to 64), block bases
+// ---- pair schedule: offset-grouped, 128-padded pair list + slot tables -----------------
+// (128 = two 64-pair tiles: conv_px3_kernel multiplies two tiles of ONE offset per step, conv_px3.hip TL)
+// One block: kbase[k] = padded prefix (each offset's pair count rounded up to 128), block bases
 // in (k, block) order, tile_k for every 64-entry tile, -1 into the padding entries, and
 // meta = {P_pad, n_tiles}.  Nothing of this is read back by the host.
 __global__ void pairs_scan_kernel(const int32_t *__restrict__ nbsizes, int32_t *__restrict__ block_counts, int k_total,
@@ -166,7 +167,7 @@ __global__ void pairs_scan_kernel(const int32_t *__restrict__ nbsizes, int32_t *
     __shared__ int kbase[257];
     if (threadIdx.x == 0) {
         int acc = 0;
-        for (int k = 0; k < k_total; ++k) { kbase[k] = acc; acc += (nbsizes[k] + 63) / 64 * 64; }
+        for (int k = 0; k < k_total; ++k) { kbase[k] = acc; acc += (nbsizes[k] + 127) / 128 * 128; }
         kbase[k_total] = acc;
         meta[0] = acc;
         meta[1] = acc / 64;
@@ -370,7 +371,7 @@ int u2mkd_kmap_compact(const int32_t *nbr, int64_t n_out, int32_t k, const int32
 
 int64_t u2mkd_pairs_capacity(int64_t n_in, int64_t n_out, int32_t k) {
     int64_t m = n_in < n_out ? n_in : n_out;
-    return ((int64_t)k * m + 63) / 64 * 64 + 64 * (int64_t)k;
+    return ((int64_t)k * m + 127) / 128 * 128 + 128 * (int64_t)k;
 }
 
 int u2mkd_pairs_build(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t k, const int32_t *nbsizes,

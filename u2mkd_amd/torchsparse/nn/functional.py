@@ -497,7 +497,7 @@ class TileSchedule:
 
 class PairSchedule:
     """Offset-grouped pair list of a kernel map (u2mkd_pairs_build): every (input i, output j)
-    pair, grouped by offset and padded to 64 entries per offset.  A conv is two launches: one
+    pair, grouped by offset and padded to 128 entries per offset (two 64-pair tiles).  A conv is two launches: one
     dense MFMA stage per 64-pair tile into a scratch y (all tiles independent -- no serial
     walk), then a gather-sum over each row's <= K slots in ascending offset order
     (deterministic, no atomics).  One schedule serves the forward (gather inputs, sum per
