@@ -385,6 +385,19 @@ int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t plan
  * (`features.permute(...)` of core/models/fusion_blocks.py:241-254, tsd_full.py:482-495) as an LDS-tiled transpose      */
 int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, u2mkd_stream_t s);
 
+/* One fusion stage's camera -> LiDAR select and pseudo-feature loss (spvcnn_swiftnet18_spformer_tsd_full.py:489-498):
+ * out = fov ? gathered : pseudo (rows), loss = mean over the fov rows of (pseudo - gathered)^2 (nn.MSELoss on the
+ * boolean-indexed rows, the target detached) -- one pass forward (+ a one-workgroup merge of the per-workgroup partial
+ * sums in a fixed order), one pass backward instead of ~30 element-wise torch launches per stage.
+ * fov: uint8 [n]; partial: 2 * u2mkd_select_mse_partials() floats; stats [2] = {loss, 2 / max(count * c, 1)}.
+ * backward: d_gathered = fov ? g_out : 0 (NULL: not wanted), d_pseudo = fov ? g_loss * stats[1] * (pseudo - gathered) : g_out;
+ * g_out / g_loss NULL = zero.                                                                                         */
+int32_t u2mkd_select_mse_partials(void);
+int u2mkd_select_mse_forward(const float *gathered, const float *pseudo, const uint8_t *fov, int64_t n, int32_t c, float *out,
+                             float *partial, float *stats, u2mkd_stream_t s);
+int u2mkd_select_mse_backward(const float *g_out, const float *g_loss, const float *stats, const float *gathered,
+                              const float *pseudo, const uint8_t *fov, int64_t n, int32_t c, float *d_gathered, float *d_pseudo,
+                              u2mkd_stream_t s);
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
  * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and

@@ -47,3 +47,33 @@ def test_l2c_plan_equals_the_torch_formulation(hip, n_list, hw):
         assert live_d == live_s == int(sum(int(m.sum()) for m in masks))
         assert torch.equal(fr_h[:live_d], fr_t[:live_d]) and torch.equal(fw_h[:live_d], fw_t[:live_d])
         assert torch.equal(bp_h[:live_s], bp_t[:live_s]) and torch.equal(bw_h[:live_s], bw_t[:live_s])
+
+
+@pytest.mark.parametrize('n,c,frac', [(80000, 64, 0.4), (5003, 128, 0.9), (777, 256, 0.0), (33, 32, 1.0)])
+def test_select_and_mse_equals_the_torch_formulation(hip, n, c, frac):
+    """kd._select_and_mse (one pass forward, one backward: csrc/fusion.hip) against torch.where + the masked MSE written with
+    torch operators (tsd_full.py:489-498): the selected rows are EQUAL, the loss and the three gradients agree to fp32
+    rounding of a sum over the rows; with no point in view the loss is 0 and only the select's gradient flows."""
+    from u2mkd_amd import kd
+    g = torch.Generator().manual_seed(n)
+    gathered = torch.randn(n, c, generator=g).cuda().requires_grad_(True)
+    pseudo = torch.randn(n, c, generator=g).cuda().requires_grad_(True)
+    fov = (torch.rand(n, generator=g) < frac).cuda()
+    w_out = torch.randn(n, c, generator=g).cuda()
+
+    def ref(gat, pse):
+        out = torch.where(fov.unsqueeze(1), gat, pse)
+        return out, kd._masked_mse(pse.double(), out.detach().double(), fov)
+    o1, l1 = kd._select_and_mse(gathered, pseudo, fov)
+    ((o1 * w_out).sum() + 3.0 * l1).backward()
+    g1 = gathered.grad.clone(), pseudo.grad.clone()
+    gathered.grad = pseudo.grad = None
+    o2, l2 = ref(gathered, pseudo)
+    ((o2 * w_out).sum() + 3.0 * l2.float()).backward()
+    assert torch.equal(o1, o2)
+    assert abs(float(l1) - float(l2)) <= 2e-6 * max(1.0, abs(float(l2)))
+    assert torch.equal(g1[0], gathered.grad)
+    assert float((g1[1] - pseudo.grad).abs().max()) <= 2e-6 * max(1e-6, float(pseudo.grad.abs().max()))
+    # reproducible: the partial sums are merged in workgroup order
+    o3, l3 = kd._select_and_mse(gathered.detach(), pseudo.detach(), fov)
+    assert torch.equal(l1.detach(), l3)

@@ -37,6 +37,8 @@ class Census(TorchDispatchMode):
         super().__init__()
         self.fwd = collections.Counter()
         self.bwd = collections.Counter()
+        self.fwd_b = collections.Counter()       # bytes touched (inputs + outputs on the device): a proxy for the kernel time
+        self.bwd_b = collections.Counter()
         self.calls = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -47,9 +49,12 @@ class Census(TorchDispatchMode):
         flat = [a for a in (list(args) + list((kwargs or {}).values()) + (list(out) if isinstance(out, (tuple, list)) else [out])) if isinstance(a, torch.Tensor)]
         if not any(t.is_cuda for t in flat):
             return out
+        nbytes = sum(t.numel() * t.element_size() for t in flat if t.is_cuda)
         node = torch._C._current_autograd_node()
         if node is None:
-            self.fwd[(site_of(traceback.extract_stack(limit=40)), name)] += 1
+            key = (site_of(traceback.extract_stack(limit=40)), name)
+            self.fwd[key] += 1
+            self.fwd_b[key] += nbytes
         else:
             tb = node.metadata.get('traceback_', None)
             where = '?'
@@ -59,7 +64,9 @@ class Census(TorchDispatchMode):
                         f = line.strip().split('\n')[0]
                         where = f.split('/u2mkd_amd/')[-1].replace('", line ', ':').replace(', in ', ' ')
                         break
-            self.bwd[(where, node.name().split('::')[-1][:36], name)] += 1
+            key = (where, node.name().split('::')[-1][:36], name)
+            self.bwd[key] += 1
+            self.bwd_b[key] += nbytes
         return out
 
 
@@ -91,6 +98,12 @@ for (s, o), v in sorted(c.fwd.items(), key=lambda kv: -kv[1])[:120]:
 print('--- backward, by (forward site of the node, node, op)')
 for (s, nd, o), v in sorted(c.bwd.items(), key=lambda kv: -kv[1])[:120]:
     print('%5d  %-60s %-36s %s' % (v, s, nd, o))
+print('--- by bytes touched (MB per step): forward')
+for (s, o), v in sorted(c.fwd_b.items(), key=lambda kv: -kv[1])[:45]:
+    print('%8.1f MB %4d  %-66s %s' % (v / 1e6, c.fwd[(s, o)], s, o))
+print('--- by bytes touched (MB per step): backward')
+for (s, nd, o), v in sorted(c.bwd_b.items(), key=lambda kv: -kv[1])[:45]:
+    print('%8.1f MB %4d  %-56s %-34s %s' % (v / 1e6, c.bwd[(s, nd, o)], s, nd, o))
 print('--- C-ABI entry points')
 for k, v in hip.most_common(60):
     print('%5d  %s' % (v, k))

@@ -102,6 +102,9 @@ SIGNATURES = {
     'u2mkd_bn_backward_local_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_apply_bf16': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_sptr_window_keys': (C.c_int, [_p, _p, _i64, _p, _p, _f32, _f32, _f32, _p, _p]),
+    'u2mkd_select_mse_partials': (_i32, []),
+    'u2mkd_select_mse_forward': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    'u2mkd_select_mse_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     'u2mkd_sptr_plan_prepare_workspace_bytes': (_sz, []),
     'u2mkd_sptr_plan_prepare': (C.c_int, [_p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
     'u2mkd_sptr_window_ranges': (C.c_int, [_p, _i64, _p, _p, _p]),

@@ -111,6 +111,75 @@ l2c_finish_kernel(const int32_t *__restrict__ order_d, const int32_t *__restrict
 
 using namespace u2mkd;
 
+// ---- camera -> LiDAR select + pseudo-feature MSE of one fusion stage (tsd_full.py:489-498) -----------------------------
+// img_feat = where(fov, gathered, pseudo); mse = MSELoss()(pseudo[fov], gathered[fov].detach()) -- in torch: a where, and
+// sub / pow / mul / two sums / clamp / div for the loss, ~20 more element-wise launches in the backward, four stages per
+// step, every one a pass over [N, C].  Here: one forward pass (the selected rows + per-workgroup partial sums of the
+// squared differences, merged in workgroup order by a one-workgroup kernel: reproducible), one backward pass.
+constexpr int kSelWg = 512;        // workgroups of the forward at most (= partial sums the finish kernel merges)
+
+__global__ void __launch_bounds__(256)
+select_mse_fwd_kernel(const float *__restrict__ gathered, const float *__restrict__ pseudo, const uint8_t *__restrict__ fov,
+                      int64_t n, int c4, float *__restrict__ out, float *__restrict__ partial /*[grid][2]*/) {
+    float sq = 0.f, cnt = 0.f;
+    const int64_t total = n * c4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / c4;
+        const bool m = fov[row] != 0;
+        const float4 g = reinterpret_cast<const float4 *>(gathered)[e], p = reinterpret_cast<const float4 *>(pseudo)[e];
+        reinterpret_cast<float4 *>(out)[e] = m ? g : p;
+        if (m) {
+            const float dx = p.x - g.x, dy = p.y - g.y, dz = p.z - g.z, dw = p.w - g.w;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            if (e - row * c4 == 0) cnt += 1.f;
+        }
+    }
+    __shared__ float red[4][2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sq += __shfl_xor(sq, off); cnt += __shfl_xor(cnt, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sq; red[threadIdx.x >> 6][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partial[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+// loss = sum / max(count * C, 1);  stats = {loss, 2 / max(count * C, 1)} (the backward's factor)
+__global__ void __launch_bounds__(64)
+select_mse_finish_kernel(const float *__restrict__ partial, int g, int c, float *__restrict__ stats) {
+    double sq = 0.0, cnt = 0.0;
+    for (int i = threadIdx.x; i < g; i += 64) { sq += partial[2 * i]; cnt += partial[2 * i + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sq += __shfl_xor(sq, off); cnt += __shfl_xor(cnt, off); }
+    if (threadIdx.x == 0) {
+        const double den = cnt * c < 1.0 ? 1.0 : cnt * c;
+        stats[0] = (float)(sq / den);
+        stats[1] = (float)(2.0 / den);
+    }
+}
+
+// d_gathered = fov ? g_out : 0;  d_pseudo = fov ? g_loss * (2 / den) * (pseudo - gathered) : g_out
+__global__ void __launch_bounds__(256)
+select_mse_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ g_loss, const float *__restrict__ stats,
+                      const float *__restrict__ gathered, const float *__restrict__ pseudo, const uint8_t *__restrict__ fov,
+                      int64_t n, int c4, float *__restrict__ d_gathered, float *__restrict__ d_pseudo) {
+    const int64_t total = n * c4;
+    const float k = (g_loss ? g_loss[0] : 0.f) * stats[1];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool m = fov[e / c4] != 0;
+        const float4 go = g_out ? reinterpret_cast<const float4 *>(g_out)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), dp = go;
+        if (m) {
+            const float4 g = reinterpret_cast<const float4 *>(gathered)[e], p = reinterpret_cast<const float4 *>(pseudo)[e];
+            dg = go;
+            dp = make_float4(k * (p.x - g.x), k * (p.y - g.y), k * (p.z - g.z), k * (p.w - g.w));
+        }
+        if (d_gathered) reinterpret_cast<float4 *>(d_gathered)[e] = dg;
+        reinterpret_cast<float4 *>(d_pseudo)[e] = dp;
+    }
+}
+
 extern "C" {
 
 int u2mkd_c2l_plan(const float *pixel_coords, const uint8_t *mask, int32_t ncam, int64_t n, int32_t sample, int32_t h,
@@ -145,6 +214,33 @@ int u2mkd_l2c_finish(const int32_t *order_d, const int32_t *seg_d, const int32_t
     hipLaunchKernelGGL(l2c_finish_kernel, dim3((unsigned)ceil_div(n_entries, kFuThreads)), dim3(kFuThreads), 0, as_stream(s),
                        order_d, seg_d, order_s, pix, row, n_entries, fwd_row, fwd_w, bwd_pix, bwd_w);
     return check_launch("u2mkd_l2c_finish");
+}
+
+
+int32_t u2mkd_select_mse_partials(void) { return kSelWg; }
+
+int u2mkd_select_mse_forward(const float *gathered, const float *pseudo, const uint8_t *fov, int64_t n, int32_t c, float *out,
+                             float *partial, float *stats, u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0, "u2mkd_select_mse_forward: %d channels, need a positive multiple of 4", c);
+    U2_REQUIRE(stats && partial, "u2mkd_select_mse_forward: null pointer");
+    int g = n > 0 ? (int)(ceil_div(n * (c / 4), 256) < kSelWg ? ceil_div(n * (c / 4), 256) : kSelWg) : 0;
+    if (g > 0) {
+        U2_REQUIRE(gathered && pseudo && fov && out, "u2mkd_select_mse_forward: null pointer");
+        hipLaunchKernelGGL(select_mse_fwd_kernel, dim3(g), dim3(256), 0, as_stream(s), gathered, pseudo, fov, n, c / 4, out, partial);
+    }
+    hipLaunchKernelGGL(select_mse_finish_kernel, dim3(1), dim3(64), 0, as_stream(s), partial, g, c, stats);
+    return check_launch("u2mkd_select_mse_forward");
+}
+
+int u2mkd_select_mse_backward(const float *g_out, const float *g_loss, const float *stats, const float *gathered,
+                              const float *pseudo, const uint8_t *fov, int64_t n, int32_t c, float *d_gathered, float *d_pseudo,
+                              u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(c > 0 && c % 4 == 0 && stats && gathered && pseudo && fov && d_pseudo, "u2mkd_select_mse_backward: bad arguments");
+    const int g = (int)(ceil_div(n * (c / 4), 256) < 2048 ? ceil_div(n * (c / 4), 256) : 2048);
+    hipLaunchKernelGGL(select_mse_bwd_kernel, dim3(g), dim3(256), 0, as_stream(s), g_out, g_loss, stats, gathered, pseudo, fov, n,
+                       c / 4, d_gathered, d_pseudo);
+    return check_launch("u2mkd_select_mse_backward");
 }
 
 }  // extern "C"

@@ -198,8 +198,8 @@ class StudentMSP2IFM(nn.Module):
             # learner's pseudo image feature (not detached), the MSE target is detached (Appendix C-5)
             img_feat_tensor = c2l_gather(skip.view(ib, ncam, ifc, ifh, ifw), pixel_coordinates, masks)
             pseudo = self.learner[idx](pts_feat.F)
-            img_feat_tensor = torch.where(fov_mask.unsqueeze(1), img_feat_tensor, pseudo)
-            mse_loss.append(_masked_mse(pseudo, img_feat_tensor.detach(), fov_mask))
+            img_feat_tensor, mse = _select_and_mse(img_feat_tensor, pseudo, fov_mask)
+            mse_loss.append(mse)
             pts_feat.F = self.c2l_fusion_blocks[idx](pts_feat.F, img_feat_tensor)
             vox_feats.append(point_to_voxel(vox_out, pts_feat))
 
@@ -255,6 +255,49 @@ class StudentMSP2IFM(nn.Module):
             join(x_pix)
             ret['x_pix'] = x_pix
         return ret
+
+
+class _SelectMSE(torch.autograd.Function):
+    """(where(fov, gathered, pseudo), MSELoss()(pseudo[fov], gathered[fov].detach())) of one fusion stage in one pass
+    each way (csrc/fusion.hip: u2mkd_select_mse_forward / _backward); the torch formulation below is ~30 element-wise
+    launches per stage over [N, C]."""
+
+    @staticmethod
+    def forward(ctx, gathered, pseudo, fov):
+        from . import _lib as L
+        n, c = pseudo.shape
+        gathered, pseudo = gathered.contiguous(), pseudo.contiguous()
+        fov8 = fov.contiguous().view(torch.uint8)
+        out = torch.empty_like(pseudo)
+        partial = torch.empty(2 * L.load().u2mkd_select_mse_partials(), dtype=torch.float32, device=pseudo.device)
+        stats = torch.empty(2, dtype=torch.float32, device=pseudo.device)
+        L.call('u2mkd_select_mse_forward', L.ptr(gathered), L.ptr(pseudo), L.ptr(fov8), n, c, L.ptr(out), L.ptr(partial),
+               L.ptr(stats), L.stream())
+        ctx.save_for_backward(gathered, pseudo, fov8, stats)
+        return out, stats[0]
+
+    @staticmethod
+    def backward(ctx, g_out, g_loss):
+        from . import _lib as L
+        gathered, pseudo, fov8, stats = ctx.saved_tensors
+        n, c = pseudo.shape
+        g_out = g_out.contiguous() if g_out is not None else None
+        g_loss = g_loss.contiguous().float() if g_loss is not None else None
+        d_g = torch.empty_like(gathered) if ctx.needs_input_grad[0] else None
+        d_p = torch.empty_like(pseudo)
+        L.call('u2mkd_select_mse_backward', L.ptr(g_out), L.ptr(g_loss), L.ptr(stats), L.ptr(gathered), L.ptr(pseudo),
+               L.ptr(fov8), n, c, L.ptr(d_g), L.ptr(d_p), L.stream())
+        return d_g, d_p, None
+
+
+def _select_and_mse(gathered, pseudo, fov):
+    """(img_feat_tensor, mse) of tsd_full.py:489-498: the learner's pseudo feature where no camera sees the point, and the
+    MSE between pseudo feature and (detached) gathered feature over the points a camera does see."""
+    if (pseudo.is_cuda and pseudo.dtype == torch.float32 and gathered.dtype == torch.float32 and pseudo.shape[1] % 4 == 0
+            and fov.dtype == torch.bool and not torch.is_autocast_enabled()):
+        return _SelectMSE.apply(gathered, pseudo, fov)
+    out = torch.where(fov.unsqueeze(1), gathered, pseudo)
+    return out, _masked_mse(pseudo, out.detach(), fov)
 
 
 def _masked_mse(a, b, mask):

@@ -30,6 +30,10 @@ def cart2sphere(xyz):
     return torch.stack([theta, beta, r], -1)
 
 
+_cart2sphere_torch = cart2sphere       # (a caller that substitutes `cart2sphere` -- the CPU-libm fixture of tests/test_kd_path.py --
+                                       # gets its function: the fused plan preparation stands in for THIS formulation only)
+
+
 class DropPath(nn.Module):
     """Stochastic depth over dim 0 (timm.models.layers.DropPath, as the reference uses it)."""
 
@@ -42,7 +46,7 @@ class DropPath(nn.Module):
             return x
         keep = 1 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return x * (mask / keep)              # (one pass over x, forward and backward; timm: x.div(keep) * mask)
 
 
 class Mlp(nn.Module):
@@ -103,7 +107,7 @@ class SparseMultiheadSASphereConcat(nn.Module):
         qkv = self.qkv(feats).reshape(N, 3, self.num_heads, C // self.num_heads)
         h1 = self.num_heads_brc1
         xyz = xyz.float()
-        if xyz.is_cuda:
+        if xyz.is_cuda and cart2sphere is _cart2sphere_torch:
             plan, plan_s, xyz_sphere = sptr.WindowPlan.pair(xyz, batch, self.window_size, self.window_size_sphere)
         else:
             xyz_sphere = cart2sphere(xyz)
