@@ -179,7 +179,7 @@ def kd_inputs(b):
 FIRST_KD_SEEDS = (78, 79, 80, 82, 85, 86)
 
 
-def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True, seeds=(77,)):
+def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True, seeds=(77,), batches=None):
     """The reference's own SPVCNN_SWIFTNET18_SPFORMER_TSD_FULL (student + teacher) and the KD loss
     arithmetic of NuScenesLCTSDFullTrainer._run_step, on CPU over the oracle operators.  (cr, cr_t) =
     (1.0, 1.0): the first fixture; (1.0, 2.0) = configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:32-43
@@ -202,9 +202,10 @@ def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write
     # fixture scene: the first candidate seed whose student / teacher outputs do not move when the quantiser inputs
     # move by +-4 ulp (one candidate = the seed is taken as it is: the round-2 fixtures at the shipped widths, which
     # hold the strict gate on the GPU)
-    for seed in seeds:
-        b = synth_kd_batch(n_vox, 2, seed=seed, image_hw=(64, 112))
-        if len(seeds) == 1:
+    # ``batches``: [(seed, numpy KD batch)] candidates from another source (the loader-fed fixture) instead of synth scenes
+    for seed in (seeds if batches is None else [sd for sd, _ in batches]):
+        b = synth_kd_batch(n_vox, 2, seed=seed, image_hw=(64, 112)) if batches is None else dict(batches)[seed]
+        if batches is None and len(seeds) == 1:
             break
 
         def probe(k):
@@ -359,6 +360,27 @@ def make_kd_eval_golden():
         outputs_vox=torch.cat(o_vox).numpy(), outputs_pix=torch.cat(o_pix).numpy(), outputs_vox_t=torch.cat(o_t).numpy())
     print('kd eval golden: points', len(f['s_inverse_map']), 'teacher points', len(inv_t))
 
+def make_loader_kd_golden():
+    """Row f1 end to end: the batch comes from u2mkd_amd/data/nuscenes_lc.py (the synthetic on-disk tree of
+    tests/nusc_tree.py: validation split, two samples, six cameras, images at 72 x 128, no augmentation -> the same bytes in
+    the GPU test), the expected outputs from the reference's own KD model class at small widths (cr = cr_t = 0.5).  The
+    tree's seed is the first of 0, 1, ... whose scene keeps every token 4 ulp away from the quantiser edges -- a CPU-only
+    criterion, no implementation output is consulted."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from nusc_tree import build_tree
+    from u2mkd_amd.data import nuscenes_lc as D
+    _, _Crit = import_reference()
+    import_reference_spformer(0.5)
+    cands = []
+    for tree_seed in range(4):
+        with tempfile.TemporaryDirectory() as root:
+            root, ver = build_tree(root, seed=tree_seed)
+            ds = D.LCNuScenesDataset(D.NuScenesTables(root, ver), split='val', im_cr=0.08)
+            cands.append((tree_seed, D.collated_to_kd_batch(D.collate_fn([ds[0], ds[1]]))))
+    make_kd_golden(_Crit(ignore_index=0), cr=0.5, cr_t=0.5, tag='kd_loader_cr05', write_keys=False, batches=cands)
+
+
 def main_kd_widths():
     """Only the KD fixtures at the shipped widths (`python tests/golden/make_golden.py kd`)."""
     _, MixLovaszCrossEntropy = import_reference()
@@ -377,6 +399,8 @@ if __name__ == '__main__':
         make_kd_golden(_Crit(ignore_index=0), seeds=FIRST_KD_SEEDS)
     elif len(sys.argv) > 1 and sys.argv[1] == 'kd_eval':
         make_kd_eval_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'kd_loader':
+        make_loader_kd_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'teacher_ms':
         make_teacher_multisweep_golden()
     else:
@@ -384,3 +408,4 @@ if __name__ == '__main__':
         main_kd_widths()
         make_teacher_multisweep_golden()
         make_kd_eval_golden()
+        make_loader_kd_golden()

@@ -11,23 +11,7 @@ import torch
 from u2mkd_amd.data import nuscenes_lc as D
 from u2mkd_amd.torchsparse import SparseTensor
 
-CAMS = D.CAM_CHANNELS
-YAW = {'CAM_FRONT_LEFT': 55.0, 'CAM_FRONT': 0.0, 'CAM_FRONT_RIGHT': -55.0, 'CAM_BACK_LEFT': 110.0, 'CAM_BACK': 180.0,
-       'CAM_BACK_RIGHT': -110.0}
-K_CAM = [[1266.0, 0.0, 816.0], [0.0, 1266.0, 491.0], [0.0, 0.0, 1.0]]
-
-
-def _quat_from_matrix(m):
-    from scipy.spatial.transform import Rotation
-    x, y, z, w = Rotation.from_matrix(m).as_quat()
-    return [float(w), float(x), float(y), float(z)]
-
-
-def _cam_rotation(yaw_deg):
-    """camera axes (x right, y down, z forward) in the ego frame (x forward, y left, z up), yawed."""
-    a = np.deg2rad(yaw_deg)
-    fwd = np.array([np.cos(a), np.sin(a), 0.0]); left = np.array([-np.sin(a), np.cos(a), 0.0]); up = np.array([0, 0, 1.0])
-    return np.stack([-left, -up, fwd], axis=1)       # columns = camera axes in ego coordinates
+from nusc_tree import CAMS, K_CAM, YAW, build_tree   # noqa: E402  (tests/ is on sys.path: conftest)
 
 
 def _points_seen(feed_dict_s, n):
@@ -46,70 +30,7 @@ def _points_seen(feed_dict_s, n):
 
 @pytest.fixture(scope='module')
 def tree(tmp_path_factory):
-    from PIL import Image
-    root = str(tmp_path_factory.mktemp('nusc'))
-    ver = 'v1.0-mini'
-    os.makedirs(os.path.join(root, ver)); os.makedirs(os.path.join(root, 'samples')); os.makedirs(os.path.join(root, 'sweeps'))
-    os.makedirs(os.path.join(root, 'lidarseg'))
-    rng = np.random.default_rng(0)
-    sensor = [{'token': 's_lidar', 'channel': 'LIDAR_TOP', 'modality': 'lidar'}] + \
-             [{'token': 's_' + c, 'channel': c, 'modality': 'camera'} for c in CAMS]
-    calib = [{'token': 'cs_lidar', 'sensor_token': 's_lidar', 'translation': [0.9, 0.0, 1.8],
-              'rotation': _quat_from_matrix(np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])), 'camera_intrinsic': []}]
-    for c in CAMS:
-        calib.append({'token': 'cs_' + c, 'sensor_token': 's_' + c, 'translation': [1.5, 0.1, 1.5],
-                      'rotation': _quat_from_matrix(_cam_rotation(YAW[c])), 'camera_intrinsic': K_CAM})
-    sample, sample_data, ego_pose, lidarseg = [], [], [], []
-
-    def pose(tok, t, yaw):
-        a = np.deg2rad(yaw)
-        m = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
-        ego_pose.append({'token': tok, 'translation': [100.0 + 5 * t, 50.0 + 0.5 * t, 0.0], 'rotation': _quat_from_matrix(m),
-                         'timestamp': int(1e6 * (1000 + t))})
-
-    def sweep_file(name, n):
-        p = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(-2, 3, (n, 1)), rng.uniform(0, 255, (n, 1)),
-                            np.zeros((n, 1))], 1).astype(np.float32)
-        p.tofile(os.path.join(root, name))
-        return p
-
-    lidar_chain = []
-    for s in range(2):
-        stok = f'sample{s}'
-        sample.append({'token': stok, 'timestamp': int(1e6 * (1000 + s)), 'scene_token': 'scene0'})
-        # key-frame sweep + two intermediate sweeps after it
-        for j in range(3):
-            tok = f'sd_lidar_{s}_{j}'
-            t = s + j * 0.3
-            pose('pose_' + tok, t, 3.0 * t)
-            folder = 'samples' if j == 0 else 'sweeps'
-            fn = f'{folder}/lidar_{s}_{j}.bin'
-            sweep_file(fn, 4000 if j == 0 else 1500)
-            sample_data.append({'token': tok, 'sample_token': stok, 'ego_pose_token': 'pose_' + tok,
-                                'calibrated_sensor_token': 'cs_lidar', 'filename': fn, 'is_key_frame': j == 0,
-                                'timestamp': int(1e6 * (1000 + t)), 'prev': '', 'next': ''})
-            lidar_chain.append(tok)
-            if j == 0:
-                lab = rng.integers(0, 32, 4000).astype(np.uint8)
-                lfn = f'lidarseg/{tok}_lidarseg.bin'
-                lab.tofile(os.path.join(root, lfn))
-                lidarseg.append({'token': 'ls_' + tok, 'sample_data_token': tok, 'filename': lfn})
-        for c in CAMS:
-            tok = f'sd_{c}_{s}'
-            pose('pose_' + tok, s + 0.02, 3.0 * s + 0.1)
-            fn = f'samples/{c}_{s}.png'
-            Image.fromarray(rng.integers(0, 255, (900, 1600, 3), dtype=np.uint8)).save(os.path.join(root, fn))
-            sample_data.append({'token': tok, 'sample_token': stok, 'ego_pose_token': 'pose_' + tok,
-                                'calibrated_sensor_token': 'cs_' + c, 'filename': fn, 'is_key_frame': True,
-                                'timestamp': int(1e6 * (1000 + s + 0.02)), 'prev': '', 'next': ''})
-    by = {r['token']: r for r in sample_data}
-    for a, b in zip(lidar_chain[:-1], lidar_chain[1:]):
-        by[a]['next'], by[b]['prev'] = b, a
-    for name, rows in (('sample', sample), ('sample_data', sample_data), ('ego_pose', ego_pose),
-                       ('calibrated_sensor', calib), ('sensor', sensor), ('lidarseg', lidarseg)):
-        with open(os.path.join(root, ver, name + '.json'), 'w') as f:
-            json.dump(rows, f)
-    return root, ver
+    return build_tree(str(tmp_path_factory.mktemp('nusc')))
 
 
 def test_quaternion_and_transform_match_scipy():
@@ -247,3 +168,61 @@ def test_loader_batch_drives_a_kd_step_on_the_gpu(tree):
     losses = [float(run(batch)) for _ in range(2)]
     assert all(np.isfinite(losses))
     assert all(p.grad is not None for p in model.model_s.parameters())
+
+
+def test_loader_equals_the_plain_loop_oracle(tree):
+    """u2mkd_amd/data/nuscenes_lc.py against oracle/loader_ref.py (point-by-point scalar restatement of
+    core/datasets/lc_semantic_nusc_tsd_full.py:241-310, 344-387, 464-486) on the synthetic tree: aggregated sweeps, the
+    camera projection with its masks, and the collate rules."""
+    from oracle import loader_ref as LR
+    root, ver = tree
+    tb = D.NuScenesTables(root, ver)
+    rt = LR.load_tables(root, ver)
+    # ---- sweep aggregation: key frame 0 (no previous sweep: all 2 * nsweeps from `next`) and key frame 1 (two of each)
+    ds = D.LCNuScenesDataset(tb, split='val', im_cr=0.1, multisweeps=2, only_past=False)
+    for s_idx in (0, 1):
+        for only_past in (False, True):
+            got_p, got_t = ds._aggregate_lidar_sweeps(ds.sample[s_idx], 2, only_past)
+            want_p, want_t = LR.aggregate_sweeps(rt, root, rt['sample'][f'sample{s_idx}'], 2, only_past)
+            got_p = np.concatenate(got_p) if got_p else np.zeros((0, 4))
+            got_t = np.concatenate(got_t) if got_t else np.zeros(0)
+            assert got_p.shape == want_p.shape and got_p.shape[0] == (0 if (only_past and s_idx == 0) else got_p.shape[0])
+            assert np.allclose(got_p, want_p, rtol=0, atol=1e-9) and np.allclose(got_t, want_t, rtol=0, atol=1e-12)
+    assert LR.aggregate_sweeps(rt, root, rt['sample']['sample1'], 2, False)[0].shape[0] > 4000
+    # ---- projection of the kept point of every voxel, all six cameras
+    ds = D.LCNuScenesDataset(tb, split='val', im_cr=0.1)
+    it = ds[1]
+    s = it['feed_dict_s']
+    pts = np.fromfile(os.path.join(root, 'samples/lidar_1_0.bin'), dtype=np.float32).reshape(-1, 5)[:, :3]
+    inds = s['inds'][0]
+    pix, masks, valid = LR.project_points(rt, rt['sample']['sample1'], pts[inds], D.CAM_CHANNELS)
+    assert np.array_equal(s['masks'], masks) and masks.sum() > 100
+    finite = np.isfinite(pix).all(-1)
+    assert np.array_equal(np.isfinite(s['pixel_coordinates']).all(-1), finite)
+    # (a point next to the camera plane projects to ~1e6: relative there, absolute inside the images)
+    assert np.allclose(s['pixel_coordinates'][finite], pix[finite], rtol=1e-8, atol=1e-9)
+    assert np.allclose(s['pixel_coordinates'][masks], pix[masks], rtol=0, atol=1e-9)
+    assert np.array_equal(s['fov_mask'].F, valid != -1)
+    # ---- collate
+    items = [ds[0], it]
+    got = D.collate_fn(items)
+    want = LR.collate(items, lambda x: isinstance(x, SparseTensor), lambda x: (x.F, x.C))
+
+    def same(a, b, path):
+        if isinstance(b, tuple):                       # a collated SparseTensor: (feats, coords + batch column)
+            assert torch.equal(torch.as_tensor(a.F), b[0]) and torch.equal(torch.as_tensor(a.C).int(), b[1]), path
+        elif isinstance(b, dict):
+            assert set(a) == set(b), path
+            for k in b:
+                same(a[k], b[k], path + '/' + k)
+        elif isinstance(b, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, '%s[%d]' % (path, i))
+        elif isinstance(b, torch.Tensor):
+            assert a.dtype == b.dtype and torch.equal(a, b), path
+        elif isinstance(b, np.ndarray):
+            assert np.array_equal(a, b), path
+        else:
+            assert a == b, path
+    same(got, want, '')
