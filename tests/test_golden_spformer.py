@@ -19,6 +19,14 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 BLK = 'transformer_blocks.1.attn.'
 
 
+# L2-relative bound of the sampled parameter gradients against the fp32 CPU golden.  Measured on MI355X: 2.2e-3 .. 5.3e-3.  The
+# convolution-only network is held to 1e-3 against an fp64 arbiter (tests/grad_arbiter.py); the attention path has none:
+# the reference's sptr operators force fp32 (spherical_transformer.py:221-244), so the CPU golden itself carries fp32
+# rounding of the same size as the HIP evaluation's -- two fp32 evaluations are compared here, at a bound 2x the
+# worst measurement.
+GRAD_GATE = 1.2e-2
+
+
 def _inputs():
     b = synth_batch(2000, 2, seed=33)
     return tuple(torch.from_numpy(b[k]) for k in ('feats', 'coords', 'labels'))
@@ -81,4 +89,6 @@ def test_hip_spformer_matches_reference_golden(hip):
     for name, key in ((BLK + 'relative_pos_query_table', 'grad_tq'),
                       (BLK + 'relative_pos_value_table_sphere', 'grad_tv_sphere'), (BLK + 'qkv.weight', 'grad_qkv')):
         a, b = g[name].grad.cpu().double(), torch.from_numpy(gold[key]).double()
-        assert float((a - b).norm() / b.norm()) < 2e-2, name
+        rel = float((a - b).norm() / b.norm())
+        print('SPFORMER-GRAD', name, '%.3e' % rel)
+        assert rel < GRAD_GATE, name

@@ -18,6 +18,14 @@ from u2mkd_amd.synth import synth_batch
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
+# L2-relative bound of the sampled parameter gradients against the fp32 CPU golden.  Measured on MI355X: 3e-7 .. 6.2e-3.  The
+# convolution-only network is held to 1e-3 against an fp64 arbiter (tests/grad_arbiter.py); the attention path has none:
+# the reference's sptr operators force fp32 (spherical_transformer.py:221-244), so the CPU golden itself carries fp32
+# rounding of the same size as the HIP evaluation's -- two fp32 evaluations are compared here, at a bound 2x the
+# worst measurement.
+GRAD_GATE = 1.2e-2
+
+
 def _inputs():
     # the seed make_golden.py settled on: the first one whose logits do not move when SphereFormer's atan2-derived
     # angles are shifted by +-4 units in the last place (CPU and GPU libm differ there), i.e. no token sits within 4 ulp
@@ -55,7 +63,7 @@ def _hip_model():
 @pytest.mark.gpu
 def test_hip_teacher_step_matches_the_reference_golden(hip):
     """forward logits <= 1e-3, the MASKED loss through train.LidarStep (the product's stage-1 driver) <= 1e-3, sampled
-    gradients within the L2-relative bound the fp32-vs-fp32 comparisons of this suite use"""
+    gradients within GRAD_GATE (two fp32 evaluations of the attention path: see its comment)"""
     from u2mkd_amd import torchsparse as ts, train as T
     gold = _gold()
     feats, coords, labels, kf = (t.cuda() for t in _inputs())
@@ -74,7 +82,9 @@ def test_hip_teacher_step_matches_the_reference_golden(hip):
         a = g[name].grad.cpu().double()
         a = a[sl] if sl is not None else a
         b = torch.from_numpy(gold[key]).double()
-        assert float((a - b).norm() / b.norm()) < 2e-2, name
+        rel = float((a - b).norm() / b.norm())
+        print('TEACHER-MS-GRAD', name, '%.3e' % rel)
+        assert rel < GRAD_GATE, name
     # rows outside the key frame receive no loss gradient: the classifier's input gradient is zero there
     out2 = model({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
     out2.retain_grad()
