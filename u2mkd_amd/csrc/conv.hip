@@ -689,11 +689,9 @@ wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__rest
 }
 
 static int wgrad_g_target(int64_t n_rows, int k) {
-    static const int scale = getenv("U2MKD_WGRAD_GSCALE") ? atoi(getenv("U2MKD_WGRAD_GSCALE")) : 2;   // tuning knob (measured: 2 helps the <= 32k-voxel levels 5-10 %)
-    int64_t g = (n_rows * (k < 8 ? k : 8) * scale + 511) / 512;
+    int64_t g = (n_rows * (k < 8 ? k : 8) * 2 + 511) / 512;      // (x 2: measured 5-10 % on the <= 32k-voxel levels)
     if (g < 32) g = 32;
-    static const int gmax = getenv("U2MKD_WGRAD_GMAX") ? atoi(getenv("U2MKD_WGRAD_GMAX")) : 1024;   // 4 workgroups per CU
-    if (g > gmax) g = gmax;
+    if (g > 1024) g = 1024;                                       // 4 workgroups per CU
     return (int)g;
 }
 
@@ -1276,11 +1274,9 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     const int g = wgrad_g_target(n_rows, k) + k;
     U2_REQUIRE(workspace_bytes >= (size_t)g * ca * cb * sizeof(float), "u2mkd_conv_wgrad_pairs: workspace too small");
     hipStream_t st = as_stream(s);
-    // bf16x3 form (conv_wgrad_x3.hip, 64 x 64-channel tiles): U2MKD_WGRAD_X3 = 0 off, 1 the 64 x 64 shape only,
-    // 2 (default) every multiple of 64, 3 every shape of at least 32 x 32 channels (partial tiles masked)
-    static const int x3_mode = getenv("U2MKD_WGRAD_X3") ? atoi(getenv("U2MKD_WGRAD_X3")) : 2;
-    const bool x3_shape = x3_mode == 3 ? (ca >= 32 && cb >= 32) : x3_mode == 2 ? (ca % 64 == 0 && cb % 64 == 0) : (ca == 64 && cb == 64);
-    if (x3_mode > 0 && x3_shape && (b16 || conv_tp_arith(0) == 2) && conv_wgrad_x3_supported(ca, cb, k)) {
+    // bf16x3 form (conv_wgrad_x3.hip, 64 x 64-channel tiles) for every shape whose channel counts are multiples of 64
+    const bool x3_shape = ca % 64 == 0 && cb % 64 == 0;
+    if (x3_shape && (b16 || conv_tp_arith(0) == 2) && conv_wgrad_x3_supported(ca, cb, k)) {
         // (bf16 rows: the same kernel without the split -- one plane, one MFMA per product)
         int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st, b16);
         if (rc) return rc;
@@ -1296,11 +1292,9 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     dim3 grid(g, tiles_a * tiles_b);
     float *slabs = reinterpret_cast<float *>(workspace);
     // pairs staged per step: fewer pairs = less LDS = more resident workgroups per CU to hide the
-    // gather latency.  Measured (tools/ab_conv.py, U2MKD_WGRAD_CP sweep): 128-wide tiles 16 > 32 > 64
+    // gather latency.  Measured (tools/ab_conv.py): 128-wide tiles 16 > 32 > 64 pairs per step
     // (256x256 at stride 8: 197 / 228 / 333 us), 32/64-wide tiles best at 32.
-    int cp = (wm >= 3 || wn >= 3) ? 16 : 32;
-    if (const char *e = getenv("U2MKD_WGRAD_CP")) cp = atoi(e);
-    U2_REQUIRE(cp == 16 || cp == 32, "u2mkd_conv_wgrad_pairs: U2MKD_WGRAD_CP must be 16 or 32");
+    const int cp = (wm >= 3 || wn >= 3) ? 16 : 32;
 #define U2_WPC(WM_, WN_, CPV)                                                                                       \
     do {                                                                                                            \
         constexpr int CP_ = CPV;                                                                                    \

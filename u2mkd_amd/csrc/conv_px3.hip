@@ -289,19 +289,12 @@ bool conv_px3_supported(int cin, int cout) { return cin >= 32 && cin % 32 == 0 &
 
 // column tile: 128 (4 waves x 2 column blocks), 96 (3 waves x 2: the 96- and 192-column layers exactly) or 256 (4 waves x 4:
 // layers whose columns are a multiple of 256 -- every row fragment read from LDS feeds twice the MFMAs: 512 -> 512 at stride
-// 8 498 -> 405 us, 256 -> 256 at stride 4 198 -> 184 us; 232 VGPRs = 2 workgroups per CU; U2MKD_PX3_WIDE=0 keeps the 128-column
-// tile there.  The same 4 blocks per wave on TWO waves for the 128-column layers was measured slower: 109 -> 129 us)
-static bool px3_wide(int cout) {
-    static const bool on = !(getenv("U2MKD_PX3_WIDE") && atoi(getenv("U2MKD_PX3_WIDE")) == 0);
-    return on && cout % 256 == 0;
-}
+// 8 498 -> 405 us, 256 -> 256 at stride 4 198 -> 184 us; 232 VGPRs = 2 workgroups per CU.  The same 4 blocks per wave on TWO waves for the 128-column layers was measured slower: 109 -> 129 us)
+static bool px3_wide(int cout) { return cout % 256 == 0; }
 
-// 192 columns per tile (3 waves x 4 blocks) for the 192-column layers, same switch: 192 -> 192 at stride 1 234 -> 225 us,
+// 192 columns per tile (3 waves x 4 blocks) for the 192-column layers: 192 -> 192 at stride 1 234 -> 225 us,
 // 256 -> 192 at stride 2 215 -> 204 us
-static bool px3_wide3(int cout) {
-    static const bool on = !(getenv("U2MKD_PX3_WIDE") && atoi(getenv("U2MKD_PX3_WIDE")) == 0);
-    return on && cout % 192 == 0;
-}
+static bool px3_wide3(int cout) { return cout % 192 == 0; }
 
 // Tile shape by layer.  Two 64-pair tiles per step on 128- / 96-column tiles (TL = 2) where the weight fragments dominate
 // what a step pulls through the vector L1 -- measured (MI355X, 80k scene, tools/ab_px3.py, TL 1 -> 2): 512 -> 512 at stride 8

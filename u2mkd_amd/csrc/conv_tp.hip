@@ -250,11 +250,10 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     const int n_it = items ? *n_items_dev : n_tiles;
     const int G = (int)gridDim.x, wg = (int)blockIdx.x;
     const int n_rd = (n_it + G - 1) / G;
-    const bool asc = (kflip & 4) != 0;          // round order (launch_conv_tp: U2MKD_TP_ORDER)
     // this workgroup's next item at or after round rq (-1: none)
     auto next_item = [&](int &rq) __attribute__((always_inline)) {
         for (; rq < n_rd; ++rq) {
-            const int rd = asc ? rq : n_rd - 1 - rq;
+            const int rd = n_rd - 1 - rq;             // (the workgroup's lightest item first)
             const int t = rd * G + ((rd & 1) ? G - 1 - wg : wg);
             if (t < n_it) return t;
         }
@@ -613,12 +612,6 @@ static int device_cus() {
     return cus;
 }
 
-// workgroups per CU the launch may use: 0 = what the occupancy query says (the default), otherwise forced (tuning knob)
-static int tp_slots_override() {
-    static const int v = getenv("U2MKD_TP_SLOTS") ? atoi(getenv("U2MKD_TP_SLOTS")) : 0;
-    return v;
-}
-
 template <int NW, int NBW, int CIN, bool STAMP = false, int AR = 1, bool SB = true>
 static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const float *wt, int cout, const int32_t *nbr,
                       const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int kflip,
@@ -634,7 +627,7 @@ static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const f
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_tp_kernel<NW, NBW, CIN, STAMP, AR, SB>, 64 * NW, lds) != hipSuccess || n <= 0) n = 1;
         occ_by_k[K] = n;
     }
-    const int per_cu = tp_slots_override() > 0 ? tp_slots_override() : occ_by_k[K];
+    const int per_cu = occ_by_k[K];
     const unsigned slots = (unsigned)(per_cu * device_cus());
     if (grid.x > slots) grid.x = slots;
     hipLaunchKernelGGL((conv_tp_kernel<NW, NBW, CIN, STAMP, AR, SB>), grid, dim3(64 * NW), lds, st, in, wt, cout, nbr, order, rr,
@@ -679,9 +672,6 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     tp_split(cout, nw, nbw);
     const int ar = conv_tp_arith(arith);
     const bool x3 = ar == 2;
-    static const bool order_asc = getenv("U2MKD_TP_ORDER") && getenv("U2MKD_TP_ORDER")[0] == 'a';      // A/B knob: main item first
-    if (order_asc) kflip |= 4;
-    static const bool double_buf = getenv("U2MKD_TP_SB") && atoi(getenv("U2MKD_TP_SB")) == 0;   // A/B knob: the double-buffered weight form at 64 -> 64
     const int64_t n_rows = rr.end - rr.begin;
     dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile; launch_tp clamps it
 #define U2_TP(NW_, NBW_, CIN_)                                                                                          \
@@ -696,7 +686,6 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     } else if (nw == 4 && nbw == 1) {
         if (stamps && cin == 64 && x3) launch_tp<4, 1, 64, true, 2>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
         else if (stamps && cin == 64) launch_tp<4, 1, 64, true, 1>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out, stamps);
-        else if (cin == 64 && x3 && double_buf) launch_tp<4, 1, 64, false, 2, false>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);
         else if (cin == 32) U2_TP(4, 1, 32); else if (cin == 64) U2_TP(4, 1, 64);
         else if (cin == 96) U2_TP(4, 1, 96); else U2_TP(4, 1, 128);
     } else if (nw == 3) {
@@ -721,7 +710,7 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
         const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
         // one-wave workgroups: the kernel is a single round of loads and stores per thread (latency-bound), and 27 x 64 x 64
         // weights are only 432 waves -- as 256-thread workgroups they sat on 108 of the 256 CUs
-        static const int bt = getenv("U2MKD_FRAG_BLOCK") ? atoi(getenv("U2MKD_FRAG_BLOCK")) : 64;
+        constexpr int bt = 64;
         const dim3 grid((unsigned)ceil_div(total, bt), transpose == 2 ? 2 : 1);
         if (ar == 2)
             hipLaunchKernelGGL(weight_fragments_x3_kernel<3>, grid, dim3(bt), 0, st, w, rows, cols, transpose,
