@@ -599,7 +599,7 @@ def run_rank(args):
                         'child process, MIOPEN_FIND_MODE=FAST bounds the first-call kernel search')
                     log('secondary kd_6cam_900x1600 done')
                 sec['kd_ddp_path_1rank'] = child_leg(
-                    args, ['--steps', '10', '--warmup', '3'], {'U2MKD_FORCE_DDP': '1'},
+                    args, ['--steps', str(args.steps), '--warmup', str(max(args.warmup, args.batches + 1))], {'U2MKD_FORCE_DDP': '1'},   # the headline's own K / W: short runs of this step scatter by +-3 ms
                     'the default KD step on the N>1 code path (bucketed gradient averaging + SyncBatchNorm conversion over a '
                     'ONE-rank RCCL group, U2MKD_FORCE_DDP=1): its price at N = 1, no communication partner')
                 log('secondary kd_ddp_path_1rank done')

@@ -92,13 +92,31 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     const int r = lane & 15, q = lane >> 4;
     const int ntile64 = DENSE ? (n_rows + 63) / 64 : *n_tiles;
     const int ntile = (ntile64 + TL - 1) / TL;                    // units
-    const int per = (ntile + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntile);
-    if (t0 >= t1) return;
+    // Work items (unit, column tile) -> workgroups.  Workgroups are dealt to the 8 XCDs round-robin by their linear index
+    // (xcd = lin % 8, slot j = lin / 8 of WPX per XCD).  Items are cut into BLOCKS of UPB (= WPX, below) consecutive units x one column tile,
+    // block b = (unit group b / gy, column tile b % gy); XCD x takes blocks x, x + 8, ...: at any time all WPX workgroups of an
+    // XCD multiply the SAME column tile against WPX consecutive units = one or two offsets, whose fragments (cin x TN x 6 B per
+    // offset: 0.4 MB at 512 x 128) stay in that XCD's 4 MB L2 -- with each workgroup on its own contiguous run of units
+    // (rounds 2-3) every XCD streamed all 27 offsets at once from the Infinity Cache (L2 hit rate 40 %).
+    const int gy = (cout + TN - 1) / TN;
+    const int lin = (int)blockIdx.x, wpx = (int)gridDim.x >> 3;
+    // short pair lists: halve the block (and split an XCD's slots into teams with blocks of their own) until every team has
+    // about three blocks to walk -- otherwise a list of a few blocks would leave whole XCDs idle
+    int upb = wpx;
+    while ((upb & 1) == 0 && ((ntile + upb - 1) / upb) * gy < 24 * (wpx / upb)) upb >>= 1;
+    const int teams = 8 * (wpx / upb);
+    const int team = (lin & 7) + 8 * ((lin >> 3) / upb), slot = (lin >> 3) % upb;
+    if (slot >= ntile) return;
+    const int gmax = (ntile - 1 - slot) / upb;                 // last unit group that holds a unit for this slot
+    const int bmax = gmax * gy + gy - 1;
+    if (bmax < team) return;
+    const int t0 = 0, t1 = (bmax - team) / teams + 1;          // this workgroup's blocks: team + teams t, t = 0 .. t1 - 1
     const int ns = cin / SC;
     const int nsteps = (t1 - t0) * ns;
     const int ncb = cout / 16;
-    const int cbw = blockIdx.y * (TN / 16) + NBW * wave;      // this wave's first column block
+    auto block_of = [&](int t) __attribute__((always_inline)) { return team + teams * min(t, t1 - 1); };
+    auto unit_of = [&](int t) __attribute__((always_inline)) { return (block_of(t) / gy) * upb + slot; };
+    auto cbw_of = [&](int t) __attribute__((always_inline)) { return (block_of(t) % gy) * (TN / 16) + NBW * wave; };   // the wave's first column block
 
     // chunk e of a step: row e / CH of the tile, 16-byte chunk e % CH of the row's step bytes
     int crow[LPT], cch[LPT];
@@ -117,10 +135,10 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     float4 bw[2][NWF * NBW];
     f32x4 g[2][LPT];
     int gix[LPT];        // pair entries of the tile the NEXT gather reads
-    int kw;              // offset of the tile the NEXT weight issue reads
+    int kw, cw;          // offset / first column block of the unit the NEXT weight issue reads
 
     auto load_idx = [&](int t, int (&ix)[LPT]) __attribute__((always_inline)) {
-        const int tt = min(t, t1 - 1);
+        const int tt = unit_of(t);
 #pragma unroll
         for (int l = 0; l < LPT; ++l) {
             if (DENSE) {
@@ -139,7 +157,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                                                      ((size_t)row * cin + SC * s) * esz + 16 * cch[l]);
         }
     };
-    auto issue_B = [&](int k, int s, float4 (&bb)[NWF * NBW]) __attribute__((always_inline)) {
+    auto issue_B = [&](int k, int cbw, int s, float4 (&bb)[NWF * NBW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
             const int cb = min(cbw + n, ncb - 1);         // column blocks past cout: computed, never stored
@@ -180,9 +198,12 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         for (int p = 0; p < NWF; ++p) aa[p] = *reinterpret_cast<const float4 *>(row + 64 * p);
     };
     auto lds_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[TL * min(t, t1 - 1)]; };
+    auto tile_offset = [&](int t) __attribute__((always_inline)) { return DENSE ? 0 : tile_k[TL * unit_of(t)]; };
 
     // positions (tile, step) of flattened step i + d; advance = next 32-channel step, then next tile
+    // positions (block, step) of flattened step i + d; advance = next 32-channel step, then the workgroup's next block
+    // (the unit / column tile of a block are re-derived by a division per use: carrying them incrementally was measured
+    // 25 % slower -- the extra live scalars pushed hipcc into a vmcnt(0) at the top of the step)
     int tc = t0, sc = 0;                 // step i   (multiplied)
     int tw = t0, sw = 0;                 // step i+1 (weights issued)
     int tg = t0, sg = 0;                 // step i+2 (rows gathered)
@@ -195,7 +216,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         int ix0[LPT];
         load_idx(tg, ix0);
         issue_G(ix0, sg, g[0]);
-        issue_B(tile_offset(tw), sw, bw[0]);
+        issue_B(tile_offset(tw), cbw_of(tw), sw, bw[0]);
         adv(tg, sg);
         adv(tw, sw);
         load_idx(tg, ix0);
@@ -203,6 +224,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         adv(tg, sg);
         load_idx(tg, gix);               // tile of step 2
         kw = tile_offset(tw);            // tile of step 1
+        cw = cbw_of(tw);
         store_G(g[0], 0);
         lds_barrier();
     }
@@ -211,12 +233,15 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         constexpr int u = decltype(U)::value;      // i mod 2: ring positions are static register names
         // -- issue what later steps need (all unconditional)
         const int kcur = __builtin_amdgcn_readfirstlane(kw);
-        issue_B(kcur, sw, bw[u ^ 1]);              // weights of step i+1
+        issue_B(kcur, __builtin_amdgcn_readfirstlane(cw), sw, bw[u ^ 1]);   // weights of step i+1
         issue_G(gix, sg, g[u]);                    // rows of step i+2 (the rows of step i left g[u] at step i-1)
         adv(tw, sw);
         adv(tg, sg);
         kw = tile_offset(tw);                      // step i+2's tile
+        cw = cbw_of(tw);
         load_idx(tg, gix);                         // step i+3's tile
+        // (measured and rejected: the index loads issued BEFORE the fragment / row loads so that the next step's wait for them
+        // leaves those in flight -- no vmcnt(0) left in the loop, and the 256- / 192-column instantiations 20 % slower)
         // -- multiply step i from LDS image u
         float4 a[2][NWF];
         read_frag(u, 0, a[0]);
@@ -251,12 +276,13 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
         }
         // -- last channel step of a tile: lane (r, q) holds columns 4q .. 4q+3 of pair r of every row block
         if (sc + 1 == ns) {
+            const int cbw = cbw_of(tc);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const int col = 16 * (cbw + n) + 4 * q;
-                    const int row = tc * RU + 16 * rb + r;
+                    const int row = unit_of(tc) * RU + 16 * rb + r;
                     if (cbw + n < ncb && (!DENSE || row < n_rows)) {
                         f32x4 o = acc[rb][n];
                         if (DENSE && bias) o += *reinterpret_cast<const f32x4 *>(bias + col);
@@ -335,12 +361,13 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
                     const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16) {
     if (!conv_px3_supported(cin, cout)) return -1;
     const Px3Shape p = px3_shape(cin, cout);
-    int64_t gx = capacity / (64 * p.tl);
-    const int64_t cap_x = (p.tl == 1 && p.nbw == 2 ? 3 : 2) * 256;   // workgroups per CU (registers), each a contiguous run of units
+    // ONE resident wave of workgroups (registers: 2 or 3 per CU), a multiple of 8 = the same number per XCD; fewer when the
+    // pair list cannot fill them (every workgroup owns at least one (unit, column tile) item of the capacity)
+    const int64_t cap_x = (p.tl == 1 && p.nbw == 2 ? 3 : 2) * 256;
     const int gy = (int)ceil_div(cout, p.tn);
-    if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
-    if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, (unsigned)gy);
+    int64_t gx = std::min<int64_t>(cap_x, ceil_div(capacity / (64 * p.tl) * gy, 8) * 8);
+    if (gx < 8) gx = 8;
+    dim3 grid((unsigned)gx);
     if (!b16) px3_launch<false, false, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     else if (cin % 64 == 0) px3_launch<false, true, 64>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     else px3_launch<false, true, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
@@ -353,10 +380,10 @@ int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin,
     if (!conv_px3_supported(cin, cout)) return -1;
     const Px3Shape p = px3_shape(cin, cout);
     const int gy = (int)ceil_div(cout, p.tn);
-    int64_t gx = ceil_div(n_rows, 64 * p.tl);
     const int64_t cap_x = (p.tl == 1 && p.nbw == 2 ? 3 : 2) * 256;
-    if (gx * gy > cap_x) gx = ceil_div(cap_x, gy);
-    dim3 grid((unsigned)gx, (unsigned)gy);
+    int64_t gx = std::min<int64_t>(cap_x, ceil_div(ceil_div(n_rows, 64 * p.tl) * gy, 8) * 8);
+    if (gx < 8) gx = 8;
+    dim3 grid((unsigned)gx);
     if (!b16) px3_launch<true, false, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     else if (cin % 64 == 0) px3_launch<true, true, 64>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     else px3_launch<true, true, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
