@@ -653,23 +653,28 @@ conv_wgrad_pairs_kernel(const float *__restrict__ a, int ca, const float *__rest
 // in lane order through LDS (deterministic, ~P/CH/16 dependent loads per thread).
 __global__ void __launch_bounds__(256)
 wgrad_pairs_reduce_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ plan, int K,
-                          int64_t tile_elems, float *__restrict__ dw) {
+                          int64_t tile_elems, float *__restrict__ dw, int merge = 1) {
     __shared__ float4 part[16][16];
     const int k = blockIdx.y;
     const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int64_t e = ((int64_t)blockIdx.x * 16 + lx) * 4;
     const int *wg = plan + 3 + K;
     const int w0 = wg[k], w1 = wg[k + 1];
+    // the slabs that were written: slot w0 and every slot of the offset that is a multiple of `merge` (conv_wgrad_x3_kernel:
+    // one slab per run of merged slots); merge = 1: every slot
+    const int m0 = (w0 / merge + 1) * merge;
+    const int nslab = w1 > w0 ? 1 + (w1 > m0 ? (w1 - m0 + merge - 1) / merge : 0) : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < tile_elems) {
         // four slab rows in flight per thread (the loads do not depend on the running sum; the order of the
-        // additions is fixed: slabs w0+g, +16, +32, ... as before)
-        for (int w = w0 + g; w < w1; w += 64) {
+        // additions is fixed: live slabs g, g + 16, g + 32, ... of the offset)
+        for (int j = g; j < nslab; j += 64) {
             float4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ww = w + 16 * i;
-                v[i] = ww < w1 ? *reinterpret_cast<const float4 *>(slabs + (size_t)ww * tile_elems + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int jj = j + 16 * i;
+                const int ww = jj == 0 ? w0 : m0 + (jj - 1) * merge;
+                v[i] = jj < nslab ? *reinterpret_cast<const float4 *>(slabs + (size_t)ww * tile_elems + e) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
@@ -1278,11 +1283,12 @@ static int wgrad_pairs_impl(bool b16, const float *a, int32_t ca, const float *b
     const bool x3_shape = ca % 64 == 0 && cb % 64 == 0;
     if (x3_shape && (b16 || conv_tp_arith(0) == 2) && conv_wgrad_x3_supported(ca, cb, k)) {
         // (bf16 rows: the same kernel without the split -- one plane, one MFMA per product)
-        int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, reinterpret_cast<float *>(workspace), st, b16);
+        const int merge = conv_wgrad_x3_merge(ca, cb);
+        int rc = launch_conv_wgrad_x3(a, ca, b, cb, pairs, plan, k, swap, g, merge, reinterpret_cast<float *>(workspace), st, b16);
         if (rc) return rc;
         const int64_t te = (int64_t)ca * cb;
         hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3((unsigned)ceil_div(te, 64), k), dim3(256), 0, st,
-                           reinterpret_cast<float *>(workspace), plan, k, te, dw);
+                           reinterpret_cast<float *>(workspace), plan, k, te, dw, merge);
         return check_launch("u2mkd_conv_wgrad_pairs");
     }
     // 32*W-channel tiles per operand: 96-channel layers get exact 96-wide tiles (W = 3)

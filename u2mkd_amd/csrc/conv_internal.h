@@ -35,6 +35,7 @@ int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin,
 // Weight gradient in bf16x3 arithmetic (conv_wgrad_x3.hip): 64 x 64-channel tiles, slabs as the f32 kernel.
 bool conv_wgrad_x3_supported(int ca, int cb, int k);
 int launch_conv_wgrad_x3(const float *a, int ca, const float *b, int cb, const int32_t *pairs, const int32_t *plan,
-                         int k, int swap, int g, float *slabs, hipStream_t st, bool b16 = false);
+                         int k, int swap, int g, int merge, float *slabs, hipStream_t st, bool b16);
+int conv_wgrad_x3_merge(int ca, int cb);
 
 }  // namespace u2mkd

@@ -71,33 +71,30 @@ template <bool B16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restrict__ b, int cb,
                      const int32_t *__restrict__ pairs, const int32_t *__restrict__ plan, int K, int swap,
-                     float *__restrict__ slabs) {
+                     int merge, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [A | B][3 (B16: 1)][32][kWxRow]
     constexpr int NPL = B16 ? 1 : 3;
     constexpr int OPB = NPL * kWxCP * kWxRow;                         // bytes of one operand's image
-    const int w = blockIdx.x;
+    // this workgroup walks `merge` consecutive workgroup slots of the plan (chunks of `ch` pairs, cut per offset): a run of
+    // slots inside one offset is ONE contiguous pair range = one segment with one slab (written at the run's first slot;
+    // wgrad_pairs_reduce_kernel reads exactly those).  merge = 1: a segment = a chunk, as the f32 kernel has it.  The wide
+    // layers run merge = 8 / 16: a 64 x 64 tile of a 512 x 512 weight at 229-pair chunks wrote (and the reduce re-read) 523
+    // slabs of 1 MB per launch.
     const int *wg = plan + 3 + K;
-    int k = 0, p_begin, p_end;
     const int ch = plan[1];
-    {
-        const int l = min((int)(threadIdx.x & 63), K);
-        const int wgv = wg[l], kof = plan[2 + l];
-        const unsigned long long le = __ballot(wgv <= w) & ((2ULL << K) - 2ULL);
-        k = __builtin_amdgcn_readfirstlane(__popcll(le));
-        if (k >= K) return;
-        p_begin = __builtin_amdgcn_readlane(kof, k) + (w - __builtin_amdgcn_readlane(wgv, k)) * ch;
-        p_end = min(p_begin + ch, __builtin_amdgcn_readlane(kof, k + 1));
-    }
+    const int lsel = min((int)(threadIdx.x & 63), K);
+    const int wgv = wg[lsel], kof = plan[2 + lsel];
+    const int total = __builtin_amdgcn_readlane(wgv, K);
+    int wlo = blockIdx.x * merge;
+    const int whi = min(wlo + merge, total);
+    if (wlo >= whi) return;
     const int a0 = (blockIdx.y / ((cb + 63) / 64)) * 64, b0 = (blockIdx.y % ((cb + 63) / 64)) * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int gq = lane >> 4, li = lane & 15;                // 16-lane group = 8 pairs of the K dimension; lane = channel
     const int wy = wave >> 1, wx = wave & 1;
 
     f32x4 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int p_begin = 0, p_end = 0;          // the current segment's pair range
 
     // gather: 32 pairs x 16 chunks of 4 channels per operand = 512 chunks, 2 per thread and operand
     f32x4 ra[2][2], rb[2][2];
@@ -196,64 +193,89 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             }
     };
 
-    // prologue: chunk 0 in the image, rows of chunk 1 and indices of chunk 2 in flight
-    load_idx(p_begin, ia[0], ib[0]);
-    load_idx(p_begin + kWxCP, ia[1], ib[1]);
-    load_rows(ia[0], ib[0], ra[0], rb[0]);
-    load_idx(p_begin + 2 * kWxCP, ia[0], ib[0]);
-    load_rows(ia[1], ib[1], ra[1], rb[1]);
-    store_chunk(p_begin, ra[0], rb[0]);
-    lds_barrier();
-    for (int p0 = p_begin; p0 < p_end; p0 += 2 * kWxCP) {
-        // even chunk c: rows c+1 in set 1, indices c+2 in set 0
-        load_idx(p0 + 3 * kWxCP, ia[1], ib[1]);
-        load_rows(ia[0], ib[0], ra[0], rb[0]);                 // rows of chunk c+2
-        __builtin_amdgcn_sched_barrier(0);
-        multiply();
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();                                         // every wave has read chunk c
-        store_chunk(p0 + kWxCP, ra[1], rb[1]);
-        lds_barrier();
-        // odd chunk c+1: rows c+2 in set 0, indices c+3 in set 1
-        load_idx(p0 + 4 * kWxCP, ia[0], ib[0]);
-        load_rows(ia[1], ib[1], ra[1], rb[1]);                 // rows of chunk c+3
-        __builtin_amdgcn_sched_barrier(0);
-        multiply();                                            // (a range with an odd number of chunks multiplies zeros)
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
-        store_chunk(p0 + 2 * kWxCP, ra[0], rb[0]);
-        lds_barrier();
-    }
-    // D[i = a channel][j = b channel]: row = 4 gq + reg, col = li
-    float *slab = slabs + (size_t)w * ca * cb;
+    while (wlo < whi) {
+        // the segment's offset = the number of prefix entries wg[1..K] <= wlo (empty offsets are skipped by construction)
+        const unsigned long long le = __ballot(wgv <= wlo) & ((2ULL << K) - 2ULL);
+        const int k = __builtin_amdgcn_readfirstlane(__popcll(le));
+        const int wk = __builtin_amdgcn_readlane(wgv, k), seg_hi = min(whi, __builtin_amdgcn_readlane(wgv, k + 1));
+        p_begin = __builtin_amdgcn_readlane(kof, k) + (wlo - wk) * ch;
+        p_end = min(__builtin_amdgcn_readlane(kof, k) + (seg_hi - wk) * ch, __builtin_amdgcn_readlane(kof, k + 1));
+        const int w = wlo;                   // the slab of this segment
+        wlo = seg_hi;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int ach = a0 + 16 * (2 * wy + m) + 4 * gq + reg;
-            if (ach < ca) {
+            for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // prologue: chunk 0 in the image, rows of chunk 1 and indices of chunk 2 in flight
+        load_idx(p_begin, ia[0], ib[0]);
+        load_idx(p_begin + kWxCP, ia[1], ib[1]);
+        load_rows(ia[0], ib[0], ra[0], rb[0]);
+        load_idx(p_begin + 2 * kWxCP, ia[0], ib[0]);
+        load_rows(ia[1], ib[1], ra[1], rb[1]);
+        store_chunk(p_begin, ra[0], rb[0]);
+        lds_barrier();
+        for (int p0 = p_begin; p0 < p_end; p0 += 2 * kWxCP) {
+            // even chunk c: rows c+1 in set 1, indices c+2 in set 0
+            load_idx(p0 + 3 * kWxCP, ia[1], ib[1]);
+            load_rows(ia[0], ib[0], ra[0], rb[0]);                 // rows of chunk c+2
+            __builtin_amdgcn_sched_barrier(0);
+            multiply();
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();                                         // every wave has read chunk c
+            store_chunk(p0 + kWxCP, ra[1], rb[1]);
+            lds_barrier();
+            // odd chunk c+1: rows c+2 in set 0, indices c+3 in set 1
+            load_idx(p0 + 4 * kWxCP, ia[0], ib[0]);
+            load_rows(ia[1], ib[1], ra[1], rb[1]);                 // rows of chunk c+3
+            __builtin_amdgcn_sched_barrier(0);
+            multiply();                                            // (a range with an odd number of chunks multiplies zeros)
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            store_chunk(p0 + 2 * kWxCP, ra[0], rb[0]);
+            lds_barrier();
+        }
+        // D[i = a channel][j = b channel]: row = 4 gq + reg, col = li
+        float *slab = slabs + (size_t)w * ca * cb;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int bch = b0 + 16 * (2 * wx + n) + li;
-                    if (bch < cb) slab[(size_t)ach * cb + bch] = acc[m][n][reg];
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ach = a0 + 16 * (2 * wy + m) + 4 * gq + reg;
+                if (ach < ca) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int bch = b0 + 16 * (2 * wx + n) + li;
+                        if (bch < cb) slab[(size_t)ach * cb + bch] = acc[m][n][reg];
+                    }
                 }
             }
-        }
+    }
 }
 
 bool conv_wgrad_x3_supported(int ca, int cb, int k) { return ca % 4 == 0 && cb % 4 == 0 && ca >= 4 && cb >= 4 && k <= 63; }
 
 int launch_conv_wgrad_x3(const float *a, int ca, const float *b, int cb, const int32_t *pairs, const int32_t *plan,
-                         int k, int swap, int g, float *slabs, hipStream_t st, bool b16) {
+                         int k, int swap, int g, int merge, float *slabs, hipStream_t st, bool b16) {
     const int tiles_a = (ca + 63) / 64, tiles_b = (cb + 63) / 64;
-    dim3 grid(g, tiles_a * tiles_b);
+    dim3 grid((g + merge - 1) / merge, tiles_a * tiles_b);
     if (b16)
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(256), (size_t)2 * kWxCP * kWxRow, st, a, ca, b, cb, pairs,
-                           plan, k, swap, slabs);
+                           plan, k, swap, merge, slabs);
     else
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<false>, grid, dim3(256), (size_t)2 * kWxOperand, st, a, ca, b, cb, pairs, plan,
-                           k, swap, slabs);
+                           k, swap, merge, slabs);
     return check_launch("u2mkd_conv_wgrad_pairs");
+}
+
+// Slots merged per workgroup, by the number of 64 x 64 tiles of the weight: every tile is a workgroup of its own, so the wide
+// layers have workgroups to spare, and their slabs (slots x ca x cb floats, written here and re-read by the reduce) were a
+// large part of what a launch moved.  Measured (MI355X, 80k scene, tools/ab_wgrad_layers.py, merge 1 -> 4 / 6): 128 x 128 at
+// stride 2 95 -> 84 us, 256 x 256 at stride 4 299 -> 238 us, 512 x 512 at stride 8 636 -> 518 us, 768 x 512 925 -> 756 us,
+// 192 x 192 at stride 1 220 -> 193 us; merge 12-16 loses again (too few workgroups for an even last wave); 64 x 64 keeps 1
+// (45 us against 35 us at merge 4: that shape needs every workgroup it can get).
+int conv_wgrad_x3_merge(int ca, int cb) {
+    const int tiles = ((ca + 63) / 64) * ((cb + 63) / 64);
+    return tiles >= 9 ? 6 : (tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1));
 }
 
 }  // namespace u2mkd
