@@ -8,7 +8,7 @@ for t in .ab_old .; do
   cd $R/$t
   n=$(echo $t | tr -d ./)_$i
   python bench.py --no-secondary --no-roofline --no-cpu-baseline --steps 20 --warmup 5 > $R/gpurun_out/ab/kd_$n.json 2> $R/gpurun_out/ab/kd_$n.err
-  U2MKD_FORCE_DDP=1 python bench.py --no-secondary --no-roofline --no-cpu-baseline --steps 10 --warmup 3 > $R/gpurun_out/ab/ddp_$n.json 2> $R/gpurun_out/ab/ddp_$n.err
+  U2MKD_FORCE_DDP=1 python bench.py --no-secondary --no-roofline --no-cpu-baseline --steps 20 --warmup 5 > $R/gpurun_out/ab/ddp_$n.json 2> $R/gpurun_out/ab/ddp_$n.err
   echo "TREE $t  kd $(grep -o '"ms_per_step": [0-9.]*' $R/gpurun_out/ab/kd_$n.json)  ddp-path $(grep -o '"ms_per_step": [0-9.]*' $R/gpurun_out/ab/ddp_$n.json)"
 done
 done

@@ -1,0 +1,37 @@
+"""Upper bound of moving every coordinate-only structure out of the step: the pipelined KD step on fresh batch copies (the
+bench) against the same step on ONE batch object whose geometry, schedules and plans survive from step to step.
+    python tools/exp_cached_geometry.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from u2mkd_amd import lidar, train as T, kd as KD
+from u2mkd_amd.synth import synth_kd_batch
+
+torch.manual_seed(0)
+sp = {k: v for k, v in lidar.spformer_kwargs().items() if k not in ('cr', 'in_channel', 'num_classes')}
+model = KD.TSDFull(cr=1.0, cr_t=2.0, in_channel=4, in_channel_t=4, num_classes=17, spformer=sp).cuda()
+run = T.KDStep(model, num_epochs=50, batch_size=1)
+run.train_mode()
+res = [T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234 + i, image_hw=(360, 640))) for i in range(4)]
+
+
+def fresh(steps):
+    cur = T.fresh_batch(res[0])
+    for i in range(steps):
+        nxt = T.fresh_batch(res[(i + 1) % 4])
+        run(cur, prefetch=nxt)
+        cur = nxt
+
+
+def cached(steps):
+    for i in range(steps):
+        run(res[0])
+
+
+for name, fn in (('fresh', fresh), ('cached', cached), ('fresh', fresh), ('cached', cached)):
+    fn(6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(16)
+    torch.cuda.synchronize()
+    print('MODE %-7s %.2f ms/step' % (name, (time.perf_counter() - t0) / 16 * 1e3), flush=True)
