@@ -143,15 +143,29 @@ def subm_algorithmic_bytes(n, p, cin, cout, k=27, s=4):
     return fwd, dgrad, wgrad
 
 
-def time_events(fns, iters, warmup=3):
+def time_events(fns, iters, warmup=3, ramp_ms=25.0):
     """Average duration (ms) of one call, measured with HIP events on the current stream -- the
     stream every u2mkd kernel is launched on.  ``fns`` is a list of closures called round-robin
     (one closure = back-to-back launches on one working set; several closures over distinct
-    buffers whose total exceeds the 256 MiB Infinity Cache = cold launches)."""
+    buffers whose total exceeds the 256 MiB Infinity Cache = cold launches).
+    ``ramp_ms``: the same closures are launched back to back for about that long right before the timed region, with no
+    synchronisation in between.  After an idle period the GPU needs 10-20 ms of sustained load to reach its working clocks
+    (tools/exp_dgrad_gap.py: the SAME launch reads 36-40 us in the first 2 ms loop after a synchronisation and 32-33 us from the
+    tenth loop on); the roofline kernels run inside a training step, i.e. under sustained load, and that is the state timed."""
     import torch
     for i in range(warmup * len(fns)):
         fns[i % len(fns)]()
     torch.cuda.synchronize()
+    if ramp_ms:
+        probe0, probe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        probe0.record()
+        for i in range(8 * len(fns)):
+            fns[i % len(fns)]()
+        probe1.record()
+        probe1.synchronize()
+        per = max(probe0.elapsed_time(probe1) / (8 * len(fns)), 1e-3)
+        for i in range(int(ramp_ms / per) + 1):
+            fns[i % len(fns)]()
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     start.record()
@@ -162,7 +176,7 @@ def time_events(fns, iters, warmup=3):
     return start.elapsed_time(stop) / iters
 
 
-def roofline_leg(coords_dev, iters=60, cold_sets=8):
+def roofline_leg(coords_dev, iters=200, cold_sets=8):
     """North-star micro-shape: Conv3d(64, 64, k=3, stride 1) on the scene's stride-1 map;
     fwd, dgrad and wgrad each timed separately, warm (one working set, L3-resident) and cold
     (``cold_sets`` distinct operand sets, > 256 MiB in total, launched round-robin)."""

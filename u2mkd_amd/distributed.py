@@ -42,16 +42,19 @@ def init_from_env(backend: str | None = None):
 
 
 def configure_runtime():
-    """Process-level HIP settings of a multi-rank run; must run before the process's first HIP call (a launcher's first
-    line: ``torch.cuda.is_available()`` already initialises the runtime)."""
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':
-        # RCCL's communicator brings streams of its own.  The step keeps four streams busy (student LiDAR, frozen teacher,
-        # camera branch, weight gradients) and the HIP runtime maps streams onto 4 hardware queues by default: with the
-        # communicator alive two of the working streams share a queue and serialise -- measured +10.5 ms per KD step
-        # (76.0 -> 86.5 ms) at ONE rank, before a single byte moves (tools/ddp_cost.py: `pg` against `pglazy`); with 8
-        # queues the same run takes 76.3-76.8 ms.  The runtime reads the variable when it initialises, i.e. at the first
-        # HIP call of the process: this has to run before anything touches the GPU (the launchers call it first).
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    """Process-level HIP settings; must run before the process's first HIP call (``import u2mkd_amd`` runs it; a launcher
+    that touches the GPU before that import calls it on its first line -- ``torch.cuda.is_available()`` already
+    initialises the runtime, and the runtime reads the variable only then).
+
+    ``GPU_MAX_HW_QUEUES=8`` (the runtime's default is 4).  A training step keeps FIVE streams busy -- student LiDAR (main),
+    frozen teacher, camera branch, weight gradients, the next batch's geometry -- and with 4 hardware queues the fifth
+    shares a queue with another stream, in order: the geometry pre-pass, issued behind the backward, then started only when
+    the backward had drained, the host sat in its size reads until then and began every step with no lead over the GPU
+    (the student's first kernel reached an idle main stream 8 ms into the step).  With 5 / 6 / 8 queues the pre-pass runs
+    underneath the backward and the host stays a whole step ahead: 72.2 -> 71.6 / 69.9 / 70.4 ms (tools/host_lead.py).
+    A multi-rank process needs the room for a second reason: RCCL's communicator brings streams of its own (with 4 queues
+    +10.5 ms per KD step at ONE rank, tools/ddp_cost.py)."""
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 
 def world() -> int:

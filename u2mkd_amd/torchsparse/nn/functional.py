@@ -770,8 +770,12 @@ def refresh_weight_fragments(*_):
         for w, (_, _, both, k, r, c, planes, ptr) in live:
             rows.append([ptr, both.data_ptr(), first, k, r, c, planes, 0])
             first += 2 * (k * r * c // 512)
-        _FRAG_TABLE[0] = torch.tensor(rows, dtype=torch.int64).to(live[0][0].device, non_blocking=False)
+        # pinned staging + asynchronous copy: a pageable copy makes the host wait for everything queued on the stream --
+        # right behind the optimizer that is the whole backward, i.e. the host's ~20 ms lead over the GPU
+        stage = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        _FRAG_TABLE[0] = stage.to(live[0][0].device, non_blocking=True)
         _FRAG_TABLE[1] = first
+        _FRAG_TABLE[2:] = [stage]          # alive until the next rebuild: the copy reads it asynchronously
     L.call('u2mkd_weight_fragments_batch', L.ptr(_FRAG_TABLE[0]), len(live), _FRAG_TABLE[1], L.stream())
     epoch = _WEIGHT_EPOCH[0]
     for w, job in live:
@@ -825,7 +829,9 @@ def _weight_layout(weight, transpose, fragments, arith=0):
             hit = (stamp, both)
             holder.__dict__[slot] = hit
             job = _FRAG_JOBS.get((id(holder), slot))
-            if not frozen and (fresh or job is None or job[0]() is not holder or job[7] != stamp[1] or job[2] is not both):
+            # (leaves only: a padded / cast copy made per call dies with the call -- registering it made the refresh rebuild
+            # its job table after every optimizer step)
+            if not frozen and holder.is_leaf and (fresh or job is None or job[0]() is not holder or job[7] != stamp[1] or job[2] is not both):
                 _register_fragments(holder, slot, both, k, r, c, arith)
         return hit[1][0 if transpose else 1]
     key = '_u2mkd_wt' + tag
