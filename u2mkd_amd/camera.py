@@ -318,15 +318,68 @@ def bn_act(bn, x, relu=False, residual=None):
     return F.relu(y) if relu else y
 
 
+class _Conv2dFunction(torch.autograd.Function):
+    """``F.conv2d`` (MIOpen) whose weight gradient leaves the chain of the backward.  Every fusion stage's LiDAR gradient waits
+    for the camera layer's INPUT gradient (camera -> LiDAR gather <- ResNet layer <- LiDAR -> camera scatter); the weight
+    gradients of the layer's convolutions (igemm + layout transposes, ~0.25 ms each) are needed by nobody before the
+    optimizer: they go to a side stream (deferred.side_for) and are joined when the backward ends."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        ctx.dtypes = (x.dtype, weight.dtype)
+        ctx.pid = id(weight)
+        if torch.is_autocast_enabled('cuda'):
+            dt = torch.get_autocast_dtype('cuda')
+            x, weight = x.to(dt), weight.to(dt)
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, padding)
+        with torch.autocast('cuda', enabled=False):
+            return F.conv2d(x, weight, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import deferred
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.conf
+        g = g.contiguous().to(x.dtype)
+
+        def bwd(mask):
+            return torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, (1, 1), False, (0, 0), 1, mask)
+        gx = bwd((True, False, False))[0].to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.pid in deferred.OWNERS:        # a second use of the weight in this pass: its accumulation reads the first
+                deferred.join()
+            side = deferred.side_for('camera_wgrad', g.device, owner=ctx.pid)
+            with torch.cuda.stream(side):
+                gw = bwd((False, True, False))[1].to(ctx.dtypes[1])
+            for t in (x, weight, g):
+                t.record_stream(side)
+            gw.record_stream(torch.cuda.current_stream(g.device))      # allocated on the side stream, consumed on this one
+        return gx, gw, None, None
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state-dict keys) on _Conv2dFunction while training on the GPU."""
+
+    def forward(self, x):
+        w = self.weight
+        if (x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.is_leaf and w.grad is None and self.bias is None
+                and self.groups == 1 and self.dilation == (1, 1) and self.padding_mode == 'zeros'
+                and not isinstance(self.padding, str) and not torch.cuda.is_current_stream_capturing()):
+            return _Conv2dFunction.apply(x, w, self.stride, self.padding)
+        return super().forward(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
 
@@ -343,7 +396,7 @@ class BNReluConv(nn.Sequential):
         super().__init__()
         self.add_module('norm', BatchNorm2d(cin, momentum=bn_momentum))
         self.add_module('relu', nn.ReLU(inplace=True))
-        self.add_module('conv', nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2, bias=False))
+        self.add_module('conv', Conv2d(cin, cout, kernel_size=k, padding=k // 2, bias=False))
 
     def forward(self, x):
         return self.conv(bn_act(self.norm, x, relu=True))
@@ -388,7 +441,7 @@ class SwiftNetResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.img_cs = [64, 64, 128, 256, num_features[0]]
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1, padding=3, bias=False)
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=1, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = MaxPool3x3s2()
@@ -418,7 +471,7 @@ class SwiftNetResNet(nn.Module):
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
         if stride != 1 or self.inplanes != planes:
-            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
                                        BatchNorm2d(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes

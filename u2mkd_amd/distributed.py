@@ -158,6 +158,8 @@ class BucketedGradientAverage(torch.nn.Module):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
         with torch.no_grad():
             if self._on_gpu:
+                from . import deferred
+                deferred.join()                   # gradients still running on a side stream of their own (camera.Conv2d)
                 cur = torch.cuda.current_stream()
                 for sid, st in b['streams'].items():
                     if sid != cur.stream_id:

@@ -373,7 +373,6 @@ class TSDFull(nn.Module):
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
-_SIDE = {}
 
 
 # Under DDP the AccumulateGrad nodes of the camera parameters are created on the default stream while their gradients
@@ -418,13 +417,11 @@ class _Fork:
 
 
 def _side_stream(ref, role):
-    """One side HIP stream per (device, role)."""
+    """One side HIP stream per (device, role) (the registry of deferred.py: deferred gradient work borrows the teacher's)."""
     if not ref.is_cuda:
         return None
-    key = (ref.device.index, role)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=ref.device)
-    return _SIDE[key]
+    from . import deferred
+    return deferred.stream(ref.device.index if ref.device.index is not None else torch.cuda.current_device(), role)
 
 
 def _tensors(o):
