@@ -908,7 +908,10 @@ class LinearFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bias_grad_is_zero=False):
         L.require_cuda(x, weight)
+        param = weight
         weight = weight.contiguous().float()
+        # the saved weight IS the parameter (no contiguous / cast copy): its gradient goes to AccumulateGrad untouched
+        ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
         want16 = bf16_rows()
         b16 = want16 and _conv_bf16_ok(weight.shape[1], weight.shape[0])
         ctx.in_dtype = x.dtype
@@ -937,20 +940,25 @@ class LinearFunction(Function):
         gx = gw = gb = None
         if n == 0:
             return x.new_zeros(x.shape), torch.zeros_like(weight), (weight.new_zeros(cout) if ctx.has_bias else None), None
-        if ctx.needs_input_grad[0] and ctx.x3:
-            gx = _dense_x3(g, weight, False)
-        elif ctx.needs_input_grad[0]:
-            w_t = torch.empty(1, cin, cout, dtype=torch.float32, device=g.device)     # [cin][cout] = W^T rows
-            L.call('u2mkd_transpose_weights', L.ptr(weight), 1, cout, cin, L.ptr(w_t), L.stream())
-            gx = _dense(g, w_t[0])
+        side, deferred_join = None, False
+        # (the weight gradient first: it goes to the side stream and runs next to gx)
         if ctx.needs_input_grad[1]:
             pairs, plan = _identity_pairs(n, g.device)
             lib = L.load()
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cout, cin, 1)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             gw = torch.empty_like(weight)
+            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan)
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin,
-                   L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), L.stream())
+                   L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), side.cuda_stream if side is not None else L.stream())
+        if ctx.needs_input_grad[0] and ctx.x3:
+            gx = _dense_x3(g, weight, False)
+        elif ctx.needs_input_grad[0]:
+            w_t = torch.empty(1, cin, cout, dtype=torch.float32, device=g.device)     # [cin][cout] = W^T rows
+            L.call('u2mkd_transpose_weights', L.ptr(weight), 1, cout, cin, L.ptr(w_t), L.stream())
+            gx = _dense(g, w_t[0])
+        if side is not None and not deferred_join:
+            torch.cuda.current_stream(g.device).wait_stream(side)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # a bias that feeds a train-mode BatchNorm has the gradient sum(dY) = 0 identically (BatchNorm's input gradient
             # sums to zero over the batch: sum(x_hat) = 0); the reduction over [N, C] would compute rounding noise
@@ -981,15 +989,39 @@ def linear(x, weight, bias=None, bias_feeds_batchnorm=False):
 
 
 _OVERLAP_WGRAD = os.environ.get('U2MKD_OVERLAP_WGRAD', '1') != '0'
-_SIDE_STREAMS = {}
 
 
 def _side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    s = _SIDE_STREAMS.get(key)
-    if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return s
+    from ... import deferred
+    return deferred.stream(device.index if device.index is not None else torch.cuda.current_device(), 'sparse_wgrad')
+
+
+def _wgrad_side(weight, is_param, device, overlap_inline, *used):
+    """(stream, deferred) for a weight-gradient launch.  The launch goes to the weight-gradient side stream; when the gradient
+    is a leaf's first of this backward pass nobody reads it before the pass ends, and the launch is joined THERE
+    (deferred.side_for: end-of-backward callback; ``used`` = the tensors the launch touches, kept from the allocator until
+    the side stream is done with them) -- the weight gradient of a wide layer takes longer than its input gradient, and a
+    linear layer's has no input-gradient launch of comparable length to hide behind; joined per function the backward's
+    chain waited for every one of them.  KD step 70.4 -> 67.6 ms (three same-box pairs).  Measured the other way round
+    earlier in round 4 (+1.5..4 ms): that was with 4 hardware queues and a host without lead -- see NOTES.md N8.
+    Otherwise (an existing .grad is accumulated into right after the function returns): joined by the caller at its end."""
+    if not _OVERLAP_WGRAD:
+        return None, False
+    # is_param: the tensor whose gradient this is IS a leaf parameter (not a contiguous / padded / cast copy made for the call:
+    # the gradient of a copy runs through more backward nodes, on the main stream, before it reaches the parameter)
+    if is_param and weight.grad is None:
+        from ... import deferred
+        if id(weight) in deferred.OWNERS:
+            deferred.join()
+        side = deferred.side_for('sparse_wgrad', device, owner=id(weight))
+        for t in used:
+            t.record_stream(side)
+        return side, True
+    if not overlap_inline:
+        return None, False
+    side = _side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    return side, False
 
 
 class ConvolutionFunction(Function):
@@ -998,7 +1030,9 @@ class ConvolutionFunction(Function):
     @staticmethod
     def forward(ctx, input, weight, kmap, transposed=False):
         L.require_cuda(input, weight)
+        param = weight
         weight = weight.contiguous().float()
+        ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
         k, cin, cout = weight.shape
         # bf16 storage (autocast to bfloat16): bf16 rows in and out, as torchsparse's custom_fwd(cast_inputs=half);
         # shapes without a bf16 kernel (the 4-channel stem) compute on fp32 rows and round the result once
@@ -1037,7 +1071,7 @@ class ConvolutionFunction(Function):
         # chip) and is joined before this function returns, so autograd sees ordinary tensors.
         do_w = ctx.needs_input_grad[1]
         do_x = ctx.needs_input_grad[0]
-        side = _side_stream(g.device) if (do_w and do_x and _OVERLAP_WGRAD) else None
+        side, deferred_join = None, False
         if do_w:
             # dW[k] = sum over the offset's pairs of X[in]^T dY[out] (transposed conv: roles swapped)
             pairs, _, plan = kmap.pairs_plan()
@@ -1045,12 +1079,8 @@ class ConvolutionFunction(Function):
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(kmap.n_out, cin, cout, k)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             grad_weight = torch.empty_like(weight)
-            if side is not None:
-                main = torch.cuda.current_stream(g.device)
-                side.wait_stream(main)
-                st = side.cuda_stream
-            else:
-                st = L.stream()
+            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, do_x, input, g, ws, grad_weight, pairs, plan)
+            st = side.cuda_stream if side is not None else L.stream()
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout,
                    L.ptr(pairs), L.ptr(plan), kmap.n_out, k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), st)
         if do_x:
@@ -1063,7 +1093,7 @@ class ConvolutionFunction(Function):
             if cout % 4 != 0:
                 raise RuntimeError(f'conv3d backward: out_channels={cout} must be a multiple of 4')
             grad_input = _conv_os(g, weight, False, cin, kmap, inverse, input.shape[0], kflip)
-        if side is not None:
+        if side is not None and not deferred_join:
             torch.cuda.current_stream(g.device).wait_stream(side)
         if grad_input is not None and grad_input.dtype != ctx.in_dtype:
             grad_input = grad_input.to(ctx.in_dtype)
