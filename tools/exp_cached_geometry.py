@@ -23,9 +23,23 @@ def fresh(steps):
         cur = nxt
 
 
+_IN = []
+
+
 def cached(steps):
+    """ONE prepared in_mod for every step: voxel sets, kernel maps, schedules, CSR lists and point<->pixel plans all survive
+    (what round 2's bench did); only what the forward never caches (window plans, the losses' sorts) is rebuilt."""
+    d = res[0]
+    if not _IN:
+        _IN.append(run.model.prepare(run._in_mod(d)))
+    in_mod = _IN[0]
     for i in range(steps):
-        run(res[0])
+        with run.amp.autocast():
+            out = run.net(in_mod)
+            ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
+                              run.crit, d['keyframe_mask_full'])
+        run.amp.backward_and_step(ld['total'], run.opt)
+        run.sched.step()
 
 
 for name, fn in (('fresh', fresh), ('cached', cached), ('fresh', fresh), ('cached', cached)):
