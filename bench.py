@@ -588,8 +588,10 @@ def run_rank(args):
         if world == 1 and not args.no_secondary:
             sec = {}
             torch.cuda.empty_cache()
-            for name, wl, hw, w_, k_, extra in (('lidar_only_configs1', 'spvcnn', args.image_hw, 3, 10, {}),
-                                                ('configs4_multisweep_bf16_1gpu', 'kd', args.image_hw, 2, 6,
+            # (warm-up covers every rotated batch once: a batch's first step allocates, and a short leg then scatters by +-3 ms)
+            wsec = max(args.batches + 1, 3)
+            for name, wl, hw, w_, k_, extra in (('lidar_only_configs1', 'spvcnn', args.image_hw, wsec, 10, {}),
+                                                ('configs4_multisweep_bf16_1gpu', 'kd', args.image_hw, wsec, 10,
                                                  {'sweeps': 9, 'dtype': 'bf16', 'voxels': 300000, 'cr': 2.0, 'cr_t': 2.0})):
                 if wl == args.workload and tuple(hw) == tuple(args.image_hw) and not extra:
                     continue
@@ -607,7 +609,7 @@ def run_rank(args):
             if args.workload == 'kd':
                 if not args.no_full_size_images and tuple(args.image_hw) != (900, 1600):
                     sec['kd_6cam_900x1600'] = child_leg(
-                        args, ['--image-hw', '900', '1600', '--steps', '4', '--warmup', '2'],
+                        args, ['--image-hw', '900', '1600', '--steps', '6', '--warmup', str(max(args.batches + 1, 3))],
                         {'MIOPEN_FIND_MODE': 'FAST'},
                         'BASELINE.json configs[2] at the literal camera size 6 x 900x1600 (SURVEY 8d: "report both"); '
                         'child process, MIOPEN_FIND_MODE=FAST bounds the first-call kernel search')
