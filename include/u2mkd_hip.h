@@ -338,6 +338,13 @@ int u2mkd_segment_sum_bf16(const void *src /*bf16 [*,c]*/, int32_t c, const int3
 size_t u2mkd_csr_workspace_bytes(int64_t n_entries, int64_t nv);
 int u2mkd_csr_build(const int32_t *keys /*[n_entries]*/, int64_t n_entries, int64_t nv, void *workspace,
                     int32_t *order /*[n_entries]*/, int32_t *seg /*[nv+1]*/, u2mkd_stream_t s);
+/* The grouping the backward of u2mkd_devoxelize_forward sums over (core/models/utils.py:70-118 -> torchsparse v1.4.0
+ * devoxelize_backward_cuda, float atomics there): the 8 n (point, corner) entries with a voxel and a non-zero weight grouped by
+ * voxel row, ascending entry id inside a voxel, as (entry_row = point, entry_w = weight) [8 n] + seg [nv + 1] for
+ * u2mkd_segment_sum -- keys, u2mkd_csr_build and the gather of rows / weights in one call.                               */
+size_t u2mkd_devoxelize_plan_workspace_bytes(int64_t n, int64_t nv);
+int u2mkd_devoxelize_plan(const int32_t *idx8 /*[n,8]*/, const float *w8 /*[n,8]*/, int64_t n, int64_t nv, void *workspace,
+                          int32_t *entry_row /*[8n]*/, float *entry_w /*[8n]*/, int32_t *seg /*[nv+1]*/, u2mkd_stream_t s);
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
 
@@ -398,6 +405,25 @@ int u2mkd_select_mse_forward(const float *gathered, const float *pseudo, const u
 int u2mkd_select_mse_backward(const float *g_out, const float *g_loss, const float *stats, const float *gathered,
                               const float *pseudo, const uint8_t *fov, int64_t n, int32_t c, float *d_gathered, float *d_pseudo,
                               u2mkd_stream_t s);
+/* ---- Lovasz-softmax, classes = 'present' (csrc/lovasz.hip; core/criterions.py:40-52, 73-101) ------------------------------
+ * The element-wise chains around the sort of the per-class errors (the sort itself stays the caller's: any ascending sort of
+ * `keys` [c * n] returning positions).  probas [n, c] f32 (softmax output), labels [n] int64, rows with label == ignore_index
+ * do not count.  Order of calls: errors -> (sort keys) -> gather -> (inclusive prefix sum of fg_sorted over all c * n entries,
+ * int64) -> terms -> ... -> backward.
+ *   u2mkd_lovasz_errors    errors [c, n] = |fg - p| (-1 on ignored rows), keys [c, n] f64 = 4 class - error
+ *   u2mkd_lovasz_gather    fg_sorted [c * n] int32: the foreground flag of every sorted entry (perm = sorted positions)
+ *   u2mkd_lovasz_terms     jgrad [c * n] = the Jaccard gradient of every sorted entry (lovasz_grad), stats [2 + c] = (loss,
+ *                          1 / max(#present classes, 1), present flag per class); partial: u2mkd_lovasz_partials(n, c) floats
+ *   u2mkd_lovasz_backward  d_probas [n, c] = g_out * d loss / d probas (every element written, no atomics)                 */
+int u2mkd_lovasz_errors(const float *probas, const int64_t *labels, int32_t ignore_index, int64_t n, int32_t c, float *errors,
+                        double *keys, u2mkd_stream_t s);
+int u2mkd_lovasz_gather(const int64_t *perm, const int64_t *labels, int32_t ignore_index, int64_t n, int32_t c,
+                        int32_t *fg_sorted, u2mkd_stream_t s);
+int64_t u2mkd_lovasz_partials(int64_t n, int32_t c);
+int u2mkd_lovasz_terms(const int64_t *perm, const float *errors, const int64_t *csum, const int32_t *fg_sorted, int64_t n,
+                       int32_t c, float *jgrad, float *partial, float *stats, u2mkd_stream_t s);
+int u2mkd_lovasz_backward(const float *g_out, const float *stats, const int64_t *perm, const float *jgrad, const float *probas,
+                          const int64_t *labels, int32_t ignore_index, int64_t n, int32_t c, float *d_probas, u2mkd_stream_t s);
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
  * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and

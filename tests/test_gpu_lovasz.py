@@ -1,0 +1,83 @@
+"""csrc/lovasz.hip (the fused Lovasz-softmax) against the oracle's line-by-line restatement of core/criterions.py:40-101 and
+against the package's torch formulation; the fused devoxelise-backward plan against the torch ops it replaced."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from u2mkd_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _case(n, c, seed, ignore_frac=0.2, absent=()):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(n, c, generator=g) * 2
+    labels = torch.randint(1, c, (n,), generator=g)
+    for a in absent:
+        labels[labels == a] = 1 if a != 1 else 2
+    labels[torch.rand(n, generator=g) < ignore_frac] = 0
+    return logits, labels
+
+
+@pytest.mark.parametrize('n,c,seed,absent', [(1, 5, 0, ()), (257, 17, 1, (3, 9)), (5000, 17, 2, ()), (80000, 17, 3, (16,)), (300, 2, 4, ())])
+def test_fused_lovasz_equals_the_reference_formulation(hip, n, c, seed, absent):
+    from oracle import spvcnn_ref as O
+    from u2mkd_amd.losses import Lovasz_softmax, lovasz_softmax_flat
+    logits, labels = _case(n, c, seed, absent=absent)
+    # oracle: the reference's compacting formulation on the CPU (fp32, as the reference runs it)
+    x64 = logits.clone().requires_grad_(True)
+    valid = labels != 0
+    want = O.lovasz_softmax_flat(torch.softmax(x64, 1)[valid], labels[valid]) if bool(valid.any()) else x64.sum() * 0
+    want.backward()
+    xg = logits.cuda().requires_grad_(True)
+    got = Lovasz_softmax(ignore_index=0)(torch.softmax(xg, 1), labels.cuda())
+    got.backward()
+    assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * max(1.0, abs(float(want.detach()))), (float(got.detach()), float(want.detach()))
+    scale = float(x64.grad.abs().max()) + 1e-12
+    assert float((xg.grad.cpu() - x64.grad).abs().max()) <= 1e-4 * scale + 1e-9
+    # the package's torch formulation on the same device: same value to rounding, same gradient
+    xt = logits.cuda().requires_grad_(True)
+    ref = lovasz_softmax_flat(torch.softmax(xt, 1), labels.cuda(), labels.cuda() != 0)
+    ref.backward()
+    assert abs(float(got.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach())))
+    assert float((xg.grad - xt.grad).abs().max()) <= 2e-6 * float(xt.grad.abs().max()) + 1e-10
+    # deterministic
+    x2 = logits.cuda().requires_grad_(True)
+    again = Lovasz_softmax(ignore_index=0)(torch.softmax(x2, 1), labels.cuda())
+    again.backward()
+    assert torch.equal(again, got) and torch.equal(x2.grad, xg.grad)
+
+
+def test_fused_lovasz_all_rows_ignored(hip):
+    from u2mkd_amd.losses import Lovasz_softmax
+    x = torch.randn(100, 17, device='cuda', requires_grad=True)
+    loss = Lovasz_softmax(ignore_index=0)(torch.softmax(x, 1), torch.zeros(100, dtype=torch.long, device='cuda'))
+    loss.backward()
+    assert float(loss.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n,nv,seed', [(0, 10, 0), (1, 1, 1), (3000, 700, 2), (80000, 75000, 3)])
+def test_devoxelize_plan_equals_the_torch_ops(hip, n, nv, seed):
+    from u2mkd_amd import _lib as L
+    from u2mkd_amd.torchsparse.nn import functional as F
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(-1, nv, (n, 8), generator=g, dtype=torch.int32).cuda()
+    w = torch.rand(n, 8, generator=g).cuda()
+    w[torch.rand(n, 8, generator=g).cuda() < 0.2] = 0.
+    w[idx < 0] = 0.
+    erow = torch.empty(8 * n, dtype=torch.int32, device='cuda')
+    ew = torch.empty(8 * n, dtype=torch.float32, device='cuda')
+    seg = torch.empty(nv + 1, dtype=torch.int32, device='cuda')
+    ws = torch.empty(max(L.load().u2mkd_devoxelize_plan_workspace_bytes(n, nv), 16), dtype=torch.uint8, device='cuda')
+    L.call('u2mkd_devoxelize_plan', L.ptr(idx), L.ptr(w), n, nv, L.ptr(ws), L.ptr(erow), L.ptr(ew), L.ptr(seg), L.stream())
+    keys = torch.where(w != 0, idx, -1).view(-1)
+    order, seg_ref = F._csr_by_destination(keys, nv)
+    live = int(seg_ref[-1])
+    assert torch.equal(seg, seg_ref)
+    assert torch.equal(erow[:live], (order >> 3)[:live])
+    assert torch.equal(ew[:live], w.view(-1)[order.long()][:live])

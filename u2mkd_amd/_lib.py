@@ -147,7 +147,14 @@ SIGNATURES = {
     'u2mkd_upbn_stats': (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_upbn_dense_grad': (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_csr_workspace_bytes': (_sz, [_i64, _i64]),
+    'u2mkd_lovasz_errors': (C.c_int, [_p, _p, _i32, _i64, _i32, _p, _p, _p]),
+    'u2mkd_lovasz_gather': (C.c_int, [_p, _p, _i32, _i64, _i32, _p, _p]),
+    'u2mkd_lovasz_partials': (_i64, [_i64, _i32]),
+    'u2mkd_lovasz_terms': (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    'u2mkd_lovasz_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
     'u2mkd_csr_build': (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p]),
+    'u2mkd_devoxelize_plan_workspace_bytes': (C.c_size_t, [_i64, _i64]),
+    'u2mkd_devoxelize_plan': (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),
 }
 

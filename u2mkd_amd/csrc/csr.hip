@@ -181,6 +181,29 @@ csr_sort_long_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__res
 
 }  // namespace u2mkd
 
+namespace u2mkd {
+
+// keys of the trilinear devoxelisation's backward grouping: entry 8 i + j = corner j of point i, keyed by its voxel row or
+// dropped (-1) where the corner has no voxel or weight 0
+__global__ void devox_keys_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t e,
+                                  int32_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < e) keys[i] = w[i] != 0.f ? idx[i] : -1;
+}
+
+// the grouped entries as (point row, weight): entry order[g] = 8 i + j
+__global__ void devox_finish_kernel(const int32_t *__restrict__ order, const float *__restrict__ w, int64_t e,
+                                    int32_t *__restrict__ erow, float *__restrict__ ew) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < e) {
+        const int32_t o = order[g];
+        erow[g] = o >> 3;
+        ew[g] = w[o];
+    }
+}
+
+}  // namespace u2mkd
+
 using namespace u2mkd;
 
 extern "C" {
@@ -218,6 +241,25 @@ int u2mkd_csr_build(const int32_t *keys, int64_t n_entries, int64_t nv, void *wo
     const unsigned gl = (unsigned)std::min<int64_t>(nv, 2048);
     hipLaunchKernelGGL(csr_sort_long_kernel, dim3(gl), dim3(64), 0, st, seg, nv, order, scratch);
     return check_launch("u2mkd_csr_build");
+}
+
+size_t u2mkd_devoxelize_plan_workspace_bytes(int64_t n, int64_t nv) {
+    return u2mkd_csr_workspace_bytes(8 * n, nv) + (size_t)16 * n * sizeof(int32_t);
+}
+
+int u2mkd_devoxelize_plan(const int32_t *idx8, const float *w8, int64_t n, int64_t nv, void *workspace, int32_t *entry_row,
+                          float *entry_w, int32_t *seg, u2mkd_stream_t s) {
+    U2_REQUIRE(n >= 0 && nv >= 0, "u2mkd_devoxelize_plan: negative sizes");
+    U2_REQUIRE(seg && workspace && (n == 0 || (idx8 && w8 && entry_row && entry_w)), "u2mkd_devoxelize_plan: null pointer");
+    const int64_t e = 8 * n;
+    int32_t *keys = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + u2mkd_csr_workspace_bytes(e, nv));
+    int32_t *order = keys + e;
+    hipStream_t st = as_stream(s);
+    if (e) hipLaunchKernelGGL(devox_keys_kernel, dim3((unsigned)ceil_div(e, 256)), dim3(256), 0, st, idx8, w8, e, keys);
+    int rc = u2mkd_csr_build(keys, e, nv, workspace, order, seg, s);
+    if (rc) return rc;
+    if (e) hipLaunchKernelGGL(devox_finish_kernel, dim3((unsigned)ceil_div(e, 256)), dim3(256), 0, st, order, w8, e, entry_row, entry_w);
+    return check_launch("u2mkd_devoxelize_plan");
 }
 
 }  // extern "C"

@@ -66,6 +66,47 @@ def lovasz_softmax_flat(probas: torch.Tensor, labels: torch.Tensor, valid: torch
     return (per_class * present).sum() / present.sum().clamp(min=1.)
 
 
+class _LovaszFunction(torch.autograd.Function):
+    """lovasz_softmax_flat(probas, labels, labels != ignore_index) on csrc/lovasz.hip: the element-wise chains around the sort as
+    three launches forward and one backward (the torch formulation above: ~45 + ~18 launches, twice per KD step, between the
+    forward and the backward of the critical stream).  Same arithmetic per element; the final sums in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, probas, labels, ignore_index):
+        from . import _lib as L
+        P, C = probas.shape
+        probas = probas.contiguous().float()
+        labels = labels.contiguous().long()
+        dev = probas.device
+        st = L.stream()
+        errors = torch.empty(C, P, dtype=torch.float32, device=dev)
+        keys = torch.empty(C, P, dtype=torch.float64, device=dev)
+        L.call('u2mkd_lovasz_errors', L.ptr(probas), L.ptr(labels), int(ignore_index), P, C, L.ptr(errors), L.ptr(keys), st)
+        perm = torch.sort(keys.view(-1))[1]
+        fg_sorted = torch.empty(C * P, dtype=torch.int32, device=dev)
+        L.call('u2mkd_lovasz_gather', L.ptr(perm), L.ptr(labels), int(ignore_index), P, C, L.ptr(fg_sorted), st)
+        csum = fg_sorted.cumsum(0)                                  # int64: exact
+        jgrad = torch.empty(C * P, dtype=torch.float32, device=dev)
+        partial = torch.empty(int(L.load().u2mkd_lovasz_partials(P, C)), dtype=torch.float32, device=dev)
+        stats = torch.empty(2 + C, dtype=torch.float32, device=dev)
+        L.call('u2mkd_lovasz_terms', L.ptr(perm), L.ptr(errors), L.ptr(csum), L.ptr(fg_sorted), P, C, L.ptr(jgrad), L.ptr(partial),
+               L.ptr(stats), st)
+        ctx.save_for_backward(probas, labels, perm, jgrad, stats)
+        ctx.ignore_index = int(ignore_index)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        probas, labels, perm, jgrad, stats = ctx.saved_tensors
+        P, C = probas.shape
+        g = g.contiguous().float().reshape(1)
+        d = torch.empty_like(probas)
+        L.call('u2mkd_lovasz_backward', L.ptr(g), L.ptr(stats), L.ptr(perm), L.ptr(jgrad), L.ptr(probas), L.ptr(labels),
+               ctx.ignore_index, P, C, L.ptr(d), L.stream())
+        return d, None, None
+
+
 class Lovasz_softmax(nn.Module):
     def __init__(self, classes='present', ignore_index=0):
         super().__init__()
@@ -73,6 +114,9 @@ class Lovasz_softmax(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, probas, labels):
+        if (probas.is_cuda and probas.dim() == 2 and probas.dtype == torch.float32 and 0 < probas.shape[0] < (1 << 24)
+                and probas.shape[1] <= 4096 and -2 ** 31 <= self.ignore_index < 2 ** 31):
+            return _LovaszFunction.apply(probas, labels, self.ignore_index)
         return lovasz_softmax_flat(probas, labels, labels != self.ignore_index)
 
 

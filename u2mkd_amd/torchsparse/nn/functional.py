@@ -215,9 +215,14 @@ class DevoxelizeFunction(Function):
             return torch.zeros(nv, c, dtype=g.dtype, device=g.device), None, None
         if c % 4 == 0:
             def build():
-                keys = torch.where(weights != 0, coords, -1).view(-1)          # [n*8], zero-weight corners dropped
-                order, seg = _csr_by_destination(keys, nv)
-                return (order >> 3).contiguous(), weights.view(-1)[order.long()].contiguous(), seg
+                # zero-weight corners dropped, the rest grouped by voxel: keys + counting sort + (row, weight) in one call
+                erow = torch.empty(8 * n, dtype=torch.int32, device=g.device)
+                ew = torch.empty(8 * n, dtype=torch.float32, device=g.device)
+                seg = torch.empty(nv + 1, dtype=torch.int32, device=g.device)
+                ws = torch.empty(max(L.load().u2mkd_devoxelize_plan_workspace_bytes(n, nv), 16), dtype=torch.uint8, device=g.device)
+                L.call('u2mkd_devoxelize_plan', L.ptr(coords), L.ptr(weights), n, nv, L.ptr(ws), L.ptr(erow), L.ptr(ew), L.ptr(seg),
+                       L.stream())
+                return erow, ew, seg
             erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build, weights)
             gi = _segment_sum(g, erow, ew, seg, nv, False)
         else:
