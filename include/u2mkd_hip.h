@@ -52,6 +52,9 @@ size_t u2mkd_hash_table_bytes(int64_t n_refs);
 int u2mkd_hash_table_build(const int64_t *refs, int64_t n_refs, void *table, u2mkd_stream_t s);
 int u2mkd_hash_table_query(const void *table, int64_t n_refs, const int64_t *queries, int64_t n_q,
                            int64_t *out /*[n_q] index or -1*/, u2mkd_stream_t s);
+/* the same with an int32 copy of the result (indices fit: n_refs < 2^31): what the voxelise / count kernels read */
+int u2mkd_hash_table_query2(const void *table, int64_t n_refs, const int64_t *queries, int64_t n_q, int64_t *out,
+                            int32_t *out32, u2mkd_stream_t s);
 
 /* ---- kernel map (rulebook) ---------------------------------------------
  * replaces the kmap build of torchsparse F.conv3d (python: sphash(offsets) +

@@ -25,6 +25,7 @@ SIGNATURES = {
     'u2mkd_hash_table_bytes': (_sz, [_i64]),
     'u2mkd_hash_table_build': (C.c_int, [_p, _i64, _p, _p]),
     'u2mkd_hash_table_query': (C.c_int, [_p, _i64, _p, _i64, _p, _p]),
+    'u2mkd_hash_table_query2': (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
     'u2mkd_kmap_build_table': (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _p]),
     'u2mkd_kmap_invert': (C.c_int, [_p, _i64, _i32, _i64, _p, _p]),
     'u2mkd_kmap_sizes': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),

@@ -54,9 +54,13 @@ __global__ void table_insert_kernel(TableView t, const int64_t *__restrict__ ref
 }
 
 __global__ void table_query_kernel(TableView t, const int64_t *__restrict__ q, int64_t n,
-                                   int64_t *__restrict__ out) {
+                                   int64_t *__restrict__ out, int32_t *__restrict__ out32 = nullptr) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int64_t)table_lookup(t, q[i]);
+    if (i < n) {
+        const int64_t v = (int64_t)table_lookup(t, q[i]);
+        out[i] = v;
+        if (out32) out32[i] = (int32_t)v;
+    }
 }
 
 // Fused kernel_hash + query: nbr[k][j] = index of (out_coords[j] + offsets[k]) or -1.
@@ -317,6 +321,16 @@ int u2mkd_hash_table_query(const void *table, int64_t n_refs, const int64_t *que
     hipLaunchKernelGGL(table_query_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, as_stream(s), t,
                        queries, n_q, out);
     return check_launch("u2mkd_hash_table_query");
+}
+
+int u2mkd_hash_table_query2(const void *table, int64_t n_refs, const int64_t *queries, int64_t n_q, int64_t *out,
+                            int32_t *out32, u2mkd_stream_t s) {
+    if (n_q == 0) return 0;
+    U2_REQUIRE(table && queries && out && out32, "u2mkd_hash_table_query2: null pointer");
+    TableView t = make_table_view(const_cast<void *>(table), n_refs);
+    hipLaunchKernelGGL(table_query_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, as_stream(s), t,
+                       queries, n_q, out, out32);
+    return check_launch("u2mkd_hash_table_query2");
 }
 
 int u2mkd_kmap_build_table(const void *table, int64_t n_refs, const int32_t *out_coords, int64_t n_out,

@@ -179,7 +179,7 @@ class StudentMSP2IFM(nn.Module):
                 cam = on_side(lambda: cam_stage(x_im, idx), x_im)      # queued ahead of this stage's LiDAR kernels
             vox_out = self.vox_downs[idx](vox_feats[idx])
             tmp_p = point_to_voxel(vox_out, zz)
-            coord_xyz, batch = tmp_p.F[:, :3], tmp_p.C[:, 3]
+            coord_xyz, batch = tmp_p.F[:, :3].contiguous(), tmp_p.C[:, 3]      # (one copy: the plan kernels need contiguous rows)
             vox_out.F = self.transformer_blocks[idx](vox_out.F, coord_xyz, batch)
             pts_feat = voxel_to_point(vox_out, z0)
             if idx == n_stage - 1:

@@ -134,8 +134,8 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     cache = z.additional_features
     if cache is None or cache.get('idx_query') is None or cache['idx_query'].get(x.s) is None:
         pc_hash = spf.sphash(_floor_coords(z.C, x.s[0]))
-        idx_query = spf.HashTable(spf.sphash(x.C)).query(pc_hash)
-        counts = spf.spcount(idx_query.int(), x.C.shape[0])
+        idx_query = spf.HashTable(spf.sphash(x.C)).query_with_i32(pc_hash)
+        counts = spf.spcount(spf._plan(idx_query, 'i32', lambda: idx_query.int().contiguous()), x.C.shape[0])
         z.additional_features['idx_query'][x.s] = idx_query
         z.additional_features['counts'][x.s] = counts
     else:

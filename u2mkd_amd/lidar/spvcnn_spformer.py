@@ -105,7 +105,7 @@ class SPVCNN_SPFORMER(nn.Module):
         for idx, down in enumerate(self.vox_downs):
             vox_out = down(feats[idx])
             tmp_p = point_to_voxel(vox_out, zz)       # mean metric xyz (+ intensity) per coarse voxel
-            coord_xyz, batch = tmp_p.F[:, :3], tmp_p.C[:, 3]
+            coord_xyz, batch = tmp_p.F[:, :3].contiguous(), tmp_p.C[:, 3]      # (one copy: the plan kernels need contiguous rows)
             vox_out.F = self.transformer_blocks[idx](vox_out.F, coord_xyz, batch)
             feats.append(vox_out)
             if idx == 3 and self.return_pts_feats:

@@ -74,6 +74,18 @@ class HashTable:
         L.call('u2mkd_hash_table_query', L.ptr(self.buf), self.n, L.ptr(q), q.numel(), L.ptr(out), L.stream())
         return out
 
+    def query_with_i32(self, queries: torch.Tensor) -> torch.Tensor:
+        """``query`` whose result carries its int32 copy (the form the voxelise / count kernels read) as the cached 'i32'
+        plan of the returned tensor: one launch instead of the query and a conversion per consumer."""
+        L.require_cuda(queries)
+        assert queries.dtype == torch.int64
+        q = queries.contiguous()
+        out = torch.empty_like(q)
+        out32 = torch.empty(q.shape, dtype=torch.int32, device=q.device)
+        L.call('u2mkd_hash_table_query2', L.ptr(self.buf), self.n, L.ptr(q), q.numel(), L.ptr(out), L.ptr(out32), L.stream())
+        out.__dict__.setdefault('_u2mkd_plans', {})['i32'] = ((out._version,), out32)
+        return out
+
 
 def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
     """Index of every query hash in ``references`` (-1 on miss), query shape kept."""
@@ -517,14 +529,15 @@ class PairSchedule:
         self.k, self.n_in, self.n_out = k, n_in, n_out
         self.cap = int(lib.u2mkd_pairs_capacity(n_in, n_out, k))
         nblocks = max((n_out + 1023) // 1024, 1)
-        nbsizes = torch.zeros(k, dtype=torch.int32, device=dev)
+        zeros = torch.zeros(k + 2, dtype=torch.int32, device=dev)      # (one fill for both zero-initialised pieces)
+        nbsizes = zeros[:k]
         block_counts = torch.empty(k, nblocks, dtype=torch.int32, device=dev)
         self.pair_in = torch.empty(self.cap, dtype=torch.int32, device=dev)
         self.pair_out = torch.empty(self.cap, dtype=torch.int32, device=dev)
         self.pos_out = torch.empty(n_out, k, dtype=torch.int32, device=dev)
         self.pos_in = torch.full((n_in, k), -1, dtype=torch.int32, device=dev)
         self.tile_k = torch.empty(self.cap // 64, dtype=torch.int32, device=dev)
-        self.meta = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.meta = zeros[k:]
         if n_out and n_in:
             st = L.stream()
             L.call('u2mkd_kmap_sizes', L.ptr(nbr), n_out, k, L.ptr(nbsizes), L.ptr(block_counts), st)
