@@ -66,21 +66,35 @@ def _free_port():
     return p
 
 
+def _run_ranks(child, outs, env, timeout, extra=()):
+    """Two ranks of ``child`` on a free rendezvous port; a port that another process took between the probe and the bind
+    (EADDRINUSE: seen once in ~50 suite runs) gets a second and a third try on a new one."""
+    for attempt in range(3):
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, '-c', child, ROOT, str(r), str(len(outs)), str(port), outs[r], *extra], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(len(outs))]
+        errs = []
+        for p in procs:
+            try:
+                _, err = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            errs.append(err)
+        if all(p.returncode == 0 for p in procs):
+            return
+        if attempt < 2 and any('EADDRINUSE' in e or 'address already in use' in e for e in errs):
+            continue
+        for p, err in zip(procs, errs):
+            assert p.returncode == 0, err[-3000:]
+
+
 @pytest.mark.timeout(600)
 def test_hip_sync_batchnorm_two_ranks_equals_batchnorm_over_all_rows(hip, tmp_path):
-    port = _free_port()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     outs = [str(tmp_path / f'r{r}.pt') for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, '-c', _CHILD, ROOT, str(r), '2', str(port), outs[r]], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        try:
-            _, err = p.communicate(timeout=400)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, err[-3000:]
+    _run_ranks(_CHILD, outs, env, 400)
     got = [torch.load(o) for o in outs]
     # ---- oracle: one process, all rows, fp64
     C, rows = 64, (1500, 377)
@@ -183,20 +197,10 @@ def test_two_rank_ddp_step_equals_one_process_on_both_scenes(hip, tmp_path):
     from u2mkd_amd import lidar, torchsparse as ts
     from u2mkd_amd.losses import MixLovaszCrossEntropy
     from u2mkd_amd.synth import synth_batch
-    port = _free_port()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
                                                             'U2MKD_FORCE_DDP', 'U2MKD_FORCE_SYNC_BN')}
     outs = [str(tmp_path / f'd{r}.pt') for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_DDP, ROOT, str(r), '2', str(port), outs[r]], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        try:
-            _, err = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, err[-3000:]
+    _run_ranks(_CHILD_DDP, outs, env, 600)
     got = [torch.load(o) for o in outs]
     for n in got[0]['grads']:
         assert torch.equal(got[0]['grads'][n], got[1]['grads'][n]), n               # all-reduced: the same on both ranks
@@ -270,19 +274,9 @@ def test_hip_sync_batchnorm2d_two_ranks_equals_batchnorm2d_over_all_images(hip, 
     """The camera branch's BatchNorm2d under DDP (SyncBatchNorm2d on the csrc/bn2d.hip pieces, ReLU / residual fused):
     two processes with 3 and 2 images against ONE fp64 nn.BatchNorm2d over all 5 -- y, dx, the residual gradient, the
     per-rank dgamma / dbeta, the running statistics with the global count."""
-    port = _free_port()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     outs = [str(tmp_path / f'q{r}.pt') for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_2D, ROOT, str(r), '2', str(port), outs[r]], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        try:
-            _, err = p.communicate(timeout=400)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, err[-3000:]
+    _run_ranks(_CHILD_2D, outs, env, 400)
     got = [torch.load(o) for o in outs]
     C, shapes = 24, ((3, 20, 36), (2, 20, 36))
     g = torch.Generator().manual_seed(11)
@@ -370,19 +364,9 @@ def test_sampled_pixel_head_two_ranks_equals_the_dense_head_over_both_samples(hi
     from test_gpu_pixel_head import _dense_fp64
     from u2mkd_amd import camera
     from u2mkd_amd.synth import synth_kd_batch
-    port = _free_port()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     outs = [str(tmp_path / f'h{r}.pt') for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, '-c', _CHILD_HEAD, ROOT, str(r), '2', str(port), outs[r]], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        try:
-            _, err = p.communicate(timeout=400)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, err[-3000:]
+    _run_ranks(_CHILD_HEAD, outs, env, 400)
     got = [torch.load(o) for o in outs]
     hw, low, c, classes, ncam = (64, 112), (32, 56), 32, 17, 6
     b = synth_kd_batch(900, 2, seed=9, image_hw=hw)['student']

@@ -420,14 +420,18 @@ def _range_flag(device):
 
 
 # -------------------------------------------------------------- kernel maps
-def _pairs_mode(cin, cout):
-    """Schedule choice, measured on MI355X over the SPVCNN layer shapes (tools/ab_hybrid.py):
+def _pairs_mode(cin, cout, n_rows=0):
+    """Schedule choice, measured on MI355X over the SPVCNN layer shapes (tools/ab_schedule.py):
     the pair schedule wins from 96x96 channels up (2x at 256x256), the tile schedule below
-    (the pair schedule's extra round trip of P x cout floats costs more than it saves)."""
+    (the pair schedule's extra round trip of P x cout floats costs more than it saves).  At the boundary itself (64 x 128,
+    128 x 64) the tile schedule wins on the large voxel sets (80k rows: 58-66 us against 71-88 us) and loses on the small ones
+    (16k rows: 37-43 us against 34 us)."""
     env = os.environ.get('U2MKD_CONV_SCHEDULE')
     if env in ('tiles', 'pairs'):
         return env == 'pairs'
-    return cin * cout >= 8192 and cout % 4 == 0
+    if cout % 4:
+        return False
+    return cin * cout > 8192 or (cin * cout == 8192 and n_rows < 24000)
 
 
 # wide layers on the bf16x3 pair kernel (csrc/conv_px3.hip); U2MKD_PAIRS_X3=0 keeps them on the f32-MFMA pair kernel
@@ -727,7 +731,7 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
         # bf16 storage, every shape the tile kernel has no instantiation for (_conv_bf16_ok: multiples of 32)
         wt = _weight_layout(weight, transpose, True, arith=3)
         return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
-    if feats.dtype != torch.bfloat16 and _pairs_mode(feats.shape[1], cout):
+    if feats.dtype != torch.bfloat16 and _pairs_mode(feats.shape[1], cout, n_rows):
         x3 = _PAIRS_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(feats.shape[1], cout))
         wt = _weight_layout(weight, transpose, x3)
         return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3)
