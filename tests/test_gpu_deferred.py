@@ -1,0 +1,95 @@
+"""Weight gradients that are joined at the end of the backward (u2mkd_amd/deferred.py): the gradients a caller reads after
+``backward()`` equal those of the inline formulation, also when a parameter already holds a gradient (accumulation) and when a
+hook reads ``.grad`` during the backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from u2mkd_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _spvcnn_grads(overlap, steps=2):
+    from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    from u2mkd_amd.synth import synth_batch
+    from u2mkd_amd.torchsparse.nn import functional as F
+    old = F._OVERLAP_WGRAD
+    F._OVERLAP_WGRAD = overlap
+    try:
+        torch.manual_seed(3)
+        model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+        crit = MixLovaszCrossEntropy(ignore_index=0)
+        b = synth_batch(6000, 1, seed=5)
+        feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+        out = []
+        for _ in range(steps):          # the second pass ACCUMULATES into existing gradients (the inline path of _wgrad_side)
+            loss = crit(model({'lidar': ts.SparseTensor(feats, coords)})['x_vox'], labels)
+            loss.backward()
+            out.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        return out
+    finally:
+        F._OVERLAP_WGRAD = old
+
+
+def test_deferred_weight_gradients_equal_the_inline_ones(hip):
+    a = _spvcnn_grads(True)
+    b = _spvcnn_grads(False)
+    assert a[0].keys() == b[0].keys() and len(a[0]) > 50
+    for step in range(2):
+        for n in a[step]:
+            assert torch.equal(a[step][n], b[step][n]), (step, n)
+
+
+def test_a_hook_that_joins_reads_finished_gradients(hip):
+    """distributed.BucketedGradientAverage's protocol: a post-accumulate hook calls deferred.join() before it reads .grad."""
+    from u2mkd_amd import deferred, lidar, torchsparse as ts
+    from u2mkd_amd.synth import synth_batch
+    torch.manual_seed(4)
+    model = lidar.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05).cuda().train()
+    b = synth_batch(6000, 1, seed=6)
+    feats, coords = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords'))
+    seen = {}
+
+    def hook(p):
+        deferred.join()
+        seen[id(p)] = p.grad.clone()
+    handles = [p.register_post_accumulate_grad_hook(hook) for p in model.parameters()]
+    model({'lidar': ts.SparseTensor(feats, coords)})['x_vox'].square().mean().backward()
+    torch.cuda.synchronize()
+    for h in handles:
+        h.remove()
+    n = 0
+    for p in model.parameters():
+        if p.grad is not None:
+            assert torch.equal(seen[id(p)], p.grad)
+            n += 1
+    assert n > 50
+
+
+def test_camera_conv2d_equals_nn_conv2d(hip):
+    from u2mkd_amd.camera import Conv2d
+    torch.manual_seed(0)
+    for cin, cout, k, stride in ((64, 64, 3, 1), (64, 128, 3, 2), (128, 128, 1, 1), (3, 64, 7, 1)):
+        conv = Conv2d(cin, cout, k, stride, k // 2, bias=False).cuda()
+        ref = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).cuda()
+        ref.weight.data.copy_(conv.weight.data)
+        x = torch.randn(2, cin, 45, 80, device='cuda')
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        g = torch.randn_like(ref(xb))
+        ya = conv(xa)
+        ya.backward(g)
+        ref(xb).backward(g)
+        torch.cuda.synchronize()
+        assert torch.allclose(ya, ref(xb), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=2e-3 * float(ref.weight.grad.abs().max()))
+        # a second backward accumulates: the inline path
+        conv(xa).backward(g)
+        ref(xb).backward(g)
+        assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=2e-3 * float(ref.weight.grad.abs().max()))
