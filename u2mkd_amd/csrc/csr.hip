@@ -17,14 +17,16 @@ constexpr int kCsrThreads = 256;
 constexpr int kScanBlock = 2048;            // elements per scan block (256 threads x 8)
 
 __global__ void __launch_bounds__(kCsrThreads)
-csr_count_kernel(const int32_t *__restrict__ keys, int64_t e, int64_t nv, int32_t *__restrict__ counts) {
+csr_count_kernel(const int32_t *__restrict__ keys, int64_t e, int64_t nv, int32_t *__restrict__ counts,
+                 int32_t *__restrict__ order) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e) return;
+    order[i] = 0;                            // entries past seg[nv] stay a valid index (the placement fills the live ones)
     const int k = keys[i];
     if (k >= 0 && k < nv) atomicAdd(&counts[k], 1);
 }
 
-// exclusive scan, three small launches: per-block sums, one block scans them, per-block scan with its offset
+// exclusive scan, two small launches: per-block sums, per-block scan behind the sum of the preceding blocks' sums
 __global__ void __launch_bounds__(kCsrThreads)
 csr_block_sums_kernel(const int32_t *__restrict__ counts, int64_t nv, int32_t *__restrict__ block_sums) {
     __shared__ int s[kCsrThreads / 64];
@@ -43,35 +45,27 @@ csr_block_sums_kernel(const int32_t *__restrict__ counts, int64_t nv, int32_t *_
 }
 
 __global__ void __launch_bounds__(kCsrThreads)
-csr_scan_sums_kernel(int32_t *__restrict__ block_sums, int nb, int32_t *__restrict__ total) {
-    // one workgroup: serial chunks of 256 with a running carry (nb <= a few hundred)
-    __shared__ int s[kCsrThreads];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += kCsrThreads) {
-        const int i = b0 + threadIdx.x;
-        const int v = i < nb ? block_sums[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < kCsrThreads; off <<= 1) {      // Hillis-Steele inclusive scan
-            const int add = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += add;
-            __syncthreads();
+csr_scan_blocks_kernel(const int32_t *__restrict__ counts, int64_t nv, const int32_t *__restrict__ block_sums, int nb,
+                       int32_t *__restrict__ seg /*[nv+1]*/, int32_t *__restrict__ cursor) {
+    // this block's offset = the sums of the blocks before it (nb <= a few hundred: summed here instead of by a one-workgroup
+    // scan launch in between); block 0 also takes the grand total = seg[nv]
+    __shared__ int s_pre[kCsrThreads / 64], s_tot[kCsrThreads / 64];
+    {
+        int pre = 0, tot = 0;
+        for (int b = threadIdx.x; b < nb; b += kCsrThreads) {
+            const int v = block_sums[b];
+            tot += v;
+            pre += b < (int)blockIdx.x ? v : 0;
         }
-        const int c = carry;
-        if (i < nb) block_sums[i] = c + s[threadIdx.x] - v;     // exclusive
-        __syncthreads();
-        if (threadIdx.x == kCsrThreads - 1) carry = c + s[threadIdx.x];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            pre += __shfl_down(pre, off);
+            tot += __shfl_down(tot, off);
+        }
+        if ((threadIdx.x & 63) == 0) { s_pre[threadIdx.x >> 6] = pre; s_tot[threadIdx.x >> 6] = tot; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ void __launch_bounds__(kCsrThreads)
-csr_scan_blocks_kernel(const int32_t *__restrict__ counts, int64_t nv, const int32_t *__restrict__ block_sums,
-                       const int32_t *__restrict__ total, int32_t *__restrict__ seg /*[nv+1]*/, int32_t *__restrict__ cursor) {
+    const int block_off = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
     // thread t owns 8 consecutive elements: local prefix, wave scan, workgroup scan
     __shared__ int s[kCsrThreads / 64];
     const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * 8;
@@ -92,7 +86,7 @@ csr_scan_blocks_kernel(const int32_t *__restrict__ counts, int64_t nv, const int
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += s[w];
-    int run = block_sums[blockIdx.x] + woff + incl - sum;
+    int run = block_off + woff + incl - sum;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         if (base + j < nv) {
@@ -101,7 +95,7 @@ csr_scan_blocks_kernel(const int32_t *__restrict__ counts, int64_t nv, const int
         }
         run += v[j];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) seg[nv] = *total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) seg[nv] = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
 }
 
 __global__ void __launch_bounds__(kCsrThreads)
@@ -113,33 +107,34 @@ csr_place_kernel(const int32_t *__restrict__ keys, int64_t e, int64_t nv, int32_
     if (k >= 0 && k < nv) order[atomicAdd(&cursor[k], 1)] = (int32_t)i;
 }
 
-// ascending entry ids inside every segment.  One thread per segment for short segments (insertion sort in
-// place), one wave per long segment (rank by counting into LDS / a scratch copy).
+// ascending entry ids inside every segment.  One thread per segment for short segments (insertion sort in place), one
+// workgroup per long segment (bitonic sort in LDS).
 constexpr int kShortSeg = 24;
 
-__global__ void __launch_bounds__(kCsrThreads)
-csr_sort_short_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order) {
-    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv) return;
-    const int b = seg[v], n = seg[v + 1] - b;
-    if (n < 2 || n > kShortSeg) return;
-    int32_t *o = order + b;
-    for (int i = 1; i < n; ++i) {
-        const int x = o[i];
-        int j = i - 1;
-        while (j >= 0 && o[j] > x) { o[j + 1] = o[j]; --j; }
-        o[j + 1] = x;
-    }
-}
-
-// long segments: wave w scans the segment list for segments longer than kShortSeg (grid-stride over segments, one
-// wave per candidate); entries are ranked by counting (ids are distinct) and rewritten through LDS in chunks
+// One launch: the first `short_blocks` workgroups sort the short segments (a thread per segment), the rest walk the long ones
+// (a workgroup per candidate, grid-stride).
 constexpr int kLongChunk = 2048;
-__global__ void __launch_bounds__(64)
-csr_sort_long_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order, int32_t *__restrict__ scratch) {
+__global__ void __launch_bounds__(kCsrThreads)
+csr_sort_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order, int32_t *__restrict__ scratch,
+                int short_blocks) {
     __shared__ int s_in[kLongChunk];
-    const int lane = threadIdx.x;
-    for (int64_t v = blockIdx.x; v < nv; v += gridDim.x) {
+    if ((int)blockIdx.x < short_blocks) {
+        int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (v >= nv) return;
+        const int b = seg[v], n = seg[v + 1] - b;
+        if (n < 2 || n > kShortSeg) return;
+        int32_t *o = order + b;
+        for (int i = 1; i < n; ++i) {
+            const int x = o[i];
+            int j = i - 1;
+            while (j >= 0 && o[j] > x) { o[j + 1] = o[j]; --j; }
+            o[j + 1] = x;
+        }
+        return;
+    }
+    const int lane = threadIdx.x, nl = kCsrThreads;
+    const int first = (int)blockIdx.x - short_blocks, stride = (int)gridDim.x - short_blocks;
+    for (int64_t v = first; v < nv; v += stride) {
         const int b = seg[v], n = seg[v + 1] - b;
         if (n <= kShortSeg) continue;
         int32_t *o = order + b;
@@ -149,26 +144,26 @@ csr_sort_long_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__res
             // LiDAR -> camera grid: 55 k against 1 M)
             int m = 64;
             while (m < n) m <<= 1;
-            for (int i = lane; i < m; i += 64) s_in[i] = i < n ? o[i] : 0x7fffffff;
+            for (int i = lane; i < m; i += nl) s_in[i] = i < n ? o[i] : 0x7fffffff;
             __syncthreads();
             for (int k = 2; k <= m; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = lane; t < (m >> 1); t += 64) {
+                    for (int t = lane; t < (m >> 1); t += nl) {
                         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;      // the t-th pair at distance j
-                        const int a = s_in[lo], b = s_in[hi];
+                        const int a = s_in[lo], b2 = s_in[hi];
                         const bool up = (lo & k) == 0;
-                        if ((a > b) == up) { s_in[lo] = b; s_in[hi] = a; }
+                        if ((a > b2) == up) { s_in[lo] = b2; s_in[hi] = a; }
                     }
                     __syncthreads();
                 }
             }
-            for (int i = lane; i < n; i += 64) o[i] = s_in[i];
+            for (int i = lane; i < n; i += nl) o[i] = s_in[i];
             __syncthreads();
         } else {      // (never on the U2MKD scenes: thousands of entries on one destination) rank against global memory
             int32_t *tmp = scratch + b;
-            for (int i = lane; i < n; i += 64) tmp[i] = o[i];
+            for (int i = lane; i < n; i += nl) tmp[i] = o[i];
             __syncthreads();
-            for (int i = lane; i < n; i += 64) {
+            for (int i = lane; i < n; i += nl) {
                 const int x = tmp[i];
                 int r = 0;
                 for (int j = 0; j < n; ++j) r += tmp[j] < x;
@@ -230,16 +225,14 @@ int u2mkd_csr_build(const int32_t *keys, int64_t n_entries, int64_t nv, void *wo
     int32_t *total = block_sums + nb;
     int32_t *scratch = total + 2;
     (void)hipMemsetAsync(counts, 0, (size_t)nv * sizeof(int32_t), st);
-    (void)hipMemsetAsync(order, 0, (size_t)n_entries * sizeof(int32_t), st);      // entries past seg[nv] stay a valid index (0)
     const unsigned ge = (unsigned)ceil_div(n_entries, kCsrThreads);
-    hipLaunchKernelGGL(csr_count_kernel, dim3(ge), dim3(kCsrThreads), 0, st, keys, n_entries, nv, counts);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(ge), dim3(kCsrThreads), 0, st, keys, n_entries, nv, counts, order);
     hipLaunchKernelGGL(csr_block_sums_kernel, dim3(nb), dim3(kCsrThreads), 0, st, counts, nv, block_sums);
-    hipLaunchKernelGGL(csr_scan_sums_kernel, dim3(1), dim3(kCsrThreads), 0, st, block_sums, nb, total);
-    hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(nb), dim3(kCsrThreads), 0, st, counts, nv, block_sums, total, seg, cursor);
+    hipLaunchKernelGGL(csr_scan_blocks_kernel, dim3(nb), dim3(kCsrThreads), 0, st, counts, nv, block_sums, nb, seg, cursor);
     hipLaunchKernelGGL(csr_place_kernel, dim3(ge), dim3(kCsrThreads), 0, st, keys, n_entries, nv, cursor, order);
-    hipLaunchKernelGGL(csr_sort_short_kernel, dim3((unsigned)ceil_div(nv, kCsrThreads)), dim3(kCsrThreads), 0, st, seg, nv, order);
-    const unsigned gl = (unsigned)std::min<int64_t>(nv, 2048);
-    hipLaunchKernelGGL(csr_sort_long_kernel, dim3(gl), dim3(64), 0, st, seg, nv, order, scratch);
+    const int gs = (int)ceil_div(nv, kCsrThreads);
+    const int gl = (int)std::min<int64_t>(nv, 512);
+    hipLaunchKernelGGL(csr_sort_kernel, dim3((unsigned)(gs + gl)), dim3(kCsrThreads), 0, st, seg, nv, order, scratch, gs);
     return check_launch("u2mkd_csr_build");
 }
 
