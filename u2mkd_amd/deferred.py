@@ -43,6 +43,11 @@ def side_for(role: str, device: torch.device, owner=None) -> torch.cuda.Stream:
     return side
 
 
+def pending():
+    """The side streams with booked, not yet joined work (a caller may queue more work behind them there)."""
+    return list(_PENDING.values())
+
+
 def join():
     """The current stream waits for every side stream with booked work."""
     for key, side in list(_PENDING.items()):

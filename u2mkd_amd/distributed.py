@@ -151,24 +151,37 @@ class BucketedGradientAverage(torch.nn.Module):
             self._reduce(b)
 
     def _reduce(self, b):
-        """Flatten the bucket and start its all-reduce from the stream the completing gradient arrived on (no stream of
-        our own: the step already keeps the GPU's hardware queues busy with its four streams, a fifth one shares a queue
-        with one of them and serialises it -- measured +10 ms per step).  The other producing streams are joined by one
-        event each, recorded now: it covers every gradient that stream has produced so far."""
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
+        """Flatten the bucket and start its all-reduce.  No stream of our own (a sixth busy stream costs the step 50 ms,
+        deferred.py).  When weight gradients are still running on their side stream (deferred.py: they are joined at the END
+        of the backward) the bucket goes THERE, behind them: the stream the completing gradient arrived on -- the backward's
+        critical one -- is not made to wait in the middle of the backward.  Otherwise it goes to the arriving stream.  Every
+        other stream that produced one of the bucket's gradients is joined by an event recorded now: it covers what that
+        stream has produced so far."""
         with torch.no_grad():
-            if self._on_gpu:
-                from . import deferred
-                deferred.join()                   # gradients still running on a side stream of their own (camera.Conv2d)
-                cur = torch.cuda.current_stream()
-                for sid, st in b['streams'].items():
-                    if sid != cur.stream_id:
-                        cur.wait_event(st.record_event())
-            torch._foreach_copy_(b['views'], grads)
-            if self._world > 1:
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
-            if self._on_gpu:
-                b['done'] = cur.record_event()
+            if not self._on_gpu:
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
+                torch._foreach_copy_(b['views'], grads)
+                if self._world > 1:
+                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
+                b['pending'] = -1
+                return
+            from . import deferred
+            cur = torch.cuda.current_stream()
+            pend = deferred.pending()
+            run = pend[0] if pend else cur
+            if run is not cur:
+                run.wait_event(cur.record_event())
+                for other in pend[1:]:
+                    run.wait_event(other.record_event())
+            for sid, st in b['streams'].items():
+                if sid != run.stream_id:
+                    run.wait_event(st.record_event())
+            with torch.cuda.stream(run):
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
+                torch._foreach_copy_(b['views'], grads)
+                if self._world > 1:
+                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
+                b['done'] = run.record_event()
         b['pending'] = -1                         # launched
 
     def _finish(self):
