@@ -9,9 +9,20 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope='module')
 def hip():
-    from u2mkd_amd import _lib
+    from u2mkd_amd import _lib, deferred
     _lib.load()
-    return _lib
+    was = deferred.enabled()
+    deferred.enable()              # (the package's trainers switch it on; the bare operators leave it off)
+    yield _lib
+    deferred.enable(was)
+
+
+def test_off_by_default_for_bare_operators():
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from u2mkd_amd import deferred; print(deferred.enabled())' % root],
+                         capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == 'False', out.stderr[-500:]
 
 
 def _spvcnn_grads(overlap, steps=2):

@@ -7,6 +7,22 @@ the caller's stream and books the join: an end-of-backward callback makes the st
 BucketedGradientAverage) calls ``join()`` itself."""
 import torch
 
+# Off until a trainer that knows the protocol switches it on (train.LidarStep / train.KDStep do): the drop-in operators used under
+# a foreign trainer -- the reference's own, with torch's DistributedDataParallel, whose reducer copies gradients inside autograd
+# hooks and knows nothing of these streams -- keep their gradient launches joined where they are issued.
+_ENABLED = [False]
+
+
+def enable(flag: bool = True):
+    """Allow (or forbid) gradient launches to be joined at the end of the backward.  A caller that enables it promises that
+    whatever reads ``.grad`` during the backward calls ``join()`` first."""
+    _ENABLED[0] = bool(flag)
+
+
+def enabled() -> bool:
+    return _ENABLED[0]
+
+
 _STREAMS = {}
 _PENDING = {}
 OWNERS = set()        # ids of the leaves whose gradient is still running on a side stream

@@ -1031,8 +1031,8 @@ def _wgrad_side(weight, is_param, device, overlap_inline, *used):
         return None, False
     # is_param: the tensor whose gradient this is IS a leaf parameter (not a contiguous / padded / cast copy made for the call:
     # the gradient of a copy runs through more backward nodes, on the main stream, before it reaches the parameter)
-    if is_param and weight.grad is None:
-        from ... import deferred
+    from ... import deferred
+    if is_param and weight.grad is None and deferred.enabled():
         if id(weight) in deferred.OWNERS:
             deferred.join()
         side = deferred.side_for('sparse_wgrad', device, owner=id(weight))

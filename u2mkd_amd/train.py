@@ -7,6 +7,7 @@ import os
 import numpy as np
 import torch
 
+from . import deferred
 from . import distributed as D
 from . import kd as KD
 from . import torchsparse as ts
@@ -101,6 +102,7 @@ class LidarStep:
         CE, SGD nesterov 0.24, cosine_warmup)."""
         self.model = model
         self.amp = _Amp(amp)
+        deferred.enable()          # this trainer's reducer (distributed.BucketedGradientAverage) joins before it reads a gradient
         self.net = D.wrap_model(model, sync_bn=True)
         self.criterion = criterion if criterion is not None else MixLovaszCrossEntropy(ignore_index=ignore_index)
         self.opt = optimizer(self.net) if optimizer is not None else \
@@ -197,6 +199,7 @@ class KDStep:
         (module) / (optimizer), as for LidarStep (train_lc_nusc_tsd_full.py:84-93)."""
         self.model = model
         self.amp = _Amp(amp)
+        deferred.enable()          # (see LidarStep)
         if D.world() > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':      # (the knob: the N>1 code path on one GPU)
             from .lidar.point_voxel import SparseSyncBatchNorm
             model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
