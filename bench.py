@@ -287,6 +287,7 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
         'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_tp_kernel x2 + conv_wgrad_x3_kernel incl. its slab reduce + this weight\'s share of the per-step weight_fragments_batch launch), N=%d Cin=Cout=64 K=27' % n,
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
+        'timing': 'HIP events on the launch stream over %d launches per kernel, behind ~25 ms of the same launches without a synchronisation (the GPU reaches its working clocks only after 10-20 ms of load: DESIGN.md section 5)' % iters,
         'ms': dict(r3(warm), fragments_share=frag['share_ms'], total=round(t_warm, 4)),
         'fragments': frag,
         'GBps': {'fwd': round(gbs(b_f, warm['fwd']), 1), 'dgrad': round(gbs(b_d, warm['dgrad']), 1),
