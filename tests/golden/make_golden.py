@@ -174,9 +174,13 @@ def kd_inputs(b):
     return stu, tea
 
 
-# candidate scenes of the first KD fixture: seeds on which tools/diag_kd_seed.py (GPU box) saw the HIP model give the
-# same outputs with the spherical angles from either libm; the +-4 ulp margin is asserted below on the CPU
-FIRST_KD_SEEDS = (78, 79, 80, 82, 85, 86)
+# candidate scenes of the first KD fixture, scanned IN ORDER from the round-2 fixture's seed (77, which sits on a quantiser edge
+# and is kept as the edge fixture): the first whose reference outputs do not move when the quantiser inputs move by +-4 ulp.
+# A CPU-only criterion on the reference's own outputs -- no output of the implementation under test is consulted (rounds 2-3
+# scanned a list that tools/diag_kd_seed.py had pre-filtered on the GPU box: selection bias).
+FIRST_KD_SEEDS = tuple(range(77, 140))
+SELECTION_NOTE = ('first candidate seed, scanned in order, whose reference outputs move by < 1e-4 under +-4 ulp of the quantiser '
+                  'inputs (CPU only; no output of the implementation under test consulted)')
 
 
 def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write_keys=True, seeds=(77,), batches=None):
@@ -244,7 +248,7 @@ def make_kd_golden(crit, cr=1.0, cr_t=1.0, tag='kd_cr10_3000', n_vox=1500, write
     total.backward()
     g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     np.savez_compressed(
-        os.path.join(HERE, tag + '.npz'), seed=np.int64(seed),
+        os.path.join(HERE, tag + '.npz'), seed=np.int64(seed), selection=np.array(SELECTION_NOTE if len(seeds) > 1 or batches is not None else 'fixed seed'),
         x_vox=x_vox.detach().numpy(), x_pix=x_pix.detach().numpy(), x_vox_t=out['t']['x_vox'].numpy(),
         mse=np.array([float(m) for m in out['stu']['mse_loss']], dtype=np.float32),
         pts_feats_s=out['stu']['pts_feats'][0].detach().numpy()[::16],
@@ -288,7 +292,7 @@ def make_teacher_multisweep_golden():
             out = ref({'lidar': ots.SparseTensor(feats.clone(), coords.clone())})['x_vox']
         return ref, out, labels, kf
 
-    for seed in (58, 61, 62, 63, 64, 65, 66):      # (seeds on which tools/diag_ms_golden.py saw the HIP model and the oracle agree to 5e-5 on the GPU box)
+    for seed in range(50, 120):      # scanned in order; CPU-only criterion below (rounds 2-3: a list pre-filtered on the GPU box)
         with torch.no_grad():
             base = forward(seed)[1].clone()
             worst = max(float((forward(seed, k)[1] - base).abs().max()) for k in (4, -4))
@@ -306,7 +310,7 @@ def make_teacher_multisweep_golden():
     np.savez_compressed(
         os.path.join(HERE, 'teacher_multisweep_cr10_6000.npz'),
         logits=out.detach().numpy().astype(np.float32), loss=np.float32(loss.item()), n_keyframe=np.int64(kf.sum()),
-        seed=np.int64(seed), grad_stem=grads['stem.3.kernel'].numpy(), grad_cls=grads['classifier_vox.0.weight'].numpy(),
+        seed=np.int64(seed), selection=np.array(SELECTION_NOTE), grad_stem=grads['stem.3.kernel'].numpy(), grad_cls=grads['classifier_vox.0.weight'].numpy(),
         grad_tk=grads[blk + 'relative_pos_key_table'].numpy(), grad_up3=grads['vox_ups.3.1.1.net.3.kernel'].numpy()[13])
     print('teacher multi-sweep golden: loss', float(loss), 'key-frame voxels', int(kf.sum()), 'of', len(kf))
 
