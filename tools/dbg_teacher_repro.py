@@ -11,6 +11,15 @@ from u2mkd_amd.synth import synth_kd_batch
 from test_gpu_configs import _runner
 from test_gpu_configs4_fullsize import _step
 
+if os.environ.get('DBG_FENCE') == '1':        # an event record (a barrier packet with a system-scope release) behind every hash query
+    from u2mkd_amd.torchsparse.nn import functional as _F
+    _q = _F.HashTable.query
+
+    def _query(self, queries):
+        out = _q(self, queries)
+        torch.cuda.current_stream().record_event()
+        return out
+    _F.HashTable.query = _query
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 hw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (900, 1600)
 d = T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234, image_hw=hw))

@@ -55,4 +55,10 @@ for step in range(steps):
         diff = [n for n, a, b in (('coords', c0, rc), ('idx_kn', k0, rk), ('weights', w0, rw)) if not torch.equal(a, b)]
         if diff:
             print('step %d scale %s: differs from the first step AT THE KERNEL: %s' % (step, s, diff), flush=True)
+            if 'weights' in diff:
+                rows = (w0 != rw).any(1).nonzero().view(-1)
+                print('   %d weight rows differ; rows %s .. %s' % (rows.numel(), rows[:4].tolist(), rows[-2:].tolist()), flush=True)
+                for r in rows[:3].tolist():
+                    print('   row %d: now %s\n            ref %s\n            idx_kn %s coords %s' % (r, [round(v, 5) for v in w0[r].tolist()], [round(v, 5) for v in rw[r].tolist()],
+                          k0[:, r].tolist(), c0[r].tolist()), flush=True)
 print('done', flush=True)
