@@ -3,6 +3,8 @@
 // and the python kmap build of F.conv3d.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace u2mkd {
@@ -238,6 +240,13 @@ __global__ void downsample_keys_kernel(const int4 *__restrict__ coords, int64_t 
     keys[i] = ((int64_t)c.w << 54) | ((int64_t)(x + bias) << 36) | ((int64_t)(y + bias) << 18) | (int64_t)(z + bias);
 }
 
+__global__ void table_clear_kernel(TableView t, int64_t cap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    t.keys[i] = -1;
+    t.vals[i] = 0x7F7F7F7F;
+}
+
 // int32 (floor(x / s) * s, floor(y / s) * s, floor(z / s) * s, (int)b) of float point coordinates (x, y, z, b):
 // the voxel a point falls into at tensor stride s (core/models/utils.py:43-47,86-90: torch.floor(z.C[:, :3] / s) * s
 // concatenated with the batch column and cast to int -- seven element-wise launches in torch)
@@ -303,9 +312,17 @@ int u2mkd_hash_table_build(const int64_t *refs, int64_t n_refs, void *table, u2m
     U2_REQUIRE(n_refs < (1LL << 31) - 1, "u2mkd_hash_table_build: too many refs");
     TableView t = make_table_view(table, n_refs);
     int64_t cap = table_capacity(n_refs);
-    hipError_t e = hipMemsetAsync(t.keys, 0xFF, cap * sizeof(int64_t), as_stream(s));
-    if (e == hipSuccess) e = hipMemsetAsync(t.vals, 0x7F, cap * sizeof(int32_t), as_stream(s));
-    if (e != hipSuccess) { set_error("u2mkd_hash_table_build: memset: %s", hipGetErrorString(e)); return 1; }
+    // (debug, NOTES N9: U2MKD_DEBUG_HASH_FILL=1 clears the table with a kernel of this library instead of the runtime's
+    // two memset commands -- one of the discriminators of the stale-read item)
+    static const bool fill_kernel = [] { const char *e = getenv("U2MKD_DEBUG_HASH_FILL"); return e && e[0] == '1'; }();
+    if (fill_kernel) {
+        hipLaunchKernelGGL(table_clear_kernel, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, as_stream(s), t, cap);
+        if (check_launch("u2mkd_hash_table_build(clear)")) return 1;
+    } else {
+        hipError_t e = hipMemsetAsync(t.keys, 0xFF, cap * sizeof(int64_t), as_stream(s));
+        if (e == hipSuccess) e = hipMemsetAsync(t.vals, 0x7F, cap * sizeof(int32_t), as_stream(s));
+        if (e != hipSuccess) { set_error("u2mkd_hash_table_build: memset: %s", hipGetErrorString(e)); return 1; }
+    }
     if (n_refs == 0) return 0;
     U2_REQUIRE(refs, "u2mkd_hash_table_build: null refs");
     hipLaunchKernelGGL(table_insert_kernel, dim3((unsigned)ceil_div(n_refs, 256)), dim3(256), 0, as_stream(s), t,

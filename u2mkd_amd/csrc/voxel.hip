@@ -6,6 +6,8 @@
 // HBM-bound row work: one thread moves 16 B (float4) of a row, so a row of C
 // floats is covered by C/4 adjacent lanes and every wave instruction touches
 // whole contiguous row segments.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace u2mkd {
@@ -312,7 +314,99 @@ __global__ void ti_weights_kernel(const float4 *__restrict__ coords, const int64
     }
 }
 
+// ---- debug: coherence probe (tools/dbg_stale_probe.py; U2MKD_DEBUG_TI_PROBE=1) -------------------------------------
+// The same arithmetic as ti_weights_kernel on the values an ORDINARY load returns, but every input word is read a second
+// and third time past the caches (agent-scope and system-scope atomic loads) and a fourth time with an ordinary load
+// behind an explicit cache invalidate; a thread whose reads disagree appends a record to a device-side log.  A record
+// means: this kernel, launched behind the producer of `idx_kn` / `coords` on the same stream, saw two different values
+// of one address that nothing writes while it runs.
+struct ProbeEntry {
+    int64_t i;          // point
+    int32_t k;          // corner (0..7), or 8 + j for the j-th 64-bit half of the coordinate row
+    uint32_t xcc;       // HW_REG_XCC_ID of the reading wave
+    uint32_t hwid;      // HW_REG_HW_ID
+    uint32_t launch;    // probe launch counter
+    int64_t v_plain, v_agent, v_sys, v_after_inv;
+    uint64_t t;         // wall_clock64() at the read
+};
+constexpr int kProbeCap = 4096;
+__device__ unsigned int g_probe_n;
+__device__ unsigned int g_probe_launch;
+__device__ ProbeEntry g_probe_log[kProbeCap];
+
+__device__ __forceinline__ int64_t plain_load_after_inv(const int64_t *p) {
+    int64_t v;
+    asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)"
+                 : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ int64_t probe_word(const int64_t *p, int64_t i, int k, unsigned launch) {
+    const int64_t v0 = *p;
+    const int64_t va = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t vs = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v0 != vs || va != vs) {
+        const int64_t vi = plain_load_after_inv(p);
+        const unsigned slot = atomicAdd(&g_probe_n, 1u);
+        if (slot < (unsigned)kProbeCap) {
+            ProbeEntry e;
+            e.i = i; e.k = k;
+            e.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+            e.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+            e.launch = launch;
+            e.v_plain = v0; e.v_agent = va; e.v_sys = vs; e.v_after_inv = vi;
+            e.t = wall_clock64();
+            g_probe_log[slot] = e;
+        }
+    }
+    return v0;
+}
+
+__global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const int64_t *__restrict__ idx_kn, int64_t n,
+                                        float scale, float *__restrict__ w_n8, int32_t *__restrict__ idx_n8, unsigned launch) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t *cw = reinterpret_cast<const int64_t *>(coords + i);
+    const int64_t c0 = probe_word(cw, i, 8, launch), c1 = probe_word(cw + 1, i, 9, launch);
+    float4 p;
+    p.x = __int_as_float((int)(c0 & 0xffffffff)); p.y = __int_as_float((int)(c0 >> 32));
+    p.z = __int_as_float((int)(c1 & 0xffffffff)); p.w = __int_as_float((int)(c1 >> 32));
+    float xf, yf, zf;
+    if (scale != 1.f) {
+        xf = floorf(p.x / scale) * scale; yf = floorf(p.y / scale) * scale; zf = floorf(p.z / scale) * scale;
+    } else {
+        xf = floorf(p.x); yf = floorf(p.y); zf = floorf(p.z);
+    }
+    float xc = xf + scale, yc = yf + scale, zc = zf + scale;
+    float w[8];
+    w[0] = (xc - p.x) * (yc - p.y) * (zc - p.z);
+    w[1] = (xc - p.x) * (yc - p.y) * (p.z - zf);
+    w[2] = (xc - p.x) * (p.y - yf) * (zc - p.z);
+    w[3] = (xc - p.x) * (p.y - yf) * (p.z - zf);
+    w[4] = (p.x - xf) * (yc - p.y) * (zc - p.z);
+    w[5] = (p.x - xf) * (yc - p.y) * (p.z - zf);
+    w[6] = (p.x - xf) * (p.y - yf) * (zc - p.z);
+    w[7] = (p.x - xf) * (p.y - yf) * (p.z - zf);
+    float s3 = scale * scale * scale;
+    float sum = 0.f;
+    int id[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (scale != 1.f) w[k] = w[k] / s3;
+        id[k] = (int)probe_word(idx_kn + (int64_t)k * n + i, i, k, launch);
+        if (id[k] == -1) w[k] = 0.f;
+        sum += w[k];
+    }
+    sum += 1e-8f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        w_n8[i * 8 + k] = w[k] / sum;
+        idx_n8[i * 8 + k] = id[k];
+    }
+}
+
 }  // namespace u2mkd
+
 
 using namespace u2mkd;
 
@@ -422,9 +516,32 @@ int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, floa
                      int32_t *idx_n8, u2mkd_stream_t s) {
     if (n == 0) return 0;
     U2_REQUIRE(coords && idx_kn && w_n8 && idx_n8, "u2mkd_ti_weights: null pointer");
+    static const bool probe = [] { const char *e = getenv("U2MKD_DEBUG_TI_PROBE"); return e && e[0] == '1'; }();
+    if (probe) {
+        static unsigned launches = 0;
+        hipLaunchKernelGGL(ti_weights_probe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
+                           reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8, launches++);
+        return check_launch("u2mkd_ti_weights(probe)");
+    }
     hipLaunchKernelGGL(ti_weights_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
                        reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8);
     return check_launch("u2mkd_ti_weights");
 }
+
+// debug: copies the coherence probe's log to the host (synchronises the device); layout = ProbeEntry of csrc/voxel.hip
+int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int32_t reset) {
+    U2_REQUIRE(dst && n_total, "u2mkd_debug_probe_read: null pointer");
+    unsigned int n = 0;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_probe_n), sizeof(n));
+    const int64_t take = n < (unsigned)kProbeCap ? n : kProbeCap;
+    if (e == hipSuccess && take > 0)
+        e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe_log), (size_t)(take < max_entries ? take : max_entries) * sizeof(ProbeEntry));
+    if (e == hipSuccess && reset) { unsigned int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_probe_n), &z, sizeof(z)); }
+    if (e != hipSuccess) { set_error("u2mkd_debug_probe_read: %s", hipGetErrorString(e)); return 1; }
+    *n_total = (int32_t)n;
+    return 0;
+}
+int32_t u2mkd_debug_probe_entry_bytes(void) { return (int32_t)sizeof(ProbeEntry); }
 
 }  // extern "C"
