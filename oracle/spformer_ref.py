@@ -228,3 +228,30 @@ def default_spformer_kwargs(voxel_size=0.05, cr=1.0, in_channel=4, num_classes=1
     return dict(cr=cr, in_channel=in_channel, num_classes=num_classes, window_size=window, window_size_sphere=wss,
                 quant_size=window / 24, quant_size_sphere=np.array(wss) / 24, window_size_scale=[2.0, 2.0],
                 drop_path_rate=drop_path_rate, a=0.0125, pres=voxel_size, vres=voxel_size)
+
+
+def over(package, sptr_package):
+    """TESTS ONLY (see spvcnn_ref.over): a second copy of this module over another torchsparse-shaped operator package and
+    another sptr-shaped attention package (``to_3d_numpy, get_indices_params, sparse_self_attention`` with the signatures of
+    third_party/SparseTransformer/sptr/{utils,modules}.py) -- the reference's SPVCNN_SPFORMER call sequence
+    (spvcnn_spformer.py:125-189, spherical_transformer.py:165-348) over the product's operators on the GPU."""
+    import importlib
+    import importlib.util
+    import sys
+    from . import spvcnn_ref
+    name = __name__ + '__over__' + package.__name__.replace('.', '_')
+    if name in sys.modules:
+        return sys.modules[name]
+    base = spvcnn_ref.over(package)
+    spec = importlib.util.spec_from_file_location(name, __file__)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = __package__
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.ts, mod.sptr = package, sptr_package
+    mod.PointTensor = package.PointTensor
+    mod.spnn = importlib.import_module(package.__name__ + '.nn')
+    for n in ('BasicConvolutionBlock', 'BasicDeconvolutionBlock', 'ResidualBlock', 'initial_voxelize', 'point_to_voxel',
+              'voxel_to_point'):
+        setattr(mod, n, getattr(base, n))
+    return mod

@@ -259,3 +259,31 @@ def fill_state_by_name(model, seed=0, conv2d_he=False):
             out[key] = 0.05 * torch.randn(t.shape, generator=g)
     model.load_state_dict(out)
     return model
+
+
+def over(package):
+    """TESTS ONLY: a second copy of this module whose operator package is ``package`` -- anything with the torchsparse
+    v1.4.0 surface this file uses (``SparseTensor / PointTensor / cat``, ``nn.{Conv3d, BatchNorm, ReLU}``,
+    ``nn.functional.{sphash, sphashquery, spcount, spvoxelize, spdevoxelize, calc_ti_weights}``,
+    ``nn.utils.get_kernel_offsets``).  With ``u2mkd_amd.torchsparse`` on the GPU box this is the REFERENCE'S OWN CALL
+    SEQUENCE (core/models/utils.py:15-118, build_blocks.py:21-83, spvcnn.py:85-142: un-fused Conv3d -> BatchNorm -> ReLU
+    modules, lazily built kernel maps, torch.unique) running over the product's operators, where /root/reference does
+    not exist (tests/test_gpu_reference_sequence.py).  The module-level operator names are looked up at call time, so
+    re-binding them in the copy is enough."""
+    import importlib
+    import importlib.util
+    import sys
+    name = __name__ + '__over__' + package.__name__.replace('.', '_')
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, __file__)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = __package__
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.ts = package
+    mod.PointTensor, mod.SparseTensor = package.PointTensor, package.SparseTensor
+    mod.spnn = importlib.import_module(package.__name__ + '.nn')
+    mod.spf = importlib.import_module(package.__name__ + '.nn.functional')
+    mod.get_kernel_offsets = importlib.import_module(package.__name__ + '.nn.utils').get_kernel_offsets
+    return mod

@@ -48,6 +48,9 @@ def _worker(rank, world, port, out_dir):
     grads = _scene_grads(seed, lambda m: D.wrap_model(m, sync_bn=False, bucket_cap_mb=0.02))      # (many buckets)
     assert D.max_over_ranks(float(rank)) == 1.0
     torch.save(grads, os.path.join(out_dir, f'g{rank}.pt'))
+    # the same scene under torch's DistributedDataParallel (what the reference wraps in): same averaged gradients
+    ddp = _scene_grads(seed, lambda m: torch.nn.parallel.DistributedDataParallel(m, find_unused_parameters=True))
+    torch.save(ddp, os.path.join(out_dir, f'ddp{rank}.pt'))
     D.shutdown()
 
 
@@ -63,6 +66,9 @@ def test_two_rank_gradients_are_the_mean(tmp_path):
         assert torch.equal(g0[name], g1[name]), name          # all-reduced: identical on both ranks
         want = (s0[name] + s1[name]) / 2
         assert torch.allclose(g0[name], want, rtol=1e-4, atol=1e-6), name
+    ddp0 = torch.load(os.path.join(tmp_path, 'ddp0.pt'))
+    for name in g0:
+        assert torch.allclose(g0[name], ddp0[name], rtol=1e-5, atol=1e-7), name      # == torch DDP's result
 
 
 def test_bucketed_gradient_average_mechanics():
@@ -102,6 +108,117 @@ def test_bucketed_gradient_average_mechanics():
             b = wrapped._bucket_of[q]
             i = [j for j, t in enumerate(b['params']) if t is q][0]
             assert q.grad.data_ptr() == b['views'][i].data_ptr()
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.b = torch.nn.Linear(16, 16)
+        self.c = torch.nn.Linear(16, 3)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def test_reducer_launches_buckets_in_index_order_whatever_the_arrival_order():
+    """collectives must pair across ranks even when gradients arrive in a different order on one of them --
+    bucket i is launched only after buckets 0..i-1 (DDP's rule).  Arrival order is forced by calling the hook by hand."""
+    from u2mkd_amd import distributed as D
+    torch.manual_seed(0)
+    net = _Net()
+    red = D.BucketedGradientAverage(net, bucket_cap_mb=0.0001)
+    nb = len(red._buckets)
+    assert nb >= 4
+    launched = []
+    orig = red._reduce
+    red._reduce = lambda b: (launched.append(b['index']), orig(b))[1]
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    red._sync = True
+    red._armed = True                      # (no engine is running: the end-of-backward callback is called by hand below)
+    order = list(range(nb))[::-1]          # last bucket's gradients first
+    for i in order:
+        for p in red._buckets[i]['params']:
+            red._on_grad(p)
+        assert launched == sorted(launched)
+        assert (len(launched) == nb) == (i == 0)      # nothing can go before bucket 0 is complete
+    red._finish()
+    assert launched == list(range(nb))
+
+
+def test_reducer_refuses_a_second_gradient_for_a_parameter_in_one_pass():
+    from u2mkd_amd import distributed as D
+    net = _Net()
+    red = D.BucketedGradientAverage(net, bucket_cap_mb=0.0001)
+    red._armed = True
+    p = red._buckets[1]['params'][0]
+    p.grad = torch.ones_like(p)
+    red._on_grad(p)
+    with pytest.raises(RuntimeError, match='twice in one backward pass'):
+        red._on_grad(p)
+
+
+def test_reducer_recovers_from_a_backward_pass_that_raised_and_arms_without_parameter_gradients():
+    """a backward that raises never runs the engine's final callbacks; the next step must average again.  And a
+    pass in which NO parameter receives a gradient still flushes every bucket (the sink on the outputs arms the reducer)."""
+    from u2mkd_amd import distributed as D
+    torch.manual_seed(0)
+    ref, net = _Net(), _Net()
+    net.load_state_dict(ref.state_dict())
+    red = D.BucketedGradientAverage(net, bucket_cap_mb=0.0001)
+    x = torch.randn(5, 8)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError('boom')
+    h = torch.relu(net.a(x))
+    with pytest.raises(ValueError, match='boom'):
+        red_out = red(x)
+        (red_out.square().mean() + Boom.apply(h).sum()).backward()
+    for step in range(2):
+        ref.zero_grad(); red.zero_grad()
+        ref(x).square().mean().backward()
+        red(x).square().mean().backward()
+        for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+            assert torch.equal(p.grad, q.grad), (step, n)
+        assert red.collectives['count'] == len(red._buckets)
+    # no parameter on the path: the sink alone books the flush
+    class Passthrough(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Linear(4, 4)
+
+        def forward(self, x):
+            return x * 2
+    red2 = D.BucketedGradientAverage(Passthrough(), bucket_cap_mb=0.0001)
+    xin = torch.randn(3, 4, requires_grad=True)
+    red2(xin).sum().backward()
+    assert red2.collectives['count'] == len(red2._buckets) and all(float(p.grad.abs().max()) == 0.0 for p in red2.parameters())
+    assert torch.equal(xin.grad, torch.full_like(xin, 2.0))
+
+
+def test_reducer_no_sync_accumulates_locally():
+    from u2mkd_amd import distributed as D
+    torch.manual_seed(0)
+    ref, net = _Net(), _Net()
+    net.load_state_dict(ref.state_dict())
+    red = D.BucketedGradientAverage(net, bucket_cap_mb=0.0001)
+    x = torch.randn(5, 8)
+    with red.no_sync():
+        red(x).square().mean().backward()
+    assert red.collectives['count'] == 0
+    red(2 * x).square().mean().backward()
+    ref(x).square().mean().backward()
+    ref(2 * x).square().mean().backward()
+    for (n, p), (_, q) in zip(ref.named_parameters(), net.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-8), n
+    assert red.collectives['count'] == len(red._buckets)
 
 
 @pytest.mark.timeout(300)

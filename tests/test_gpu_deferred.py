@@ -104,3 +104,86 @@ def test_camera_conv2d_equals_nn_conv2d(hip):
         conv(xa).backward(g)
         ref(xb).backward(g)
         assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=2e-3 * float(ref.weight.grad.abs().max()))
+
+
+def test_a_weight_used_twice_in_one_pass_accumulates_finished_gradients(hip):
+    """a second contribution to a leaf in one backward pass (a shared / tied weight) is added to the first by
+    autograd as soon as the second function returns -- the first must be complete on that stream and the second computed in
+    line.  A SubM convolution applied twice and a camera Conv2d applied twice, against the formulation without side streams."""
+    from u2mkd_amd import torchsparse as ts
+    from u2mkd_amd.camera import Conv2d
+    from u2mkd_amd.synth import synth_batch
+    from u2mkd_amd.torchsparse import nn as spnn
+    from u2mkd_amd.torchsparse.nn import functional as F
+    b = synth_batch(20000, 1, seed=9)
+    coords = torch.from_numpy(b['coords']).cuda()
+    torch.manual_seed(1)
+    feats = torch.randn(coords.shape[0], 64, device='cuda')
+    conv = spnn.Conv3d(64, 64, 3).cuda()
+    cam = Conv2d(32, 32, 3, 1, 1, bias=False).cuda()
+    img = torch.randn(2, 32, 90, 160, device='cuda')
+
+    def run(overlap):
+        old = F._OVERLAP_WGRAD
+        F._OVERLAP_WGRAD = overlap
+        try:
+            for m in (conv, cam):
+                m.zero_grad(set_to_none=True)
+            x = ts.SparseTensor(feats, coords)
+            y = conv(conv(x))                     # the same kernel twice
+            z = cam(torch.relu(cam(img)))         # the same filter twice
+            (y.F.square().mean() + z.square().mean()).backward()
+            torch.cuda.synchronize()
+            return conv.kernel.grad.clone(), cam.weight.grad.clone()
+        finally:
+            F._OVERLAP_WGRAD = old
+    a = [run(True) for _ in range(3)]
+    from u2mkd_amd import deferred
+    with deferred.scope(False):
+        ref = run(False)
+    for got in a:
+        assert torch.equal(got[0], ref[0])
+        assert torch.allclose(got[1], ref[1], rtol=1e-4, atol=2e-3 * float(ref[1].abs().max()))     # (MIOpen: not bit-reproducible)
+
+
+def test_a_backward_pass_that_raises_does_not_disarm_the_next_one(hip):
+    """the engine's final callbacks do not run when a backward raises; the next pass books its own join (per graph
+    task) and first waits for what the failed pass left on the side streams."""
+    from u2mkd_amd import deferred, torchsparse as ts
+    from u2mkd_amd.synth import synth_batch
+    from u2mkd_amd.torchsparse import nn as spnn
+    b = synth_batch(20000, 1, seed=10)
+    coords = torch.from_numpy(b['coords']).cuda()
+    torch.manual_seed(2)
+    feats = torch.randn(coords.shape[0], 64, device='cuda', requires_grad=True)
+    c1, c2 = spnn.Conv3d(64, 64, 3).cuda(), spnn.Conv3d(64, 64, 3).cuda()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError('boom')
+
+    def loss(fail):
+        h = c1(ts.SparseTensor(feats, coords))
+        if fail:
+            h.F = Boom.apply(h.F)                 # c2's weight gradient is issued (deferred) before this node raises
+        return c2(h).F.square().mean()
+    with pytest.raises(ValueError, match='boom'):
+        loss(True).backward()
+    assert deferred.pending()                     # the failed pass left booked work behind
+    for m in (c1, c2):
+        m.zero_grad(set_to_none=True)
+    loss(False).backward()
+    assert not deferred.pending()                 # this pass's own end-of-backward join ran
+    got = (c1.kernel.grad.clone(), c2.kernel.grad.clone())
+    torch.cuda.synchronize()
+    for m in (c1, c2):
+        m.zero_grad(set_to_none=True)
+    with deferred.scope(False):
+        loss(False).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], c1.kernel.grad) and torch.equal(got[1], c2.kernel.grad)

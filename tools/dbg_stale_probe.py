@@ -39,16 +39,73 @@ def read_log():
     return buf[:min(n.value, CAP)], n.value
 
 
+WG_RING, WG_MAX = 64, 2048
+calls = []            # this step's probe launches: (launch number, n, scale, w, i8, stream)
+_launch = [0]
+
+
+def ti_weights_sentinel(coords, idx_query_kn, scale=1):
+    """functional.ti_weights_n8 with its two outputs pre-filled (NaN / -7777) on the launch stream: a row the launch did not
+    write stays recognisable."""
+    coords = coords.contiguous().float()
+    idx = idx_query_kn.contiguous()
+    n = coords.shape[0]
+    w = torch.full((n, 8), float('nan'), dtype=torch.float32, device=coords.device)
+    i8 = torch.full((n, 8), -7777, dtype=torch.int32, device=coords.device)
+    L.call('u2mkd_ti_weights', L.ptr(coords), L.ptr(idx), n, float(scale), L.ptr(w), L.ptr(i8), L.stream())
+    calls.append((_launch[0], n, scale, w, i8, torch.cuda.current_stream().cuda_stream))
+    _launch[0] += 1
+    return w, i8
+
+
+from u2mkd_amd.torchsparse.nn import functional as _F
+_F.ti_weights_n8 = ti_weights_sentinel
+
+
+def read_wg():
+    buf = np.zeros((WG_RING, WG_MAX, 2), np.uint32)
+    n = C.c_int32(0)
+    L.call('u2mkd_debug_probe_wg_read', buf.ctypes.data, C.addressof(n), 1)
+    return buf, n.value
+
+
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 hw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (360, 640)
 d = T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234, image_hw=hw))
 run = _runner(1.0, 2.0)
 state = {k: v.clone() for k, v in run.model.state_dict().items()}
 prev, all_rec, dev_steps, rec_steps = None, [], [], []
+unwritten_steps, ghost_steps = [], []
+read_wg()
 for step in range(steps):
     run.model.load_state_dict(state)
+    calls.clear()
     out, ld = _step(run, d, False)
     rec, n = read_log()
+    wg, total = read_wg()
+    assert total == _launch[0], (total, _launch[0])
+    mine = set()
+    for ln, npts, scale, w, i8, st in calls:
+        nb = (npts + 255) // 256
+        mine.add(ln + 1)
+        row = wg[ln % WG_RING, :min(nb, WG_MAX)]
+        missing = np.nonzero(row[:, 0] != ln + 1)[0]
+        wrongptr = np.nonzero((row[:, 0] == ln + 1) & (row[:, 1] != (w.data_ptr() & 0xffffffff)))[0]
+        bad_w = torch.isnan(w).any(1)
+        bad_i = (i8 == -7777).any(1)
+        nbw, nbi = int(bad_w.sum()), int(bad_i.sum())
+        if len(missing) or len(wrongptr) or nbw or nbi:
+            unwritten_steps.append(step)
+            rows = bad_w.nonzero().view(-1)
+            print('step %d launch %d (n %d scale %s stream %#x): %d workgroups without a record %s, %d with another output pointer; '
+                  '%d weight rows / %d index rows NEVER WRITTEN (rows %s.., workgroups %s)'
+                  % (step, ln, npts, scale, st, len(missing), missing[:8].tolist(), len(wrongptr), nbw, nbi, rows[:4].tolist(),
+                     torch.unique(rows // 256)[:12].tolist()), flush=True)
+    ghosts = [(r, b, int(wg[r, b, 0]) - 1, int(wg[r, b, 1])) for r, b in zip(*np.nonzero((wg[:, :, 0] != 0) & ~np.isin(wg[:, :, 0], list(mine))))]
+    if ghosts:
+        ghost_steps.append(step)
+        print('step %d: %d workgroup records that belong to NO launch of this step (ran on old arguments): first %s; this step\'s launches %s'
+              % (step, len(ghosts), ghosts[:6], sorted(mine)[:3]), flush=True)
     t = out['t']['x_vox'].clone()
     rows = 0
     if prev is not None:
@@ -65,6 +122,7 @@ for step in range(steps):
             print('   point %d word %d launch %d xcc %#x hwid %#x: plain %d agent %d system %d plain-after-inv %d t %d'
                   % (e['i'], e['k'], e['launch'], e['xcc'], e['hwid'], e['v_plain'], e['v_agent'], e['v_sys'], e['v_after_inv'], e['t']), flush=True)
     prev = t
+print('steps %d: %d with rows never written / workgroups without a record %s; %d with ghost records %s' % (steps, len(unwritten_steps), unwritten_steps[:20], len(ghost_steps), ghost_steps[:20]))
 print('steps %d: %d with probe records %s; %d with deviating teacher rows %s' % (steps, len(rec_steps), rec_steps[:20], len(dev_steps), dev_steps[:20]))
 if all_rec:
     r = np.concatenate(all_rec)

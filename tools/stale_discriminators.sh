@@ -13,7 +13,7 @@ export U2MKD_BN2D=0 U2MKD_SAMPLED_PIXEL_HEAD=0
 run() {            # name, steps, env...
     local name=$1 steps=$2; shift 2
     echo "== $name ($*)"
-    env "$@" timeout -k 10 420 python tools/dbg_teacher_repro.py $steps 360 640 > $OUT/$name.log 2>&1
+    env "$@" timeout -k 10 600 python tools/dbg_teacher_repro.py $steps ${SIZE:-360 640} > $OUT/$name.log 2>&1
     echo "   rc $? deviating comparisons: $(grep -c 'teacher rows differ' $OUT/$name.log | tr -d '\n') with rows > 0: $(grep 'teacher rows differ' $OUT/$name.log | grep -vc ': 0 of')  of $(grep -c '^step' $OUT/$name.log)"
 }
 for w in $WHICH; do
@@ -26,6 +26,18 @@ for w in $WHICH; do
     q4) run q4 $STEPS GPU_MAX_HW_QUEUES=4;;
     q2) run q2 $STEPS GPU_MAX_HW_QUEUES=2;;
     q1) run q1 $STEPS GPU_MAX_HW_QUEUES=1;;
+    q5) run q5 $STEPS GPU_MAX_HW_QUEUES=5;;
+    q6) run q6 $STEPS GPU_MAX_HW_QUEUES=6;;
+    q4long) run q4long 500 GPU_MAX_HW_QUEUES=4;;
+    q4big) SIZE="900 1600" run q4big 150 GPU_MAX_HW_QUEUES=4 U2MKD_SAMPLED_PIXEL_HEAD=1;;
+    q8big) SIZE="900 1600" run q8big 100 GPU_MAX_HW_QUEUES=8 U2MKD_SAMPLED_PIXEL_HEAD=1;;
+    kahdp) run kahdp $STEPS DEBUG_CLR_KERNARG_HDP_FLUSH_WA=1;;
+    devkarg0) run devkarg0 $STEPS HIP_FORCE_DEV_KERNARG=0;;
+    devkarg1) run devkarg1 $STEPS HIP_FORCE_DEV_KERNARG=1;;
+    kpool) run kpool $STEPS HSA_KERNARG_POOL_SIZE=67108864;;
+    fgs0) run fgs0 $STEPS ROC_USE_FGS_KERNARG=0;;
+    argcopy) run argcopy $STEPS DEBUG_HIP_KERNARG_COPY_OPT=0;;
+    map) for q in 2 4 5 6 8; do GPU_MAX_HW_QUEUES=$q python tools/queue_map.py > $OUT/map_q$q.log 2>&1; cat $OUT/map_q$q.log; done;;
     hashfill) run hashfill $STEPS U2MKD_DEBUG_HASH_FILL=1;;
     esac
 done

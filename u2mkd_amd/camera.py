@@ -348,14 +348,18 @@ class _Conv2dFunction(torch.autograd.Function):
         gx = bwd((True, False, False))[0].to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            if ctx.pid in deferred.OWNERS:        # a second use of the weight in this pass: its accumulation reads the first
+            if deferred.owned(ctx.pid):
+                # a second use of the weight in this pass: autograd adds the two contributions when this function returns, on
+                # this stream -- the first must be complete here and this one is computed in line
                 deferred.join()
-            side = deferred.side_for('camera_wgrad', g.device, owner=ctx.pid)
-            with torch.cuda.stream(side):
                 gw = bwd((False, True, False))[1].to(ctx.dtypes[1])
-            for t in (x, weight, g):
-                t.record_stream(side)
-            gw.record_stream(torch.cuda.current_stream(g.device))      # allocated on the side stream, consumed on this one
+            else:
+                side = deferred.side_for('camera_wgrad', g.device, owner=ctx.pid)
+                with torch.cuda.stream(side):
+                    gw = bwd((False, True, False))[1].to(ctx.dtypes[1])
+                for t in (x, weight, g):
+                    t.record_stream(side)
+                gw.record_stream(torch.cuda.current_stream(g.device))      # allocated on the side stream, consumed on this one
         return gx, gw, None, None
 
 

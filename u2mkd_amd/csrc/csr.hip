@@ -245,6 +245,14 @@ int u2mkd_devoxelize_plan(const int32_t *idx8, const float *w8, int64_t n, int64
     U2_REQUIRE(n >= 0 && nv >= 0, "u2mkd_devoxelize_plan: negative sizes");
     U2_REQUIRE(seg && workspace && (n == 0 || (idx8 && w8 && entry_row && entry_w)), "u2mkd_devoxelize_plan: null pointer");
     const int64_t e = 8 * n;
+    if (nv == 0 || e == 0) {     // no voxel rows (or no points): every segment is empty, `order` is never written -- nothing to gather
+        (void)hipMemsetAsync(seg, 0, (size_t)(nv + 1) * sizeof(int32_t), as_stream(s));
+        if (e) {                 // (the entry arrays are defined: row 0, weight 0; no segment addresses them)
+            (void)hipMemsetAsync(entry_row, 0, (size_t)e * sizeof(int32_t), as_stream(s));
+            (void)hipMemsetAsync(entry_w, 0, (size_t)e * sizeof(float), as_stream(s));
+        }
+        return check_launch("u2mkd_devoxelize_plan");
+    }
     int32_t *keys = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + u2mkd_csr_workspace_bytes(e, nv));
     int32_t *order = keys + e;
     hipStream_t st = as_stream(s);

@@ -362,8 +362,16 @@ __device__ __forceinline__ int64_t probe_word(const int64_t *p, int64_t i, int k
     return v0;
 }
 
+// every workgroup reports the launch number and the output pointer IT received as kernel arguments (the array is addressed
+// through its symbol, not through an argument): a workgroup that ran on another launch's arguments shows up as a record missing
+// from its launch's row and as a record in a row that is not of this step
+constexpr int kWgRing = 64, kWgMax = 2048;
+__device__ uint2 g_wg_seen[kWgRing][kWgMax];
+
 __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const int64_t *__restrict__ idx_kn, int64_t n,
                                         float scale, float *__restrict__ w_n8, int32_t *__restrict__ idx_n8, unsigned launch) {
+    if (threadIdx.x == 0 && blockIdx.x < kWgMax)
+        g_wg_seen[launch % kWgRing][blockIdx.x] = make_uint2(launch + 1, (unsigned)(uintptr_t)w_n8);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t *cw = reinterpret_cast<const int64_t *>(coords + i);
@@ -409,6 +417,8 @@ __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const
 
 
 using namespace u2mkd;
+
+static unsigned g_probe_launches_host = 0;      // (debug probe: launches so far; the host thread that launches is the only writer)
 
 #define LAUNCH_ROWS(kernel, n, c, ...)                                                                  \
     do {                                                                                                \
@@ -518,9 +528,8 @@ int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, floa
     U2_REQUIRE(coords && idx_kn && w_n8 && idx_n8, "u2mkd_ti_weights: null pointer");
     static const bool probe = [] { const char *e = getenv("U2MKD_DEBUG_TI_PROBE"); return e && e[0] == '1'; }();
     if (probe) {
-        static unsigned launches = 0;
         hipLaunchKernelGGL(ti_weights_probe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
-                           reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8, launches++);
+                           reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8, g_probe_launches_host++);
         return check_launch("u2mkd_ti_weights(probe)");
     }
     hipLaunchKernelGGL(ti_weights_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
@@ -543,5 +552,20 @@ int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int
     return 0;
 }
 int32_t u2mkd_debug_probe_entry_bytes(void) { return (int32_t)sizeof(ProbeEntry); }
+// debug: the per-workgroup argument records of the probe launches ([64 launches mod 64][2048 workgroups] x {launch + 1, low 32
+// bits of the output pointer}), optionally cleared; *launches = number of probe launches so far
+int u2mkd_debug_probe_wg_read(void *dst, int32_t *launches, int32_t reset) {
+    U2_REQUIRE(dst && launches, "u2mkd_debug_probe_wg_read: null pointer");
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_seen), sizeof(uint2) * kWgRing * kWgMax);
+    if (e == hipSuccess && reset) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_seen));
+        if (e == hipSuccess) e = hipMemset(p, 0, sizeof(uint2) * kWgRing * kWgMax);
+    }
+    if (e != hipSuccess) { set_error("u2mkd_debug_probe_wg_read: %s", hipGetErrorString(e)); return 1; }
+    *launches = (int32_t)g_probe_launches_host;
+    return 0;
+}
 
 }  // extern "C"

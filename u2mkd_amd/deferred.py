@@ -3,14 +3,23 @@
 A leaf's gradient is read by nobody before the backward ends (the optimizer, or a gradient hook), so the kernels that compute
 it may run on a side stream next to the rest of the backward.  ``side_for(role, device)`` hands out the stream ordered behind
 the caller's stream and books the join: an end-of-backward callback makes the stream that called ``backward()`` wait for it, so
-``.grad`` is ordinary data once ``backward()`` returns; a hook that reads ``.grad`` DURING the backward (distributed.
-BucketedGradientAverage) calls ``join()`` itself."""
+``.grad`` is ordinary data once ``backward()`` returns; code that reads ``.grad`` DURING the backward (a gradient hook, the
+accumulation of a second contribution to the same leaf) calls ``join()`` first, which orders the CURRENT stream behind the side
+streams and leaves the end-of-backward join in place for the stream that called ``backward()``.
+
+Bookkeeping is per backward pass (the autograd engine's graph-task id): a pass that raised -- out of memory, a NaN check --
+never runs its final callbacks, and the next pass must book its own join instead of trusting a stale one; whatever the failed
+pass left on the side streams is joined first."""
+import contextlib
+
 import torch
 
-# Off until a trainer that knows the protocol switches it on (train.LidarStep / train.KDStep do): the drop-in operators used under
-# a foreign trainer -- the reference's own, with torch's DistributedDataParallel, whose reducer copies gradients inside autograd
-# hooks and knows nothing of these streams -- keep their gradient launches joined where they are issued.
+# Off until a trainer that knows the protocol switches it on (train.LidarStep / train.KDStep hold it for their lifetime:
+# acquire() / release()): the drop-in operators used under a foreign trainer -- the reference's own, with torch's
+# DistributedDataParallel, whose reducer copies gradients inside autograd hooks and knows nothing of these streams -- keep their
+# gradient launches joined where they are issued.
 _ENABLED = [False]
+_HOLDERS = [0]
 
 
 def enable(flag: bool = True):
@@ -23,9 +32,36 @@ def enabled() -> bool:
     return _ENABLED[0]
 
 
+def acquire():
+    """A trainer's hold on the switch (train.LidarStep / KDStep constructors); ``release()`` when the trainer goes away: the
+    switch is on exactly while a trainer that follows the protocol exists in the process."""
+    _HOLDERS[0] += 1
+    _ENABLED[0] = True
+
+
+def release():
+    _HOLDERS[0] = max(0, _HOLDERS[0] - 1)
+    if _HOLDERS[0] == 0:
+        _ENABLED[0] = False
+
+
+@contextlib.contextmanager
+def scope(flag: bool = True):
+    """``with deferred.scope():`` -- the switch for the duration of a block (tests, a caller that drives forward + backward
+    itself); leftovers of a pass that raised inside are joined on the way out."""
+    old = _ENABLED[0]
+    _ENABLED[0] = bool(flag)
+    try:
+        yield
+    finally:
+        _ENABLED[0] = old
+        begin_step()
+
+
 _STREAMS = {}
-_PENDING = {}
-OWNERS = set()        # ids of the leaves whose gradient is still running on a side stream
+_PENDING = {}         # (device, role) -> side stream with work booked in the pass `_TASK`
+_TASK = [None]        # graph-task id of the backward pass whose end-of-backward join is booked
+OWNERS = set()        # ids of the leaves whose gradient was issued on a side stream in the pass `_TASK`
 
 
 # The GPU runs five streams of this package side by side without trouble (main, teacher, camera, sparse weight gradients,
@@ -44,19 +80,49 @@ def stream(device_index: int, role: str) -> torch.cuda.Stream:
     return s
 
 
+def _graph_task():
+    """Identity of the running backward pass (-1 outside one)."""
+    return torch._C._current_graph_task_id()
+
+
+def _drop_stale():
+    """Work booked by a pass other than the running one (that pass raised: its callback never ran): the current stream waits
+    for it, then the books are cleared."""
+    for side in _PENDING.values():
+        torch.cuda.current_stream(side.device).wait_stream(side)
+    _PENDING.clear()
+    OWNERS.clear()
+    _TASK[0] = None
+
+
+def begin_step():
+    """Called by the trainers at the start of every step (and by ``scope``): nothing of an earlier pass stays booked."""
+    if _PENDING or OWNERS or _TASK[0] is not None:
+        _drop_stale()
+
+
 def side_for(role: str, device: torch.device, owner=None) -> torch.cuda.Stream:
     """The side stream of ``role`` on ``device``, waiting for everything queued on the current stream, its join booked.
     Only callable from inside a backward pass (the callback belongs to the running autograd engine)."""
     index = device.index if device.index is not None else torch.cuda.current_device()
+    task = _graph_task()
+    if _TASK[0] != task:
+        _drop_stale()
+        _TASK[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
     side = stream(index, role)
     key = (index, _ALIAS.get(role, role))
     side.wait_stream(torch.cuda.current_stream(device))
-    if key not in _PENDING:
-        torch.autograd.Variable._execution_engine.queue_callback(join)
     _PENDING[key] = side
     if owner is not None:
         OWNERS.add(owner)
     return side
+
+
+def owned(owner) -> bool:
+    """True if ``owner``'s gradient was issued on a side stream in the RUNNING backward pass: a second contribution to the
+    same leaf must ``join()`` and be computed in line (autograd adds the two as soon as the second function returns)."""
+    return owner in OWNERS and _TASK[0] == _graph_task()
 
 
 def pending():
@@ -65,8 +131,15 @@ def pending():
 
 
 def join():
-    """The current stream waits for every side stream with booked work."""
-    for key, side in list(_PENDING.items()):
+    """The CURRENT stream waits for every side stream with booked work.  The books stay: the end-of-backward callback still
+    joins them into the stream that called ``backward()`` (a hook may run on any of the backward's streams)."""
+    for side in _PENDING.values():
         torch.cuda.current_stream(side.device).wait_stream(side)
-        del _PENDING[key]
+
+
+def _end_of_backward():
+    """Engine callback, on the thread and stream that called ``backward()``."""
+    join()
+    _PENDING.clear()
     OWNERS.clear()
+    _TASK[0] = None

@@ -9,7 +9,9 @@ There is no data-path collective.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -76,11 +78,47 @@ def _is_sync_bn(m) -> bool:
     return isinstance(m, torch.nn.SyncBatchNorm)
 
 
+class _ArmSink(torch.autograd.Function):
+    """Identity on the wrapped module's outputs whose backward runs FIRST in a backward pass that reaches them: it books the
+    reducer's end-of-backward callback even on a rank where (this step) no parameter receives a gradient, so every rank issues
+    every bucket's collective (torch DDP's _DDPSink plays this role)."""
+
+    @staticmethod
+    def forward(ctx, reducer_ref, *tensors):
+        ctx.reducer_ref = reducer_ref
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        red = ctx.reducer_ref()
+        if red is not None:
+            red._arm()
+        return (None,) + grads
+
+
+def _map_tensors(o, fn):
+    if torch.is_tensor(o):
+        return fn(o)
+    if isinstance(o, dict):
+        return type(o)((k, _map_tensors(v, fn)) for k, v in o.items())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_map_tensors(v, fn) for v in o)
+    return o
+
+
 class BucketedGradientAverage(torch.nn.Module):
     """Data-parallel gradient averaging, the role DistributedDataParallel plays in train_lc_nusc_tsd_full.py:80-84: the
     parameters are cut into buckets in reverse registration order (~ the order their gradients appear), and as soon as
     the last gradient of a bucket has been accumulated the bucket is flattened and all-reduced (average) on a side
     stream while the backward keeps running; when the backward ends every ``p.grad`` IS its slice of the reduced buffer.
+
+    Collectives are issued in BUCKET INDEX ORDER on every rank (bucket i only after buckets 0..i-1, as DDP's reducer does):
+    a bucket that completes early waits for its predecessors, so two ranks whose gradients arrive in a different order --
+    a data-dependent branch, a stage without points on one rank -- still pair the same buffers.  The end-of-backward
+    callback that flushes the buckets with missing gradients (zeros for those) is booked by a sink on the module's outputs,
+    i.e. by every backward pass that reaches them, and the per-step state is reset at every forward, so a backward that
+    raised (out of memory, a NaN check) does not leave the reducer disarmed.  A gradient hook that fires twice for one
+    parameter in a pass (re-entrant checkpointing) raises.  ``no_sync()`` accumulates local gradients without collectives.
 
     Why not torch's DDP: with ``gradient_as_bucket_view`` every parameter's gradient is COPIED into its bucket slice as
     it is produced -- one copy kernel per parameter per step, 485 for the KD student: +515 launches and +3.2 ms of kernel
@@ -116,6 +154,10 @@ class BucketedGradientAverage(torch.nn.Module):
         if cur:
             self._add_bucket(cur)
         self._armed = False
+        self._sync = True
+        self._next = 0                # the next bucket (index) to launch
+        self.collectives = {'count': 0, 'bytes': 0}     # all-reduces issued by the last backward pass (bench.py reports them)
+        self._self_ref = weakref.ref(self)
         for p in params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -125,30 +167,84 @@ class BucketedGradientAverage(torch.nn.Module):
         for p in plist:
             views.append(flat[o:o + p.numel()].view_as(p))
             o += p.numel()
-        b = {'params': list(plist), 'flat': flat, 'views': views, 'pending': len(plist), 'work': None, 'streams': {}}
+        b = {'params': list(plist), 'flat': flat, 'views': views, 'pending': len(plist), 'seen': set(), 'ready': False,
+             'launched': False, 'work': None, 'streams': {}, 'index': len(self._buckets)}
         for p in plist:
             self._bucket_of[p] = b
         self._buckets.append(b)
+
+    def _reset(self):
+        """Per-pass state; also what a backward pass that raised left behind (its end-of-backward callback never ran)."""
+        for b in self._buckets:
+            b['pending'] = len(b['params'])
+            b['seen'] = set()
+            b['ready'] = b['launched'] = False
+            b['streams'] = {}
+            b['work'] = None
+            b['done'] = None
+        self._armed = False
+        self._next = 0
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate LOCAL gradients (no collectives), as DistributedDataParallel.no_sync."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def forward(self, *args, **kwargs):
         if self.broadcast_buffers and self._world > 1 and self.training:
             with torch.no_grad():
                 for t in self.module.buffers():
                     dist.broadcast(t, 0)
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        if torch.is_grad_enabled() and self._sync:
+            self._reset()
+            tensors = []
+            _map_tensors(out, lambda t: tensors.append(t) if t.requires_grad else None)
+            if tensors:
+                sunk = iter(_ArmSink.apply(self._self_ref, *tensors))
+                out = _map_tensors(out, lambda t: next(sunk) if t.requires_grad else t)
+        return out
 
     # ---- backward side
-    def _on_grad(self, p):
-        if not self._armed:                       # first gradient of this backward: finish when the engine is done
+    def _arm(self):
+        if self._sync and not self._armed:        # first event of this backward: finish when the engine is done
             self._armed = True
+            self.collectives = {'count': 0, 'bytes': 0}
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+
+    def _on_grad(self, p):
+        if not self._sync:
+            return
+        self._arm()
         b = self._bucket_of[p]
+        if id(p) in b['seen'] or b['launched']:
+            raise RuntimeError('BucketedGradientAverage: a parameter received its gradient twice in one backward pass '
+                               '(re-entrant backward / activation checkpointing is not supported); use no_sync() for '
+                               'gradient accumulation over several passes')
+        b['seen'].add(id(p))
         if self._on_gpu:                          # (gradients come from several streams: camera branch, weight-gradient stream)
             st = torch.cuda.current_stream()
             b['streams'][st.stream_id] = st
         b['pending'] -= 1
         if b['pending'] == 0:
-            self._reduce(b)
+            b['ready'] = True
+            self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch, in index order, every bucket whose predecessors have all been launched."""
+        while self._next < len(self._buckets) and self._buckets[self._next]['ready']:
+            self._reduce(self._buckets[self._next])
+            self._next += 1
+
+    def _all_reduce(self, b):
+        self.collectives['count'] += 1
+        self.collectives['bytes'] += b['flat'].numel() * b['flat'].element_size()
+        if self._world > 1:
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
 
     def _reduce(self, b):
         """Flatten the bucket and start its all-reduce.  No stream of our own (a sixth busy stream costs the step 50 ms,
@@ -157,13 +253,12 @@ class BucketedGradientAverage(torch.nn.Module):
         critical one -- is not made to wait in the middle of the backward.  Otherwise it goes to the arriving stream.  Every
         other stream that produced one of the bucket's gradients is joined by an event recorded now: it covers what that
         stream has produced so far."""
+        b['launched'] = True
         with torch.no_grad():
             if not self._on_gpu:
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
                 torch._foreach_copy_(b['views'], grads)
-                if self._world > 1:
-                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
-                b['pending'] = -1
+                self._all_reduce(b)
                 return
             from . import deferred
             cur = torch.cuda.current_stream()
@@ -179,18 +274,16 @@ class BucketedGradientAverage(torch.nn.Module):
             with torch.cuda.stream(run):
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b['params']]
                 torch._foreach_copy_(b['views'], grads)
-                if self._world > 1:
-                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
+                self._all_reduce(b)
                 b['done'] = run.record_event()
-        b['pending'] = -1                         # launched
 
     def _finish(self):
-        """End of the backward: buckets with a parameter that received no gradient go now (zeros for the missing ones, so
-        every rank issues the same collectives), the caller's stream joins every bucket's copy / collective, and every
-        ``p.grad`` becomes its slice of the reduced bucket."""
-        for b in self._buckets:
-            if b['pending'] >= 0:
-                self._reduce(b)
+        """End of the backward: the buckets not yet launched go now, in index order (zeros for the parameters that received
+        no gradient, so every rank issues the same collectives), the caller's stream joins every bucket's copy /
+        collective, and every ``p.grad`` becomes its slice of the reduced bucket."""
+        for b in self._buckets[self._next:]:
+            self._reduce(b)
+        self._next = len(self._buckets)
         with torch.no_grad():
             for b in self._buckets:
                 if self._on_gpu and b.get('done') is not None:
@@ -204,9 +297,7 @@ class BucketedGradientAverage(torch.nn.Module):
         for b in self._buckets:
             for p, v in zip(b['params'], b['views']):
                 p.grad = v
-            b['pending'] = len(b['params'])
-            b['streams'] = {}
-        self._armed = False
+        self._reset()
 
 
 def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int = 25):

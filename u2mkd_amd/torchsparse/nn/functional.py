@@ -1033,12 +1033,15 @@ def _wgrad_side(weight, is_param, device, overlap_inline, *used):
     # the gradient of a copy runs through more backward nodes, on the main stream, before it reaches the parameter)
     from ... import deferred
     if is_param and weight.grad is None and deferred.enabled():
-        if id(weight) in deferred.OWNERS:
+        if deferred.owned(id(weight)):
+            # a second contribution to this leaf in one pass (a shared weight): autograd adds the two as soon as this function
+            # returns, on this stream -- the first must be complete here, and this one is joined in line below
             deferred.join()
-        side = deferred.side_for('sparse_wgrad', device, owner=id(weight))
-        for t in used:
-            t.record_stream(side)
-        return side, True
+        else:
+            side = deferred.side_for('sparse_wgrad', device, owner=id(weight))
+            for t in used:
+                t.record_stream(side)
+            return side, True
     if not overlap_inline:
         return None, False
     side = _side_stream(device)

@@ -3,6 +3,7 @@ trainers): LiDAR-only (core/spformer_trainer.py:58-94) and KD
 (core/nusc_trainers.py:255-366).  One call = forward, losses, zero_grad, backward (DDP
 all-reduce overlapped), SGD-nesterov step, LR-scheduler step; no ``.item()`` host syncs."""
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -102,7 +103,8 @@ class LidarStep:
         CE, SGD nesterov 0.24, cosine_warmup)."""
         self.model = model
         self.amp = _Amp(amp)
-        deferred.enable()          # this trainer's reducer (distributed.BucketedGradientAverage) joins before it reads a gradient
+        deferred.acquire()         # held for this trainer's lifetime: its reducer (distributed.BucketedGradientAverage) follows the protocol
+        weakref.finalize(self, deferred.release)
         self.net = D.wrap_model(model, sync_bn=True)
         self.criterion = criterion if criterion is not None else MixLovaszCrossEntropy(ignore_index=ignore_index)
         self.opt = optimizer(self.net) if optimizer is not None else \
@@ -114,6 +116,7 @@ class LidarStep:
         its geometry -- voxel set and kernel maps, every host synchronisation of a step (point_voxel.prepare_geometry) --
         is built between this step's forward and backward, and the next call issues its forward without waiting for the
         GPU (as KDStep does)."""
+        deferred.begin_step()      # (nothing of a backward pass that raised stays booked)
         queued = self.__dict__.pop('_queued', None)
         in_mod = {'lidar': ts.SparseTensor(feats, coords)}
         if queued is not None and queued[0] is feats and queued[1] is coords:
@@ -199,7 +202,8 @@ class KDStep:
         (module) / (optimizer), as for LidarStep (train_lc_nusc_tsd_full.py:84-93)."""
         self.model = model
         self.amp = _Amp(amp)
-        deferred.enable()          # (see LidarStep)
+        deferred.acquire()         # (see LidarStep)
+        weakref.finalize(self, deferred.release)
         if D.world() > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1':      # (the knob: the N>1 code path on one GPU)
             from .lidar.point_voxel import SparseSyncBatchNorm
             model.model_s = SparseSyncBatchNorm.convert_sync_batchnorm(model.model_s)   # train_lc_nusc_tsd_full.py:80
@@ -226,6 +230,7 @@ class KDStep:
         this step's forward and backward, where the GPU queue is short; the next call then issues its whole forward
         without waiting for the GPU while this step's backward drains.  The work per batch is the same, it only moves
         one step ahead, as a data loader's prefetch does."""
+        deferred.begin_step()      # (nothing of a backward pass that raised stays booked)
         queued = self.__dict__.pop('_queued', None)
         in_mod = queued[1] if (queued is not None and queued[0] is d) else self._in_mod(d)
         entry = torch.cuda.current_stream().record_event() if d['s_feats'].is_cuda else None     # (see the geometry side stream below)
