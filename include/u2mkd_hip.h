@@ -356,6 +356,7 @@ int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_
  * u2mkd_debug_probe_read copies the log to the host (device synchronisation), entries of u2mkd_debug_probe_entry_bytes(). */
 int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int32_t reset);
 int32_t u2mkd_debug_probe_entry_bytes(void);
+int u2mkd_debug_probe_rows_read(void *dst /*[2][81920] x uint32[4]*/, int32_t slot /*launch mod 16*/);
 int u2mkd_debug_probe_wg_read(void *dst /*[64][2048] x {uint32 launch + 1, uint32 low bits of w_n8}*/, int32_t *launches, int32_t reset);
 
 /* ---- the pixel head's full-resolution tail at the pixels that are read (csrc/pixhead.hip) -----------------------------

@@ -97,7 +97,7 @@ def scatter_softmax_csr(src: torch.Tensor, indptr: torch.Tensor, dim: int = 0):
     n_seg = indptr.shape[0] - 1
     seg = torch.repeat_interleave(torch.arange(n_seg, device=src.device), torch.diff(indptr))
     mx = torch.full((n_seg,) + src.shape[1:], float('-inf'), dtype=src.dtype, device=src.device)
-    mx = mx.index_reduce(0, seg, src.detach(), 'amax', include_self=True)
+    mx = mx.scatter_reduce(0, seg.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src.detach(), reduce='amax', include_self=True)
     recentered_scores_exp = (src - mx[seg]).exp()
     sum_per_index = torch.zeros((n_seg,) + src.shape[1:], dtype=src.dtype, device=src.device).index_add(0, seg, recentered_scores_exp)
     return recentered_scores_exp.div(sum_per_index[seg])

@@ -162,3 +162,42 @@ def test_ops_compose_to_the_fused_attention():
     out = torch.empty_like(x)
     out[sort_idx] = x
     assert torch.allclose(out, ref, atol=1e-10)
+
+
+def test_python_layer_over_the_operator_backend_equals_the_fused_oracle():
+    """oracle.sptr_layer_ref (sptr/functional.py's autograd Functions + modules.py:11-66 + utils.py:49-95 restated over a
+    `sptr_cuda`-shaped backend) over the CPU operator oracle == oracle.sptr_ref.sparse_self_attention (the formulation the
+    fused kernel is held to), forward and every gradient; cubic and spherical (exponential split) branches."""
+    from functools import partial
+    from oracle import sptr_layer_ref as P
+    lay = P.layer(P.CpuBackend())
+    for split_a, window, quant, qgl, L in ((None, [0.6, 0.6, 0.6], [0.025, 0.025, 0.025], 24, 47),
+                                           (0.0125, [2.0, 2.0, 120.0], [2 / 24, 2 / 24, 5.0], 24, 48)):
+        xyz, b = _tokens(seed=5)
+        if split_a is not None:
+            xyz = S.cart2sphere(xyz - torch.tensor([3.0, 3.0, 1.0]))
+        h, d = 3, 16
+        g = torch.Generator().manual_seed(11)
+        q, k, v = (torch.randn(len(xyz), h, d, generator=g) for _ in range(3))
+        tq, tk, tv = (0.2 * torch.randn(L, 3, h, d, generator=g) for _ in range(3))
+        window, quant = np.array(window, dtype=np.float32), np.array(quant, dtype=np.float32)
+        # index structures: the layer's own (precompute_all through the backend) equal the oracle's
+        i0, i0o, n_max, i1, i1o, sort_idx = lay.get_indices_params(xyz, b, window, False)
+        r0, r0o, rn, r1, r1o, rsort = S.get_indices_params(xyz, b, window)
+        assert n_max == rn and torch.equal(i0, r0) and torch.equal(i1, r1) and torch.equal(i0o.long(), r0o) \
+            and torch.equal(i1o.long(), r1o) and torch.equal(sort_idx, rsort)
+        leaves = [t.clone().requires_grad_(True) for t in (q, k, v, tq, tk, tv)]
+        out = lay.sparse_self_attention(leaves[0], leaves[1], leaves[2], xyz, i0.int(), i0o.int(), n_max, i1.int(), i1o.int(), sort_idx,
+                                        window, False, pe_type='contextual', rel_query=True, rel_key=True, rel_value=True,
+                                        quant_size=quant, quant_grid_length=qgl, relative_pos_query_table=leaves[3],
+                                        relative_pos_key_table=leaves[4], relative_pos_value_table=leaves[5],
+                                        split_func=None if split_a is None else partial(S.exponential_split, a=split_a))
+        ref_leaves = [t.clone().requires_grad_(True) for t in (q, k, v, tq, tk, tv)]
+        ref = S.sparse_self_attention(ref_leaves[0], ref_leaves[1], ref_leaves[2], xyz, r0, r0o, rn, r1, r1o, rsort, window, quant,
+                                      qgl, ref_leaves[3], ref_leaves[4], ref_leaves[5], split_a)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+        go = torch.randn(out.shape, generator=g)
+        out.backward(go)
+        ref.backward(go)
+        for a, b_ in zip(leaves, ref_leaves):
+            assert torch.allclose(a.grad, b_.grad, rtol=1e-4, atol=1e-5 * float(b_.grad.abs().max()) + 1e-6)

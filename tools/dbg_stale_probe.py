@@ -75,7 +75,9 @@ d = T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234, image_hw=hw))
 run = _runner(1.0, 2.0)
 state = {k: v.clone() for k, v in run.model.state_dict().items()}
 prev, all_rec, dev_steps, rec_steps = None, [], [], []
-unwritten_steps, ghost_steps = [], []
+unwritten_steps, ghost_steps, value_steps = [], [], []
+ref_calls = None
+main_stream = torch.cuda.current_stream().cuda_stream
 read_wg()
 for step in range(steps):
     run.model.load_state_dict(state)
@@ -101,6 +103,36 @@ for step in range(steps):
                   '%d weight rows / %d index rows NEVER WRITTEN (rows %s.., workgroups %s)'
                   % (step, ln, npts, scale, st, len(missing), missing[:8].tolist(), len(wrongptr), nbw, nbi, rows[:4].tolist(),
                      torch.unique(rows // 256)[:12].tolist()), flush=True)
+    # values: every launch against the same launch of the first step (the batch and the state are the same every step)
+    cur = [(npts, scale, st == main_stream, w.cpu(), i8.cpu()) for ln, npts, scale, w, i8, st in calls]
+    if ref_calls is None:
+        ref_calls = cur
+        print('%d ti_weights launches per step: %s' % (len(cur), [('main' if m else 'side', n_, sc) for n_, sc, m, _, _ in cur]), flush=True)
+    else:
+        for j, ((n_, sc, m, w, i8), (_, _, _, rw, ri)) in enumerate(zip(cur, ref_calls)):
+            dw = (w != rw).any(1)
+            di = (i8 != ri).any(1)
+            if bool(dw.any()) or bool(di.any()):
+                value_steps.append(step)
+                rows = dw.nonzero().view(-1)
+                print('step %d: launch #%d of the step (%s stream, n %d, scale %s): %d weight rows / %d index rows differ from step 0; rows %s .. %s, workgroups %s'
+                      % (step, j, 'main' if m else 'side', n_, sc, int(dw.sum()), int(di.sum()), rows[:4].tolist(), rows[-2:].tolist(),
+                         torch.unique(rows // 256)[:16].tolist()), flush=True)
+                dbg2 = np.zeros((2, 81920, 4), np.uint32)
+                L.call('u2mkd_debug_probe_rows_read', dbg2.ctypes.data, calls[j][0] % 16)
+                dbg, tim = dbg2[0], dbg2[1]
+                bad = rows.numpy()
+                good = np.setdiff1d(np.arange(n_), bad)
+                print('     thread durations (10 ns ticks): deviating rows median %d max %d; all other rows median %d, 99.9th percentile %d, max %d; TRAPSTS of deviating rows %s, of the others %s; STATUS %s / %s'
+                      % (np.median(tim[bad, 0]), tim[bad, 0].max(), np.median(tim[good, 0]), np.percentile(tim[good, 0], 99.9), tim[good, 0].max(),
+                         [hex(v) for v in np.unique(tim[bad, 1])[:6]], [hex(v) for v in np.unique(tim[good, 1])[:6]],
+                         [hex(v) for v in np.unique(tim[bad, 2])[:6]], [hex(v) for v in np.unique(tim[good, 2])[:6]]), flush=True)
+                for r in rows[:4].tolist():
+                    miss = int(dbg[r, 0]) & 0xff
+                    print('     row %d now %s | step 0 %s | idx now %s | the thread SAW idx == -1 at corners %s (xcc %d), computed w[0] = %.4f, fractions %s, launch %d (expected %d)'
+                          % (r, [round(x, 4) for x in w[r].tolist()], [round(x, 4) for x in rw[r].tolist()], i8[r].tolist(),
+                             [k for k in range(8) if miss >> k & 1], int(dbg[r, 0]) >> 8 & 0xf, float(dbg[r, 1:2].view(np.float32)[0]),
+                             [int(dbg[r, 2]) & 0xff, int(dbg[r, 2]) >> 8 & 0xff, int(dbg[r, 2]) >> 16 & 0xff], int(dbg[r, 3]), calls[j][0]), flush=True)
     ghosts = [(r, b, int(wg[r, b, 0]) - 1, int(wg[r, b, 1])) for r, b in zip(*np.nonzero((wg[:, :, 0] != 0) & ~np.isin(wg[:, :, 0], list(mine))))]
     if ghosts:
         ghost_steps.append(step)
@@ -123,6 +155,7 @@ for step in range(steps):
                   % (e['i'], e['k'], e['launch'], e['xcc'], e['hwid'], e['v_plain'], e['v_agent'], e['v_sys'], e['v_after_inv'], e['t']), flush=True)
     prev = t
 print('steps %d: %d with rows never written / workgroups without a record %s; %d with ghost records %s' % (steps, len(unwritten_steps), unwritten_steps[:20], len(ghost_steps), ghost_steps[:20]))
+print('steps %d: %d with ti_weights outputs that differ from step 0: %s' % (steps, len(set(value_steps)), sorted(set(value_steps))[:30]))
 print('steps %d: %d with probe records %s; %d with deviating teacher rows %s' % (steps, len(rec_steps), rec_steps[:20], len(dev_steps), dev_steps[:20]))
 if all_rec:
     r = np.concatenate(all_rec)

@@ -18,7 +18,11 @@ run() {            # name, steps, env...
 }
 for w in $WHICH; do
     case $w in
-    probe) echo "== probe"; timeout -k 10 600 python tools/dbg_stale_probe.py $((STEPS + 50)) 360 640 > $OUT/probe.log 2>&1; echo "   rc $?"; tail -n 14 $OUT/probe.log;;
+    probeA) echo "== probe, student after teacher"; U2MKD_DEBUG_ORDER=student_after_teacher timeout -k 10 600 python tools/dbg_stale_probe.py $STEPS 360 640 > $OUT/probeA.log 2>&1; echo "   rc $?"; grep -v "^step\|^ \|MIOpen" $OUT/probeA.log | tail -n 6;;
+    probeB) echo "== probe, teacher after camera head"; U2MKD_DEBUG_ORDER=teacher_after_camera timeout -k 10 600 python tools/dbg_stale_probe.py $STEPS 360 640 > $OUT/probeB.log 2>&1; echo "   rc $?"; grep -v "^step\|^ \|MIOpen" $OUT/probeB.log | tail -n 6;;
+    probeC) echo "== probe, teacher alone on the GPU"; U2MKD_DEBUG_ORDER=teacher_after_camera,student_after_teacher timeout -k 10 600 python tools/dbg_stale_probe.py $STEPS 360 640 > $OUT/probeC.log 2>&1; echo "   rc $?"; grep -v "^step\|^ \|MIOpen" $OUT/probeC.log | tail -n 6;;
+    probeD) echo "== probe, no deferred weight gradients"; U2MKD_OVERLAP_WGRAD=0 timeout -k 10 600 python tools/dbg_stale_probe.py $STEPS 360 640 > $OUT/probeD.log 2>&1; echo "   rc $?"; grep -v "^step\|^ \|MIOpen" $OUT/probeD.log | tail -n 6;;
+    probe) echo "== probe"; timeout -k 10 600 python tools/dbg_stale_probe.py $((STEPS + 50)) 360 640 > $OUT/probe.log 2>&1; echo "   rc $?"; grep -v "MIOpen" $OUT/probe.log | tail -n 40;;
     base) run base $STEPS A=1;;
     nocache) run nocache 40 PYTORCH_NO_HIP_MEMORY_CACHING=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1;;
     serialize) run serialize $STEPS AMD_SERIALIZE_KERNEL=3;;

@@ -367,6 +367,11 @@ __device__ __forceinline__ int64_t probe_word(const int64_t *p, int64_t i, int k
 // from its launch's row and as a record in a row that is not of this step
 constexpr int kWgRing = 64, kWgMax = 2048;
 __device__ uint2 g_wg_seen[kWgRing][kWgMax];
+// what every thread of a probe launch SAW and COMPUTED, kept apart from its outputs: {bit k = (idx of corner k == -1) | xcc << 8,
+// bits of its normalised w[0], the three cell fractions as small integers, launch}
+constexpr int kRowRing = 16, kRowMax = 81920;
+__device__ uint4 g_row_dbg[kRowRing][kRowMax];
+__device__ uint4 g_row_dbg2[kRowRing][kRowMax];     // {wall-clock ticks between the thread's first load and its stores, TRAPSTS, STATUS, launch}
 
 __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const int64_t *__restrict__ idx_kn, int64_t n,
                                         float scale, float *__restrict__ w_n8, int32_t *__restrict__ idx_n8, unsigned launch) {
@@ -374,6 +379,7 @@ __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const
         g_wg_seen[launch % kWgRing][blockIdx.x] = make_uint2(launch + 1, (unsigned)(uintptr_t)w_n8);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint64_t t_begin = wall_clock64();
     const int64_t *cw = reinterpret_cast<const int64_t *>(coords + i);
     const int64_t c0 = probe_word(cw, i, 8, launch), c1 = probe_word(cw + 1, i, 9, launch);
     float4 p;
@@ -406,6 +412,16 @@ __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const
         sum += w[k];
     }
     sum += 1e-8f;
+    if (i < kRowMax) {
+        unsigned miss = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) miss |= (id[k] == -1 ? 1u : 0u) << k;
+        const unsigned frac = (unsigned)(int)(p.x - xf) | (unsigned)(int)(p.y - yf) << 8 | (unsigned)(int)(p.z - zf) << 16;
+        g_row_dbg[launch % kRowRing][i] = make_uint4(miss | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 8,
+                                                     __float_as_uint(w[0] / sum), frac, launch);
+        g_row_dbg2[launch % kRowRing][i] = make_uint4((unsigned)(wall_clock64() - t_begin), __builtin_amdgcn_s_getreg((31 << 11) | 3),
+                                                      __builtin_amdgcn_s_getreg((31 << 11) | 2), launch);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         w_n8[i * 8 + k] = w[k] / sum;
@@ -552,6 +568,16 @@ int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int
     return 0;
 }
 int32_t u2mkd_debug_probe_entry_bytes(void) { return (int32_t)sizeof(ProbeEntry); }
+// debug: one launch's per-thread records ([81920] x uint4, see g_row_dbg) of ring slot `slot`
+int u2mkd_debug_probe_rows_read(void *dst, int32_t slot) {
+    U2_REQUIRE(dst && slot >= 0 && slot < kRowRing, "u2mkd_debug_probe_rows_read: bad argument");
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_row_dbg), sizeof(uint4) * kRowMax, sizeof(uint4) * kRowMax * (size_t)slot);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(reinterpret_cast<char *>(dst) + sizeof(uint4) * kRowMax, HIP_SYMBOL(g_row_dbg2), sizeof(uint4) * kRowMax,
+                                                 sizeof(uint4) * kRowMax * (size_t)slot);
+    if (e != hipSuccess) { set_error("u2mkd_debug_probe_rows_read: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
 // debug: the per-workgroup argument records of the probe launches ([64 launches mod 64][2048 workgroups] x {launch + 1, low 32
 // bits of the output pointer}), optionally cleared; *launches = number of probe launches so far
 int u2mkd_debug_probe_wg_read(void *dst, int32_t *launches, int32_t reset) {

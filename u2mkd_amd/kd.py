@@ -360,9 +360,13 @@ class TSDFull(nn.Module):
         if _CAMERA_STREAM and self.training:
             # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
             stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
+        if 'teacher_after_camera' in _DEBUG_ORDER:      # (debug, NOTES N9: the teacher starts when the camera head has finished)
+            side.wait_stream(_side_stream(in_mod['teacher']['lidar'].F, 'camera'))
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
             t = self.model_t(in_mod['teacher'])
+        if 'student_after_teacher' in _DEBUG_ORDER:     # (debug: the student's LiDAR branch starts when the teacher has finished)
+            main.wait_stream(side)
         ret = {'stu': self.model_s(stu_in)}
         main.wait_stream(side)
         for v in _tensors(t):
@@ -372,6 +376,7 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
+_DEBUG_ORDER = os.environ.get('U2MKD_DEBUG_ORDER', '')      # (tools/stale_discriminators.sh only)
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 
 
