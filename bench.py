@@ -450,6 +450,7 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
     from u2mkd_amd import lidar, train as T
     from u2mkd_amd.synth import synth_batch, synth_kd_batch
     torch.manual_seed(0)
+    build_step.watch = None
     amp = 'bf16' if (dtype or args.dtype) == 'bf16' else False
     n_vox = voxels or args.voxels
     if workload == 'spvcnn':
@@ -499,8 +500,11 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
     counter = [0]
     nxt = [None]
     prefetch = os.environ.get('U2MKD_PREFETCH_GEOMETRY', '1') != '0'
+    watch = T.TeacherWatch(model.model_t)       # (one clone of the teacher's logits per step, on its stream: ~5 MB)
+    build_step.watch = watch
 
     def step():
+        watch.key = counter[0] % n_batches
         # a fresh device copy of the next resident batch: new tensor objects every step (what the data loader's
         # host-to-device copy hands the reference's _prepare_input, core/nusc_trainers.py:257-279), so nothing cached
         # on a batch tensor -- point<->pixel plans, kernel maps, schedules -- survives from an earlier step.
@@ -565,6 +569,7 @@ def run_rank(args):
         log('model built, scene resident; warm-up')
         dt, loss = timed_run(step, args.warmup, args.steps, world)
         log('timed region done: %.3f s' % dt)
+        teacher_bad, teacher_compared = (build_step.watch.deviating_steps() if getattr(build_step, 'watch', None) else (None, None))
         result.update({
             'metric': METRIC, 'value': round(world * n_pts * args.steps / dt, 1), 'unit': 'points/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -576,7 +581,10 @@ def run_rank(args):
                                                  'schedules, window and point<->pixel plans are rebuilt inside the timed '
                                                  'region (the voxel sets / kernel maps of batch i+1 during step i, between '
                                                  'its forward and backward: one geometry pass per step)' % args.batches,
-                       'final_loss': round(loss, 5)},
+                       'final_loss': round(loss, 5),
+                       # the frozen teacher is a pure function of the batch: steps (warm-up + timed) whose teacher logits differ in
+                       # any bit from the first step that ran the same resident batch (train.TeacherWatch; NOTES N9)
+                       'teacher_deviating_steps': teacher_bad, 'teacher_steps_compared': teacher_compared},
             # what the N > 1 path actually ran on: the process group the gradient buckets and the BatchNorm statistics were
             # reduced over, and the spread of the ranks' own clocks over the same timed region
             'distributed': {'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),

@@ -148,8 +148,7 @@ def main(argv=None):
     cfg = builder.Config.load(args.config, recursive=True)
     cfg.update(opts)
     cfg.update({k: v for k, v in vars(args).items() if k != 'config'})
-    if not args.non_dist:
-        D.configure_runtime()                  # (before the first HIP call of the process)
+    D.configure_runtime()                      # (before the first HIP call of the process)
     if not torch.cuda.is_available():
         raise RuntimeError('run_training.py drives the HIP operators: no GPU is visible (there is no CPU fallback)')
     if not args.non_dist:

@@ -6,8 +6,8 @@ BF16 STORAGE between the sparse operators.  The CPU oracle cannot run this size,
 properties (the per-operator and small-scene parity against the oracle / the reference goldens is in
 test_gpu_bf16_rows.py, test_golden_teacher_multisweep.py, test_kd_path.py):
   * run-to-run reproducibility of the bf16 step from one state: the frozen teacher (this package's order-deterministic
-    kernels throughout, SphereFormer's Linear layers included) bit for bit on its own and to within one bf16 step on a
-    sliver of its rows beside the student's streams; the student, whose camera branch runs
+    kernels throughout, SphereFormer's Linear layers included) bit for bit over ten repetitions beside the student's streams;
+    the student, whose camera branch runs
     MIOpen convolutions that are not run-to-run reproducible (measured: the first module whose output differs between two
     identical forwards is pix_branch.layer2.0.conv1, DESIGN.md section 7b), within rounding noise;
   * every student parameter receives a finite fp32 gradient, the frozen teacher none;
@@ -62,20 +62,18 @@ def test_scene_is_configs4_sized(world):
 def test_bf16_step_is_reproducible_and_trains_every_student_parameter(world):
     nb, d, run, state = world
     res = []
-    for _ in range(3):            # (the first pass also settles MIOpen's solver choice)
+    REPS = 10
+    for _ in range(REPS):         # (the first pass also settles MIOpen's solver choice)
         run.model.load_state_dict(state)
         out, ld = _step(run, d, True)
         res.append((out['t']['x_vox'].clone(), out['stu']['x_vox'].detach().float().clone(),
                     {k: (torch.stack(list(v)) if isinstance(v, (list, tuple)) else v).detach().float().clone() for k, v in ld.items()}))
     assert res[0][0].shape[0] == nb['teacher']['num_vox'][0]
-    # teacher: every kernel on its path is order-deterministic and alone it reproduces bit for bit
-    # (tools/dbg_determinism.py); next to the student's streams about one run in five moves a few hundred of the
-    # 276 000 rows by ONE bf16 step (tools/dbg_determinism_kd.py) -- bound that, do not hide it
-    for a_, b_ in ((res[0][0], res[1][0]), (res[1][0], res[2][0])):
-        dt = (a_.float() - b_.float()).abs()
-        rows = (dt.max(1).values > 0).float().mean()
-        # (seen: 0 .. 0.5 % of the rows, every one of them by a single bf16 step)
-        assert float(rows) < 0.02 and float(dt.max()) <= 2.0 ** -6 * float(b_.float().abs().max()), (float(rows), float(dt.max()))
+    # teacher: every kernel on its path is order-deterministic (this package's kernels throughout, SphereFormer's Linear layers
+    # included): bit-identical logits in every repetition, next to the student's streams (NOTES N9 for what rounds 3-4 saw here)
+    for i in range(1, REPS):
+        assert torch.equal(res[0][0], res[i][0]), ('teacher logits of repetition %d differ from repetition 0' % i,
+                                                   float((res[0][0].float() - res[i][0].float()).abs().max()))
     # student: bf16 logits of two runs agree to within two bf16 steps on all but a sliver of the rows (a last-place
     # difference upstream of a rounding edge moves a value by one bf16 step), the loss terms to 3e-3 relative
     a, b = res[1][1], res[2][1]

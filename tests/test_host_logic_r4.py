@@ -21,12 +21,15 @@ def test_deferred_joins_are_off_until_a_trainer_enables_them():
     assert r.stdout.split() == ['False', 'True', 'False', '[]']
 
 
-def test_import_sets_eight_hardware_queues_unless_the_user_chose():
+def test_hardware_queue_setting_is_the_launchers_not_the_imports():
+    """importing the package leaves the environment alone; distributed.configure_runtime() (called by bench.py /
+    run_training.py before their first GPU call) sets GPU_MAX_HW_QUEUES=8 unless the user exported a value."""
     env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
-    r = subprocess.run([sys.executable, '-c', 'import sys, os; sys.path.insert(0, %r); import u2mkd_amd; print(os.environ["GPU_MAX_HW_QUEUES"])' % ROOT],
+    r = subprocess.run([sys.executable, '-c', 'import sys, os; sys.path.insert(0, %r); import u2mkd_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"));'
+                        'from u2mkd_amd import distributed as D; D.configure_runtime(); print(os.environ.get("GPU_MAX_HW_QUEUES"))' % ROOT],
                        capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0 and r.stdout.strip() == '8', (r.stdout, r.stderr[-1000:])
-    r = _py('import os, u2mkd_amd\nprint(os.environ["GPU_MAX_HW_QUEUES"])', {'GPU_MAX_HW_QUEUES': '4'})
+    assert r.returncode == 0 and r.stdout.split() == ['None', '8'], (r.stdout, r.stderr[-1000:])
+    r = _py('import os, u2mkd_amd\nfrom u2mkd_amd import distributed as D\nD.configure_runtime()\nprint(os.environ["GPU_MAX_HW_QUEUES"])', {'GPU_MAX_HW_QUEUES': '4'})
     assert r.returncode == 0 and r.stdout.strip() == '4'
 
 

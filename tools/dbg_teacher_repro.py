@@ -23,15 +23,18 @@ if os.environ.get('DBG_FENCE') == '1':        # an event record (a barrier packe
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 hw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (900, 1600)
 d = T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234, image_hw=hw))
-run = _runner(1.0, 2.0)
+amp = os.environ.get('DBG_AMP') or False          # DBG_AMP=bf16: the step under bf16 autocast (bf16 rows, library kernels in bf16)
+run = _runner(float(os.environ.get('DBG_CR', '1.0')), 2.0, amp=amp)
 state = {k: v.clone() for k, v in run.model.state_dict().items()}
-prev = None
+prev, rows_total = None, 0
 for i in range(steps):
     run.model.load_state_dict(state)
-    out, ld = _step(run, d, False)
+    out, ld = _step(run, d, bool(amp))
     t = out['t']['x_vox'].clone()
     if prev is not None:
         dt = (t - prev).abs()
         rows = int((dt.max(1).values > 0).sum())
+        rows_total += int(rows > 0)
         print('step %d: %d of %d teacher rows differ, max |diff| %.3g (max |logit| %.3g)' % (i, rows, t.shape[0], float(dt.max()), float(t.abs().max())), flush=True)
     prev = t
+print('SUMMARY: %d steps, %d deviating comparisons' % (steps, rows_total), flush=True)

@@ -334,6 +334,23 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost));
     printf("alone: div_kernel in-kernel mismatches %u\n", h);
 
+    {   // rate of the matrix instructions used as aggressors, one launch filling the chip (1024 workgroups x 4 waves)
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        struct { const char *name; void (*k)(float *, int); double flop; int iters; } rates[] = {
+            {"v_mfma_f32_16x16x32_bf16", ag_bf16_16x16x32, 2.0 * 16 * 16 * 32, 4096}, {"v_mfma_f32_16x16x16_bf16", ag_bf16_16x16x16_1k, 2.0 * 16 * 16 * 16, 8192},
+            {"v_mfma_f32_16x16x4_f32", ag_f32_16x16x4, 2.0 * 16 * 16 * 4, 4096}, {"v_mfma_f32_16x16x32_f16", ag_f16_16x16x32, 2.0 * 16 * 16 * 32, 4096}};
+        for (auto &r : rates) {
+            hipLaunchKernelGGL(r.k, dim3(1024), dim3(256), 0, sa, scratch, r.iters);
+            CK(hipEventRecord(e0, sa));
+            hipLaunchKernelGGL(r.k, dim3(1024), dim3(256), 0, sa, scratch, r.iters);
+            CK(hipEventRecord(e1, sa));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("rate: %-28s %.1f TFLOP/s (dependent chain per wave, 4096 waves)\n", r.name, 1024.0 * 4 * r.iters * r.flop / (ms * 1e-3) / 1e12);
+        }
+    }
     const int NA = 16;
     const char *aname[NA] = {"nothing", "the same victim kernels", "exp/rcp/sqrt loop", "LDS + barriers", "MFMA 16x16x32 bf16 loop", "streaming copy",
                              "MFMA 16x16x4 f32 loop", "MFMA 32x32x16 bf16 loop", "MFMA 16x16x32 bf16, 64 workgroups only",

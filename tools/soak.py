@@ -34,11 +34,16 @@ torch.cuda.reset_peak_memory_stats()
 sizes = [int(rng.choice([2000, 9000, 30000, 80000])) for _ in range((int(sys.argv[2]) if len(sys.argv) > 2 else 30) + 1)]
 batches = [T.kd_batch_to_device(synth_kd_batch(n, 1, seed=100 + i, image_hw=(360, 640))) for i, n in enumerate(sizes[:6])]
 cur = T.fresh_batch(batches[0])
+watch = T.TeacherWatch(kd_model.model_t)     # the frozen teacher must give bit-identical logits whenever a batch comes round again
 for it in range(len(sizes) - 1):
     nxt = T.fresh_batch(batches[(it + 1) % len(batches)])
+    watch.key = it % len(batches)
     loss = float(kd_run(cur, prefetch=nxt))
     assert np.isfinite(loss), (it, loss)
     cur = nxt
     if it % 5 == 0:
         print(f'kd it {it}: points {sizes[it % len(batches)]} loss {loss:.4f} peak mem {torch.cuda.max_memory_allocated() / 2**20:.0f} MiB', flush=True)
+bad, compared = watch.deviating_steps()
+assert bad == 0, f'the frozen teacher deviated in {bad} of {compared} revisited steps'
+print(f'kd soak: teacher bit-identical in all {compared} revisited steps')
 print(f'kd soak ok: {time.time() - t0:.1f} s, peak {torch.cuda.max_memory_allocated() / 2**20:.0f} MiB')

@@ -7,11 +7,8 @@ There is no CPU / PyTorch fallback: operators raise on CPU tensors.
 """
 __version__ = '0.1.0'
 
-import os as _os
-
-# distributed.configure_runtime: 8 HIP hardware queues for the step's five streams -- read by the HIP runtime at its first call,
-# so it is set at import (a value the user exported wins); importing `distributed` itself would pull in torch.distributed
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# (Importing the package changes nothing in the process environment.  The launchers -- bench.py, run_training.py -- call
+# ``distributed.configure_runtime()`` before their first GPU call: 8 HIP hardware queues for the step's five streams.)
 
 
 def install_as_torchsparse():

@@ -6,6 +6,37 @@ namespace u2mkd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- the bf16 matrix instruction of every kernel of this library --------------------------------------------------------------
+// D += A[16 x 32] * B[32 x 16] on bf16 operands, fp32 accumulate; a / b = the lane's 8 consecutive k of the 16x16x32 operand maps
+// (lane l: row or column l & 15, k = 8 (l >> 4) + j).
+//
+// gfx950's own form, v_mfma_f32_16x16x32_bf16, is NOT used by default: while waves of it (or of v_mfma_f32_32x32x16_bf16 /
+// v_mfma_f32_16x16x32_f16) execute, waves of OTHER kernels resident on the chip -- another HIP stream's -- can compute wrong
+// results from correct inputs: tools/repro_concurrent_kernels.hip, a program without torch, shows u2mkd_ti_weights returning a
+// weight of 0 for lanes 48..63 of a wave in ~50 % of its launches next to such a loop, and never next to the gfx942 forms, the
+// fp32 matrix instructions or any non-matrix load (NOTES N9).  The product is the same set of 32 products either way: two
+// v_mfma_f32_16x16x16_bf16 take k = 8 (l >> 4) + {0..3} and + {4..7} of the same operand registers (a dot product does not care
+// which slot a k sits in as long as A and B agree), so fragments, LDS images and weight layouts are unchanged; only the order in
+// which the 32 products reach the fp32 accumulator differs (still fixed, results stay bitwise reproducible).
+// -DU2MKD_MFMA_GFX950_K32=1 builds the gfx950 form (tools/build_variant.sh: A/B runs only).
+#ifndef U2MKD_MFMA_GFX950_K32
+#define U2MKD_MFMA_GFX950_K32 0
+#endif
+typedef short u2_s16x8 __attribute__((ext_vector_type(8)));
+typedef short u2_s16x4 __attribute__((ext_vector_type(4)));
+template <class V8>
+__device__ __forceinline__ f32x4 mfma_bf16_k32(const V8 &a, const V8 &b, f32x4 c, int = 0, int = 0, int = 0) {
+    static_assert(sizeof(V8) == 16, "mfma_bf16_k32: 8 bf16 per lane");
+#if U2MKD_MFMA_GFX950_K32
+    typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+#else
+    const u2_s16x8 a8 = __builtin_bit_cast(u2_s16x8, a), b8 = __builtin_bit_cast(u2_s16x8, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a8.lo, b8.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a8.hi, b8.hi, c, 0, 0, 0);
+#endif
+}
+
 // Rows a table-walking forward launch covers: sorted rows [begin, end) of the neighbour table
 // nbr[k * ld + row].
 struct RowRange {

@@ -254,7 +254,7 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                     f32x4 c = acc[rb][n];
 #pragma unroll
                     for (int p = 0; p < NWF; ++p)
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(px_bf8(bw[u][NWF * n + p]), px_bf8(a[rb & 1][p]), c, 0, 0, 0);
+                        c = mfma_bf16_k32(px_bf8(bw[u][NWF * n + p]), px_bf8(a[rb & 1][p]), c, 0, 0, 0);
                     acc[rb][n] = c;
                 }
                 continue;
@@ -265,12 +265,12 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 const px_bf16x8 wh = px_bf8(bw[u][NWF * n]), wm = px_bf8(bw[u][NWF * n + NWF / 2]), wl = px_bf8(bw[u][NWF * n + NWF - 1]);
                 // the six partial products, low order first; weights = A operand: D[col][pair]
                 f32x4 c = acc[rb][n];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                c = mfma_bf16_k32(wl, xh, c, 0, 0, 0);
+                c = mfma_bf16_k32(wh, xl, c, 0, 0, 0);
+                c = mfma_bf16_k32(wm, xm, c, 0, 0, 0);
+                c = mfma_bf16_k32(wm, xh, c, 0, 0, 0);
+                c = mfma_bf16_k32(wh, xm, c, 0, 0, 0);
+                c = mfma_bf16_k32(wh, xh, c, 0, 0, 0);
                 acc[rb][n] = c;
             }
         }

@@ -504,18 +504,18 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                         const bf16x8 wh = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk][n]), wm = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 1][n]),
                                      wl = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 2][n]);
                         const bf16x8 xh = as_bf8(a[3 * sk]), xm = as_bf8(a[3 * sk + 1]), xl = as_bf8(a[3 * sk + 2]);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc1, 0, 0, 0);
+                        acc0 = mfma_bf16_k32(wl, xh, acc0, 0, 0, 0);
+                        acc1 = mfma_bf16_k32(wh, xl, acc1, 0, 0, 0);
+                        acc0 = mfma_bf16_k32(wm, xm, acc0, 0, 0, 0);
+                        acc1 = mfma_bf16_k32(wm, xh, acc1, 0, 0, 0);
+                        acc0 = mfma_bf16_k32(wh, xm, acc0, 0, 0, 0);
+                        acc1 = mfma_bf16_k32(wh, xh, acc1, 0, 0, 0);
                     }
                 } else if (B16) {
 #pragma unroll
                     for (int sk = 0; sk < CIN / 32; ++sk) {
-                        if (sk & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc0, 0, 0, 0);
+                        if (sk & 1) acc1 = mfma_bf16_k32(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc1, 0, 0, 0);
+                        else acc0 = mfma_bf16_k32(as_bf8(bw[SB ? 0 : (u & 1)][sk][n]), as_bf8(a[sk]), acc0, 0, 0, 0);
                     }
                 } else {
                     // two interleaved accumulation chains (16x16x4 f32: 40-cycle dependent latency, 32 issue)

@@ -179,15 +179,15 @@ conv_wgrad_x3_kernel(const float *__restrict__ a, int ca, const float *__restric
             for (int n = 0; n < 2; ++n) {
                 f32x4 c = acc[m][n];
                 if (B16) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][0], fb[n][0], c, 0, 0, 0);
                 } else {
                     // the six partial products, low order first (plane 0 = h, 1 = m, 2 = l)
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL - 1], fb[n][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][NPL - 1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL / 2], fb[n][NPL / 2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][NPL / 2], fb[n][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][NPL / 2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][0], fb[n][0], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][NPL - 1], fb[n][0], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][0], fb[n][NPL - 1], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][NPL / 2], fb[n][NPL / 2], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][NPL / 2], fb[n][0], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][0], fb[n][NPL / 2], c, 0, 0, 0);
+                    c = mfma_bf16_k32(fa[m][0], fb[n][0], c, 0, 0, 0);
                 }
                 acc[m][n] = c;
             }

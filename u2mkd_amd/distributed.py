@@ -44,9 +44,9 @@ def init_from_env(backend: str | None = None):
 
 
 def configure_runtime():
-    """Process-level HIP settings; must run before the process's first HIP call (``import u2mkd_amd`` runs it; a launcher
-    that touches the GPU before that import calls it on its first line -- ``torch.cuda.is_available()`` already
-    initialises the runtime, and the runtime reads the variable only then).
+    """Process-level HIP settings; must run before the process's first HIP call (the launchers -- bench.py,
+    run_training.py -- call it on their first line; nothing is changed at ``import u2mkd_amd``): the runtime reads the
+    variable at its initialisation only, so a late call warns and changes nothing.
 
     ``GPU_MAX_HW_QUEUES=8`` (the runtime's default is 4).  A training step keeps FIVE streams busy -- student LiDAR (main),
     frozen teacher, camera branch, weight gradients, the next batch's geometry -- and with 4 hardware queues the fifth
@@ -56,7 +56,16 @@ def configure_runtime():
     underneath the backward and the host stays a whole step ahead: 72.2 -> 71.6 / 69.9 / 70.4 ms (tools/host_lead.py).
     A multi-rank process needs the room for a second reason: RCCL's communicator brings streams of its own (with 4 queues
     +10.5 ms per KD step at ONE rank, tools/ddp_cost.py)."""
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    if 'GPU_MAX_HW_QUEUES' in os.environ:       # the user's choice wins
+        return
+    if torch.cuda.is_initialized():
+        import warnings
+        warnings.warn('u2mkd_amd.distributed.configure_runtime() was called after the HIP runtime had been initialised: '
+                      'GPU_MAX_HW_QUEUES keeps the runtime\'s default (4) and the step\'s fifth stream shares a hardware queue '
+                      '(a few percent of step time); call it before the first GPU call, or export GPU_MAX_HW_QUEUES=8',
+                      RuntimeWarning, stacklevel=2)
+        return
+    os.environ['GPU_MAX_HW_QUEUES'] = '8'
 
 
 def world() -> int:

@@ -14,7 +14,7 @@ from . import kd as KD
 from . import torchsparse as ts
 from .losses import MixLovaszCrossEntropy
 
-__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'kd_batch_to_device', 'fresh_batch', 'state_dict',
+__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'TeacherWatch', 'kd_batch_to_device', 'fresh_batch', 'state_dict',
            'load_state_dict', 'load_weights']
 
 
@@ -190,6 +190,41 @@ def fresh_batch(d):
             return type(v)(cp(x) for x in v)
         return v
     return {k: cp(v) for k, v in d.items()}
+
+
+class TeacherWatch:
+    """Bit-reproducibility monitor of the frozen teacher.  The teacher runs under ``no_grad`` with eval-mode BatchNorm
+    (core/nusc_trainers.py:285-324, tsd_full.py:590-596): its logits are a pure function of the batch, whatever the student
+    does next to it on the other streams.  A forward hook keeps a clone of every step's teacher logits under the key the
+    caller set (``watch.key = batch id``); ``deviating_steps()`` -- called after the run, it synchronises -- counts the steps
+    whose logits differ in any bit from the FIRST step that saw the same key.  bench.py reports it for its timed run
+    (``config.teacher_deviating_steps``), tools/soak.py asserts it is 0."""
+
+    def __init__(self, model_t):
+        self.key = None
+        self.log = []
+        self._handle = model_t.register_forward_hook(self._hook)
+
+    def _hook(self, module, inputs, output):
+        if self.key is not None:
+            self.log.append((self.key, output['x_vox'].detach().clone()))
+
+    def deviating_steps(self):
+        """(steps that differ from the first visit of their batch, steps compared)"""
+        first, bad, compared = {}, 0, 0
+        if self.log and self.log[0][1].is_cuda:
+            torch.cuda.synchronize()
+        for key, t in self.log:
+            if key not in first:
+                first[key] = t
+            else:
+                compared += 1
+                bad += int(not torch.equal(first[key], t))
+        return bad, compared
+
+    def close(self):
+        self._handle.remove()
+        self.log = []
 
 
 class KDStep:
