@@ -69,12 +69,14 @@ def parse():
     ap.add_argument('--kernel-only', action='store_true', help='run only the SubMConv3d roofline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--h2d', action='store_true',
+                    help='batches start in pinned host memory: every step includes its host-to-device copies (a secondary leg of the default run)')
     ap.add_argument('--no-roofline', action='store_true', help='skip the SubMConv3d roofline leg (child legs)')
     ap.add_argument('--no-full-size-images', action='store_true',
                     help='skip the KD step on 6 x 900x1600 images in `secondary`')
     ap.add_argument('--batches', type=int, default=4,
                     help='distinct resident batches rotated through the timed loop (every step gets fresh tensors)')
-    ap.add_argument('--child-timeout', type=int, default=300, help='seconds a secondary child process may take')
+    ap.add_argument('--child-timeout', type=int, default=360, help='seconds a secondary child process may take')
     ap.add_argument('--cpu-sample-voxels', type=int, default=20000)
     return ap.parse_args()
 
@@ -340,6 +342,19 @@ def micro():
     R.conv_forward(x, w, nbmaps, nbsizes, (n, n)); R.conv_backward(x, w, gy, nbmaps, nbsizes)
 out['micro_s'] = med(micro, 5)
 out['micro_n'] = n
+# (i') BASELINE.json configs[0] (BASELINE.md section 2 "Config 1"): SPVCNN cr 0.5, one 30 000-voxel scene, forward + Lovasz/CE +
+# backward + SGD on the CPU path, 1 warm-up, median of 3
+b0 = synth_batch(30000, 1, seed=1234)
+f0, c0, l0 = (torch.from_numpy(b0[k]) for k in ('feats', 'coords', 'labels'))
+m0 = O.fill_state_by_name(O.SPVCNN(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
+o0 = torch.optim.SGD(m0.parameters(), lr=0.24, momentum=0.9, weight_decay=1e-4, nesterov=True)
+def step0():
+    o = m0({'lidar': ots.SparseTensor(f0, c0)})['x_vox']
+    loss = O.mix_lovasz_cross_entropy(o, l0)
+    o0.zero_grad(); loss.backward(); o0.step()
+out['configs0_s'] = med(step0, 3)
+out['configs0_n'] = int(c0.shape[0])
+del m0, o0
 # (ii) the step on a bounded sample scene
 if workload == 'spvcnn':
     model = O.fill_state_by_name(O.SPVCNN(cr=cr, in_channel=4, num_classes=17, pres=0.05, vres=0.05)).train()
@@ -378,7 +393,7 @@ print(json.dumps(out))
 """
 
 
-def cpu_baseline_leg(args, timeout_s=420):
+def cpu_baseline_leg(args, timeout_s=480):
     """The CPU oracle (a port of the torchsparse v1.4.0 CPU algorithm: per kernel offset
     gather -> mm -> scatter-add; SwiftNet-18 is plain torch.nn on both sides) on the host cores, on a
     bounded sample of the bench workload, plus the CPU time of the roofline leg's micro-shape.  Runs
@@ -408,6 +423,10 @@ def cpu_baseline_leg(args, timeout_s=420):
         return dict(base, sample=sample + ' -- FAILED: %s' % type(e).__name__)
     return dict(base, value=round(n_vox / o['step_s'], 1), sample=sample + ', %.1f s' % o['step_s'],
                 parts_s={k: round(v, 3) for k, v in o['parts'].items()},
+                configs0={'value': round(o['configs0_n'] / o['configs0_s'], 1), 'unit': 'points/s', 'ms_per_step': round(o['configs0_s'] * 1e3, 1),
+                          'workload': 'BASELINE.json configs[0]: SPVCNN cr=0.5 LiDAR-only train step (fwd + Lovasz/CE + bwd + SGD) on one '
+                                      '%d-voxel synthetic scene, CPU oracle (torchsparse v1.4.0 CPU algorithm), %d threads, 1 warm-up, median of 3'
+                                      % (o['configs0_n'], threads)},
                 subm_conv_64x64_fwd_bwd={'ms': round(o['micro_s'] * 1e3, 2), 'N': o['micro_n'],
                                          'note': 'the roofline leg\'s shape on the CPU oracle (gather -> mm -> index_add per '
                                                  'offset, fwd + dX + dW), median of 5 after 1 warm-up, %d threads' % threads})
@@ -424,7 +443,8 @@ def child_leg(args, extra_argv, extra_env, workload_note):
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.child_timeout, env=env, start_new_session=True)
         o = json.loads(r.stdout.strip().splitlines()[-1])
-        return {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
+        return {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'ms_per_step_median': o.get('ms_per_step_median'),
+                'teacher_deviating_steps': o['config'].get('teacher_deviating_steps'), 'steps': o['steps'],
                 'warmup': o['warmup'], 'batches_rotated': o['config'].get('batches_rotated'),
                 'env': extra_env, 'leg_wall_s': round(time.perf_counter() - t0, 1), 'distributed': o.get('distributed'),
                 'workload': o['config']['workload'] + ' -- ' + workload_note}
@@ -442,7 +462,7 @@ _T0 = time.perf_counter()
 
 
 # --------------------------------------------------------------------------------- workloads
-def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=None, cr=None, cr_t=None):
+def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=None, cr=None, cr_t=None, h2d=False):
     """(step closure, points per step on this rank, description).  sweeps / dtype / voxels / cr / cr_t: the configs[4]
     variant (multi-sweep teacher scene of `voxels` points, bf16 autocast with bf16 storage, the `_B` widths cr 2.0 /
     cr_t 2.0 of configs/nuscenes/train/spformer_tsd_full_ours_star_B.yaml:34-36)."""
@@ -484,7 +504,10 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
     nb = nbs[0]
     n_pts = int(sum(nb['teacher']['num_pts']))
     assert all(int(sum(b['teacher']['num_pts'])) == n_pts for b in nbs)
-    resident = [T.kd_batch_to_device(b) for b in nbs]
+    # h2d: the batches stay in page-locked HOST memory and every step starts with their host-to-device copies (asynchronous, on
+    # the step's stream), as the reference's `_prepare_input` does with its pinned loader output (core/nusc_trainers.py:257-279)
+    resident = [T.pin_kd_batch(b) for b in nbs] if h2d else [T.kd_batch_to_device(b) for b in nbs]
+    fresh = T.kd_batch_to_device if h2d else T.fresh_batch
     desc = ('BASELINE.json configs[2]: SPVCNN+SphereFormer teacher (cr_t %g, frozen) + SwiftNet18/SPVCNN+SphereFormer student '
             '(cr %g) + KD losses train step, one %d-point scene + 6 cameras %dx%d per GPU'
             % (cr_t, cr, n_pts, image_hw[0], image_hw[1]))
@@ -511,10 +534,11 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
         # Software pipelining: the copy of batch i+1 is made inside step i and its geometry (voxel sets, kernel
         # maps: the host synchronisations) is prepared between step i's forward and backward (KDStep prefetch=);
         # every batch's geometry is built exactly once, inside the timed loop.
-        d = nxt[0] if nxt[0] is not None else T.fresh_batch(resident[counter[0] % n_batches])
+        d = nxt[0] if nxt[0] is not None else fresh(resident[counter[0] % n_batches])
         counter[0] += 1
-        nxt[0] = T.fresh_batch(resident[counter[0] % n_batches]) if prefetch else None
+        nxt[0] = fresh(resident[counter[0] % n_batches]) if prefetch else None
         return runner(d, prefetch=nxt[0])
+    step.runner = runner
     return step, n_pts, desc
 
 
@@ -529,13 +553,24 @@ def timed_run(step, warmup, steps, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    D.collective_counts(reset=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         loss = step()
+        marks[i + 1].record()       # end of step i on the stream the step's last work (optimizer) was queued on; no host wait
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    timed_run.median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    timed_run.min_max_ms = (per_step[0], per_step[-1])
+    cc = D.collective_counts(getattr(getattr(step, 'runner', None), 'net', None))
+    timed_run.collectives = {'sync_bn_all_gather_per_step': {k: round(v / steps, 1) for k, v in cc['all_gather'].items()},
+                             'sync_bn_all_reduce_per_step': {k: round(v / steps, 1) for k, v in cc['all_reduce'].items()},
+                             'gradient_all_reduce_per_step': cc.get('gradient_buckets_last_pass')}
     timed_run.per_rank = (D.min_over_ranks(dt), D.max_over_ranks(dt))     # fastest / slowest rank of this timed region
     return timed_run.per_rank[1], float(loss.detach())
 
@@ -565,7 +600,9 @@ def run_rank(args):
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     result = {}
     if not args.kernel_only:
-        step, n_pts, desc = build_step(args, rank, args.workload, args.image_hw)
+        step, n_pts, desc = build_step(args, rank, args.workload, args.image_hw, h2d=args.h2d)
+        if args.h2d:
+            desc += ' -- every step starts from a PINNED HOST batch (host-to-device copies inside the timed region)'
         log('model built, scene resident; warm-up')
         dt, loss = timed_run(step, args.warmup, args.steps, world)
         log('timed region done: %.3f s' % dt)
@@ -573,6 +610,9 @@ def run_rank(args):
         result.update({
             'metric': METRIC, 'value': round(world * n_pts * args.steps / dt, 1), 'unit': 'points/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            # (ms_per_step / value: the contract's wall clock over the K steps; median / min / max: the K intervals between
+            # consecutive end-of-step events on the GPU -- SURVEY 8d asks for the median)
+            'ms_per_step_median': round(timed_run.median_ms, 3), 'ms_per_step_min_max': [round(v, 3) for v in timed_run.min_max_ms],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': DTYPE_LABEL[args.dtype], 'data': 'synthetic',
             'config': {'workload': desc, 'points_per_gpu': n_pts, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
@@ -590,6 +630,9 @@ def run_rank(args):
             'distributed': {'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                             'rccl_world_size': (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
                             'gradient_reducer': 'u2mkd_amd.distributed.BucketedGradientAverage' if (world > 1 or os.environ.get('U2MKD_FORCE_DDP') == '1') else None,
+                            # collectives of one step on this rank (count, bytes sent): issued at N > 1; at one rank on the forced
+                            # N > 1 path (U2MKD_FORCE_DDP=1) the ones it WOULD issue; zeros on the plain one-GPU path
+                            'collectives_per_step': timed_run.collectives,
                             'ms_per_step_min_rank': round(timed_run.per_rank[0] / args.steps * 1e3, 3),
                             'ms_per_step_max_rank': round(timed_run.per_rank[1] / args.steps * 1e3, 3)},
         })
@@ -608,6 +651,7 @@ def run_rank(args):
                     s2, n2, d2 = build_step(args, rank, wl, hw, **extra)
                     dt2, l2 = timed_run(s2, w_, k_, 1)
                     sec[name] = {'value': round(n2 * k_ / dt2, 1), 'unit': 'points/s', 'ms_per_step': round(dt2 / k_ * 1e3, 3),
+                                 'ms_per_step_median': round(timed_run.median_ms, 3),
                                  'steps': k_, 'warmup': w_, 'batches_rotated': args.batches, 'workload': d2}
                     del s2
                     torch.cuda.empty_cache()
@@ -618,11 +662,17 @@ def run_rank(args):
             if args.workload == 'kd':
                 if not args.no_full_size_images and tuple(args.image_hw) != (900, 1600):
                     sec['kd_6cam_900x1600'] = child_leg(
-                        args, ['--image-hw', '900', '1600', '--steps', '6', '--warmup', str(max(args.batches + 1, 3))],
+                        args, ['--image-hw', '900', '1600', '--steps', str(max(args.steps, 20)), '--warmup', str(max(args.warmup, args.batches + 1))],
                         {'MIOPEN_FIND_MODE': 'FAST'},
-                        'BASELINE.json configs[2] at the literal camera size 6 x 900x1600 (SURVEY 8d: "report both"); '
-                        'child process, MIOPEN_FIND_MODE=FAST bounds the first-call kernel search')
+                        'BASELINE.json configs[2] at the literal camera size 6 x 900x1600 (SURVEY 8d: "report both"), the headline\'s '
+                        'K / W; child process, MIOPEN_FIND_MODE=FAST bounds the first-call kernel search of the warm-up (the solver '
+                        'chosen there is the one the timed steps run)')
                     log('secondary kd_6cam_900x1600 done')
+                sec['kd_h2d'] = child_leg(
+                    args, ['--h2d', '--steps', str(args.steps), '--warmup', str(max(args.warmup, args.batches + 1))], {},
+                    'the default KD step fed from PINNED HOST memory: the host-to-device copies of every batch (6 images + both '
+                    'point clouds) are inside the timed region (core/nusc_trainers.py:257-279)')
+                log('secondary kd_h2d done')
                 sec['kd_ddp_path_1rank'] = child_leg(
                     args, ['--steps', str(args.steps), '--warmup', str(max(args.warmup, args.batches + 1))], {'U2MKD_FORCE_DDP': '1'},   # the headline's own K / W: short runs of this step scatter by +-3 ms
                     'the default KD step on the N>1 code path (bucketed gradient averaging + SyncBatchNorm conversion over a '

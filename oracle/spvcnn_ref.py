@@ -58,10 +58,10 @@ def point_to_voxel(x, z):  # utils.py:40-65
 def voxel_to_point(x, z, nearest=False):  # utils.py:70-118
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None \
             or z.weights.get(x.s) is None:
-        off = get_kernel_offsets(2, x.s, 1)
+        off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
         old_hash = spf.sphash(torch.cat([torch.floor(z.C[:, :3] / x.s[0]).int() * x.s[0],
                                          z.C[:, -1].int().view(-1, 1)], 1), off)
-        pc_hash = spf.sphash(x.C)
+        pc_hash = spf.sphash(x.C.to(z.F.device))
         idx_query = spf.sphashquery(old_hash, pc_hash)
         weights = spf.calc_ti_weights(z.C, idx_query, scale=x.s[0]).transpose(0, 1).contiguous()
         idx_query = idx_query.transpose(0, 1).contiguous()

@@ -227,7 +227,7 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, bn, relu, group, world):
         from . import _lib as L
-        from .torchsparse.nn.functional import _gather_rows
+        from .torchsparse.nn.functional import _gather_rows, note_collective
         b, c, h, w = x.shape
         hw = h * w
         dev, st = x.device, L.stream()
@@ -235,6 +235,7 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
         stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
         L.call('u2mkd_bn2d_local_stats', L.ptr(x), b, c, hw, L.ptr(ws), L.ptr(stats), st)
         gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
+        note_collective('all_gather', stats)
         if world > 1:
             _gather_rows(gathered, stats, group)
         else:
@@ -256,7 +257,7 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         from . import _lib as L
-        from .torchsparse.nn.functional import _sum_over_ranks
+        from .torchsparse.nn.functional import _sum_over_ranks, note_collective
         x, weight, bias, res, mean, invstd, total = ctx.saved_tensors
         b, c, h, w = x.shape
         hw = h * w
@@ -267,6 +268,7 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
         L.call('u2mkd_bn2d_backward_local', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd),
                L.ptr(weight), L.ptr(bias), int(ctx.relu), L.ptr(ws), L.ptr(sums), L.stream())
         local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        note_collective('all_reduce', sums)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
         dx = torch.empty_like(x)

@@ -16,7 +16,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'configure_runtime', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
+__all__ = ['init_from_env', 'configure_runtime', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'collective_counts', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
 
 
 def init_from_env(backend: str | None = None):
@@ -329,6 +329,21 @@ def wrap_model(model: torch.nn.Module, sync_bn: bool = True, bucket_cap_mb: int 
              if isinstance(m, _BatchNorm) and m.training and m.track_running_stats and not _is_sync_bn(m)
              and any(p.requires_grad for p in m.parameters())]
     return BucketedGradientAverage(model, bucket_cap_mb=bucket_cap_mb, broadcast_buffers=bool(plain))
+
+
+def collective_counts(reducer=None, reset=False):
+    """Collectives this process has issued (or, at world size 1 on the forced N > 1 path, would issue) since the last reset:
+    SyncBatchNorm statistics (one all_gather of [2C+1] per synchronising BatchNorm forward, one all_reduce of [2C] per
+    backward -- the reference's count, core/models/utils.py:138-220 -> torch.nn.SyncBatchNorm) and, with ``reducer`` (the
+    BucketedGradientAverage), the gradient buckets of its LAST backward pass."""
+    from .torchsparse.nn import functional as F
+    out = {k: {'count': v[0], 'bytes': v[1]} for k, v in F.COLLECTIVES.items()}
+    if reducer is not None and hasattr(reducer, 'collectives'):
+        out['gradient_buckets_last_pass'] = dict(reducer.collectives)
+    if reset:
+        for v in F.COLLECTIVES.values():
+            v[0] = v[1] = 0
+    return out
 
 
 def max_over_ranks(value: float) -> float:

@@ -92,10 +92,11 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
             if sync is not None:
                 # SyncBatchNorm: every rank's (mean, M2, count) in ONE all_gather of [2C+1] floats, merged in rank order
                 # (Chan) -- the statistics torch.nn.SyncBatchNorm takes over the ranks' up-sampled maps
-                from .torchsparse.nn.functional import _gather_rows
+                from .torchsparse.nn.functional import _gather_rows, note_collective
                 group, world = sync
                 row = torch.cat([mean, var * count, torch.full((1,), float(count), dtype=torch.float64, device=x.device)]).float()
                 rows = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=x.device)
+                note_collective('all_gather', row)
                 if world > 1:
                     _gather_rows(rows, row, group)
                 else:
@@ -137,6 +138,9 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
             # dU = scale * (g - mean(g) - xhat * mean(g * xhat)) over ALL count pixels; g = 0 off the samples.  The two
             # mean terms reach every pixel: c0 + c1 * U, folded through the up-sampling by the dense-gradient kernel.
             sb, sg = dbeta, dgamma
+            if sync is not None:
+                from .torchsparse.nn.functional import note_collective
+                note_collective('all_reduce', torch.empty(0, dtype=dbeta.dtype).new_empty(2 * dbeta.numel()))
             if sync is not None and sync[1] > 1:          # the two sums over every rank's pixels: ONE all_reduce of [2C]
                 from .torchsparse.nn.functional import _sum_over_ranks
                 both = torch.cat([dbeta, dgamma])

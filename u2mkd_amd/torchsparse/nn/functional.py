@@ -1243,6 +1243,18 @@ class BatchNormFunction(Function):
                 None, None, None, None, None, None, None, dres)
 
 
+# SyncBatchNorm exchanges of the current process since the last reset: [calls, bytes sent per rank] per kind.  Counted where a
+# synchronising BatchNorm WOULD exchange (also at world size 1 under U2MKD_FORCE_SYNC_BN, where nothing is sent), so
+# bench.py can state the collectives per step of the N > 1 path before anybody has N > 1 GPUs (distributed.collective_counts).
+COLLECTIVES = {'all_gather': [0, 0], 'all_reduce': [0, 0]}
+
+
+def note_collective(kind, t):
+    c = COLLECTIVES[kind]
+    c[0] += 1
+    c[1] += t.numel() * t.element_size()
+
+
 def _gather_rows(out, row, group):
     """out[r] = rank r's `row` (device tensors).  RCCL: one all_gather on the device.  A gloo group cannot move
     device tensors in an all_gather: the [2C+1] floats travel through host memory (the TRANSPORT only -- this is how
@@ -1294,6 +1306,7 @@ class SyncBatchNormFunction(Function):
         stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
         L.call('u2mkd_bn_local_stats' + sfx, L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
         gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
+        note_collective('all_gather', stats)
         if world > 1:
             _gather_rows(gathered, stats, group)
         else:
@@ -1333,6 +1346,7 @@ class SyncBatchNormFunction(Function):
             L.call('u2mkd_bn_backward_local_res' + sfx, L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd),
                    L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
         local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        note_collective('all_reduce', sums)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
         dx = torch.empty_like(x)

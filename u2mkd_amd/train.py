@@ -14,7 +14,7 @@ from . import kd as KD
 from . import torchsparse as ts
 from .losses import MixLovaszCrossEntropy
 
-__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'TeacherWatch', 'kd_batch_to_device', 'fresh_batch', 'state_dict',
+__all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'TeacherWatch', 'kd_batch_to_device', 'pin_kd_batch', 'fresh_batch', 'state_dict',
            'load_state_dict', 'load_weights']
 
 
@@ -160,7 +160,9 @@ def kd_batch_to_device(b, device='cuda'):
     laid out as NuScenesLCTSDFullTrainer._prepare_input does (images -> [B, ncam, 3, H, W])."""
     s, t = b['student'], b['teacher']
     dev = torch.device(device)
-    f = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+    # (arrays, or the pinned host tensors of pin_kd_batch: then every copy is asynchronous on the current stream, as the
+    # reference's `.cuda(non_blocking=True)` over its pinned loader output, core/nusc_trainers.py:257-279)
+    f = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(dev, non_blocking=True)
     out = {
         's_feats': f(s['feats']), 's_coords': f(s['coords']), 'targets': f(s['targets']),
         'images': f(s['images']).permute(0, 1, 4, 2, 3).contiguous(),
@@ -177,6 +179,20 @@ def kd_batch_to_device(b, device='cuda'):
     if 'keyframe_mask' in t:
         out['keyframe_mask'] = f(t['keyframe_mask'])
     return out
+
+
+def pin_kd_batch(b):
+    """The numpy KD batch as page-locked host tensors (what a DataLoader(pin_memory=True) hands the trainer,
+    train_lc_nusc_tsd_full.py:63-78): ``kd_batch_to_device`` of the result issues asynchronous host-to-device copies."""
+    def pin(v):
+        if isinstance(v, np.ndarray):
+            return torch.from_numpy(v).pin_memory()
+        if isinstance(v, dict):
+            return {k: pin(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)) and v and isinstance(v[0], (np.ndarray, list, tuple)):
+            return type(v)(pin(x) for x in v)
+        return v
+    return pin(b)
 
 
 def fresh_batch(d):
