@@ -24,6 +24,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 typedef short u2_s16x8 __attribute__((ext_vector_type(8)));
 typedef short u2_s16x4 __attribute__((ext_vector_type(4)));
+// one half (H = 0: k slots 0..3 of every lane, H = 1: slots 4..7) of the K = 32 product: a caller with several independent
+// products interleaves their halves so that no two consecutive matrix instructions accumulate into the same registers
+template <int H, class V8>
+__device__ __forceinline__ f32x4 mfma_bf16_k32_half(const V8 &a, const V8 &b, f32x4 c) {
+    static_assert(sizeof(V8) == 16, "mfma_bf16_k32_half: 8 bf16 per lane");
+    const u2_s16x8 a8 = __builtin_bit_cast(u2_s16x8, a), b8 = __builtin_bit_cast(u2_s16x8, b);
+    return H == 0 ? __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a8.lo, b8.lo, c, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a8.hi, b8.hi, c, 0, 0, 0);
+}
+
 template <class V8>
 __device__ __forceinline__ f32x4 mfma_bf16_k32(const V8 &a, const V8 &b, f32x4 c, int = 0, int = 0, int = 0) {
     static_assert(sizeof(V8) == 16, "mfma_bf16_k32: 8 bf16 per lane");

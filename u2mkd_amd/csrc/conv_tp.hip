@@ -504,12 +504,28 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                         const bf16x8 wh = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk][n]), wm = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 1][n]),
                                      wl = as_bf8(bw[SB ? 0 : (u & 1)][3 * sk + 2][n]);
                         const bf16x8 xh = as_bf8(a[3 * sk]), xm = as_bf8(a[3 * sk + 1]), xl = as_bf8(a[3 * sk + 2]);
+#if U2MKD_MFMA_GFX950_K32
                         acc0 = mfma_bf16_k32(wl, xh, acc0, 0, 0, 0);
                         acc1 = mfma_bf16_k32(wh, xl, acc1, 0, 0, 0);
                         acc0 = mfma_bf16_k32(wm, xm, acc0, 0, 0, 0);
                         acc1 = mfma_bf16_k32(wm, xh, acc1, 0, 0, 0);
                         acc0 = mfma_bf16_k32(wh, xm, acc0, 0, 0, 0);
                         acc1 = mfma_bf16_k32(wh, xh, acc1, 0, 0, 0);
+#else
+                        // the gfx942 form: twelve K = 16 instructions, the two accumulation chains alternating
+                        acc0 = mfma_bf16_k32_half<0>(wl, xh, acc0);
+                        acc1 = mfma_bf16_k32_half<0>(wh, xl, acc1);
+                        acc0 = mfma_bf16_k32_half<1>(wl, xh, acc0);
+                        acc1 = mfma_bf16_k32_half<1>(wh, xl, acc1);
+                        acc0 = mfma_bf16_k32_half<0>(wm, xm, acc0);
+                        acc1 = mfma_bf16_k32_half<0>(wm, xh, acc1);
+                        acc0 = mfma_bf16_k32_half<1>(wm, xm, acc0);
+                        acc1 = mfma_bf16_k32_half<1>(wm, xh, acc1);
+                        acc0 = mfma_bf16_k32_half<0>(wh, xm, acc0);
+                        acc1 = mfma_bf16_k32_half<0>(wh, xh, acc1);
+                        acc0 = mfma_bf16_k32_half<1>(wh, xm, acc0);
+                        acc1 = mfma_bf16_k32_half<1>(wh, xh, acc1);
+#endif
                     }
                 } else if (B16) {
 #pragma unroll
