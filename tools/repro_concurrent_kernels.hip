@@ -222,6 +222,40 @@ __global__ void ag_bf16_16x16x32_spaced(float *__restrict__ p, int iters) {
     }
     p[blockIdx.x * blockDim.x + threadIdx.x] = acc[0];
 }
+// the gfx950 form with its accumulator in the ACCUMULATION register file (a[...]) instead of the vector register file
+__global__ void ag_bf16_16x16x32_agpr(float *__restrict__ p, int iters) {
+    f4 acc = {0, 0, 0, 0};
+    s8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = 0x3f80; b[k] = 0x3f80; }
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+    p[blockIdx.x * blockDim.x + threadIdx.x] = acc[0];
+}
+// ... with four independent accumulators in the accumulation file (no dependent chain)
+__global__ void ag_bf16_16x16x32_agpr4(float *__restrict__ p, int iters) {
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    s8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = 0x3f80; b[k] = 0x3f80; }
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %5, %1\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %2, %4, %5, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %4, %5, %3"
+                     : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a), "v"(b));
+    }
+    p[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0];
+}
+// the gfx950 form, four independent accumulators in vector registers (the compiler's default placement)
+__global__ void ag_bf16_16x16x32_vgpr4(float *__restrict__ p, int iters) {
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    s8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = 0x3f80; b[k] = 0x3f80; }
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %5, %1\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %2, %4, %5, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %4, %5, %3"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+    }
+    p[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0];
+}
 __global__ void ag_valu_fma(float *__restrict__ p, int iters) {
     float v = (float)threadIdx.x, a = 0.f;
     for (int it = 0; it < iters; ++it) {
@@ -351,15 +385,17 @@ int main(int argc, char **argv) {
             printf("rate: %-28s %.1f TFLOP/s (dependent chain per wave, 4096 waves)\n", r.name, 1024.0 * 4 * r.iters * r.flop / (ms * 1e-3) / 1e12);
         }
     }
-    const int NA = 16;
+    const int NA = 19;
     const char *aname[NA] = {"nothing", "the same victim kernels", "exp/rcp/sqrt loop", "LDS + barriers", "MFMA 16x16x32 bf16 loop", "streaming copy",
                              "MFMA 16x16x4 f32 loop", "MFMA 32x32x16 bf16 loop", "MFMA 16x16x32 bf16, 64 workgroups only",
                              "64 wg: v_mfma_f32_16x16x32_bf16", "64 wg: v_mfma_f32_16x16x16_bf16 (gfx942 form)", "64 wg: v_mfma_f32_16x16x4_f32",
                              "64 wg: v_mfma_f32_32x32x2_f32", "64 wg: v_mfma_f32_16x16x32_f16", "64 wg: v_mfma_f32_16x16x32_bf16 + 16 idle cycles each",
-                             "64 wg: plain VALU fma loop (no MFMA)"};
+                             "64 wg: plain VALU fma loop (no MFMA)", "64 wg: v_mfma_f32_16x16x32_bf16, accumulator in a[...] (AGPR)",
+                             "64 wg: v_mfma_f32_16x16x32_bf16, 4 independent accumulators in a[...]",
+                             "64 wg: v_mfma_f32_16x16x32_bf16, 4 independent accumulators in v[...]"};
     std::vector<uint32_t> hout, href;
     for (int phase = 0; phase < NA; ++phase) {
-        if (only_aggr >= 0 && phase != only_aggr) continue;
+        if (only_aggr >= 0 && phase < only_aggr) continue;
         unsigned rounds_bad[NV] = {0}, elems_bad[NV] = {0}, inkernel = 0;
         bool sampled[NV] = {false};
         CK(hipMemset(bad, 0, 4));
@@ -381,6 +417,9 @@ int main(int argc, char **argv) {
                 case 13: hipLaunchKernelGGL(ag_f16_16x16x32, dim3(64), dim3(256), 0, sb, scratch, 2048); break;
                 case 14: hipLaunchKernelGGL(ag_bf16_16x16x32_spaced, dim3(64), dim3(256), 0, sb, scratch, 1024); break;
                 case 15: hipLaunchKernelGGL(ag_valu_fma, dim3(64), dim3(256), 0, sb, scratch, 16384); break;
+                case 16: hipLaunchKernelGGL(ag_bf16_16x16x32_agpr, dim3(64), dim3(256), 0, sb, scratch, 2048); break;
+                case 17: hipLaunchKernelGGL(ag_bf16_16x16x32_agpr4, dim3(64), dim3(256), 0, sb, scratch, 512); break;
+                case 18: hipLaunchKernelGGL(ag_bf16_16x16x32_vgpr4, dim3(64), dim3(256), 0, sb, scratch, 512); break;
                 default: break;
                 }
                 if (rep == 0) {

@@ -53,3 +53,15 @@ def install_as_sptr():
     for sub in ('functional',):
         sys.modules['third_party.SparseTransformer.sptr.' + sub] = importlib.import_module('u2mkd_amd.sptr.' + sub)
     return drop_in
+
+
+def install_as_sptr_cuda():
+    """Make ``import sptr_cuda`` (third_party/SparseTransformer/sptr/functional.py:5) resolve to
+    :mod:`u2mkd_amd.sptr.sptr_cuda`: the ten functions of the reference's CUDA extension (src/sptr/pointops_api.cpp:9-20)
+    over the C-ABI entries ``u2mkd_sptr_*`` -- for a maintainer who keeps sptr's own Python layer instead of switching to
+    :func:`install_as_sptr`'s fused attention."""
+    import importlib
+    import sys
+    mod = importlib.import_module('u2mkd_amd.sptr.sptr_cuda')
+    sys.modules['sptr_cuda'] = mod
+    return mod
