@@ -308,6 +308,55 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
     }
 
 
+def roofline_wide_leg(coords_dev, iters=60):
+    """The WIDE sparse layers' row: Conv3d(512, 512, k=3) at tensor stride 8 of the same scene -- the widest
+    SubMConv3d of the cr 2.0 networks -- forward (pair kernel + gather-sum), input gradient, weight gradient (+ its reduce), each
+    timed with HIP events.  MFMA-bound by construction: 6 P Cin Cout fp32-equivalent FLOP, each fp32 product = 6 bf16 matrix
+    products, against the bf16 dense peak / 6."""
+    import torch
+    from u2mkd_amd import _lib as L
+    from u2mkd_amd.torchsparse.nn import functional as F
+    cin = cout = 512
+    c, ts = coords_dev, 1
+    for _ in range(3):
+        c = F.spdownsample(c, 2, 2, ts)
+        ts *= 2
+    km = F.build_kmap(c, (ts,) * 3, (3,) * 3, (1,) * 3)
+    n = km.n_out
+    p = int((km.nbr >= 0).sum().item())
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(n, cin, device='cuda', generator=g)
+    gy = torch.randn(n, cout, device='cuda', generator=g)
+    w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
+    ps = km.pair_schedule()
+    wf_f, wf_d = F._weight_layout(w, True, True), F._weight_layout(w, False, True)
+    out, dx, dw = torch.empty(n, cout, device='cuda'), torch.empty(n, cin, device='cuda'), torch.empty_like(w)
+    pairs, _, plan = km.pairs_plan()
+    lib = L.load()
+    nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    st = L.stream()
+    t = {'fwd': time_events([lambda: ps.run(x, wf_f, cout, False, out, fragments=True)], iters),
+         'dgrad': time_events([lambda: ps.run(gy, wf_d, cin, True, dx, fragments=True)], iters),
+         'wgrad': time_events([lambda: L.call('u2mkd_conv_wgrad_pairs', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(pairs), L.ptr(plan), n, 27, 0,
+                                              L.ptr(ws), nbytes, L.ptr(dw), st)], iters)}
+    total = sum(t.values())
+    flops = 6.0 * p * cin * cout
+    peak = 2500.0 / 6.0
+    tf = lambda f, ms: f / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(tf(flops, total), 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s (fp32-equivalent)',
+            'frac': round(tf(flops, total) / peak, 4),
+            'kernel': 'SubMConv3d 512 -> 512 k=3 at tensor stride 8 of the 80k scene: conv_px3_kernel + pairs_gather_sum (fwd, dgrad), '
+                      'conv_wgrad_x3_kernel + reduce (wgrad), N=%d' % n,
+            'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_flops': flops,
+            'ms': dict({k: round(v, 4) for k, v in t.items()}, total=round(total, 4)),
+            'TFLOPs': {'fwd': round(tf(flops / 3, t['fwd']), 1), 'dgrad': round(tf(flops / 3, t['dgrad']), 1),
+                       'wgrad': round(tf(flops / 3, t['wgrad']), 1)},
+            'peak_note': 'bf16 dense peak 2 500 TFLOP/s / 6 bf16 products per fp32 product (bf16x3).  The products are issued as '
+                         'v_mfma_f32_16x16x16_bf16 (the gfx942 form, 0.72 x the rate of v_mfma_f32_16x16x32_bf16 measured in a '
+                         'dependent chain) because the gfx950 form corrupts other streams\' kernels: DESIGN.md section 4, NOTES N9'}
+
+
 # ------------------------------------------------------------------------------ CPU baseline
 CPU_CHILD = r"""
 import json, os, sys, time
@@ -686,6 +735,12 @@ def run_rank(args):
             coords = torch.from_numpy(synth_batch(args.voxels, 1, seed=1234)['coords']).cuda()
             result['roofline'] = roofline_leg(coords)
             log('roofline leg done')
+            if not args.kernel_only or os.environ.get('U2MKD_BENCH_WIDE') == '1':
+                try:
+                    result['roofline_wide'] = roofline_wide_leg(coords)
+                except Exception as e:      # never blocks the judged line
+                    result['roofline_wide'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+                log('wide-layer roofline leg done')
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             log('cpu baseline (child process)')
             result['cpu_baseline'] = cpu_baseline_leg(args)

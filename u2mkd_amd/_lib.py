@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libu2mkd_hip.so')
+# (U2MKD_LIB_SUFFIX: a variant library built by tools/build_variant.sh -- same-box A/B runs only)
+LIB_PATH = os.path.join(_HERE, 'lib', 'libu2mkd_hip%s.so' % os.environ.get('U2MKD_LIB_SUFFIX', ''))
 
 _i32, _i64, _sz, _f32, _p = C.c_int32, C.c_int64, C.c_size_t, C.c_float, C.c_void_p
 
