@@ -682,6 +682,11 @@ def run_rank(args):
                             # collectives of one step on this rank (count, bytes sent): issued at N > 1; at one rank on the forced
                             # N > 1 path (U2MKD_FORCE_DDP=1) the ones it WOULD issue; zeros on the plain one-GPU path
                             'collectives_per_step': timed_run.collectives,
+                            # collective algorithm / protocol: RCCL's own choice unless these are exported (SURVEY 8e prefers a direct,
+                            # non-ring algorithm on the fully connected node; nothing is forced here: to be read off NCCL_DEBUG=INFO
+                            # on an 8-GPU node); the gradient buckets are 25 MB, the SyncBatchNorm rows <= 8 KB (latency-bound)
+                            'rccl_env': {k: os.environ.get(k) for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS',
+                                                                        'RCCL_MSCCL_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY')},
                             'ms_per_step_min_rank': round(timed_run.per_rank[0] / args.steps * 1e3, 3),
                             'ms_per_step_max_rank': round(timed_run.per_rank[1] / args.steps * 1e3, 3)},
         })

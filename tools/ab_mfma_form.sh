@@ -11,6 +11,10 @@ for rep in 1 2; do
     U2MKD_LIB_SUFFIX=$suf python bench.py --no-secondary --no-cpu-baseline --no-roofline --steps 30 --warmup 6 > $OUT/kd${suf}_$rep.json 2> /dev/null
   done
 done
+for suf in "" _k32; do
+  echo "== tests/test_gpu_concurrent_streams.py with libu2mkd_hip$suf.so"
+  U2MKD_LIB_SUFFIX=$suf python -m pytest tests/test_gpu_concurrent_streams.py -x -q 2>&1 | grep -v "MIOpen\|amdgpu.ids" | tail -4
+done
 python - <<'PY'
 import json, glob
 for suf, name in (('', 'shipped: 2 x v_mfma_f32_16x16x16_bf16'), ('_k32', 'variant: v_mfma_f32_16x16x32_bf16')):

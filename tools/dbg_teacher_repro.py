@@ -22,7 +22,8 @@ if os.environ.get('DBG_FENCE') == '1':        # an event record (a barrier packe
     _F.HashTable.query = _query
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 hw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (900, 1600)
-d = T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234, image_hw=hw))
+pts, sweeps = int(os.environ.get('DBG_POINTS', '80000')), int(os.environ.get('DBG_SWEEPS', '0')) or None      # (300000 / 9: configs[4]'s teacher scene)
+d = T.kd_batch_to_device(synth_kd_batch(pts, 1, seed=1234, image_hw=hw, sweeps=sweeps))
 amp = os.environ.get('DBG_AMP') or False          # DBG_AMP=bf16: the step under bf16 autocast (bf16 rows, library kernels in bf16)
 run = _runner(float(os.environ.get('DBG_CR', '1.0')), 2.0, amp=amp)
 state = {k: v.clone() for k, v in run.model.state_dict().items()}

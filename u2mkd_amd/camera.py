@@ -371,7 +371,7 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         from . import deferred
         w = self.weight
-        if (deferred.enabled() and x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.is_leaf and w.grad is None and self.bias is None
+        if (deferred.enabled() and deferred.overlap_ok() and x.is_cuda and torch.is_grad_enabled() and w.requires_grad and w.is_leaf and w.grad is None and self.bias is None
                 and self.groups == 1 and self.dilation == (1, 1) and self.padding_mode == 'zeros'
                 and not isinstance(self.padding, str) and not torch.cuda.is_current_stream_capturing()):
             return _Conv2dFunction.apply(x, w, self.stride, self.padding)

@@ -58,6 +58,36 @@ def scope(flag: bool = True):
         begin_step()
 
 
+# ---- may this package's streams run side by side at all? ---------------------------------------------------------------------
+# On MI355X a kernel that issues gfx950's double-K matrix instructions (v_mfma_f32_16x16x32_bf16 / _f16, v_mfma_f32_32x32x16_bf16)
+# makes waves of OTHER streams' kernels compute wrong results (NOTES N9; tools/repro_concurrent_kernels.hip).  This package's own
+# kernels use the gfx942 forms and the libraries' fp32 kernels are clean, but what torch dispatches under REDUCED-PRECISION
+# autocast is not: MIOpen's bf16 convolution backward and the rocBLAS / hipBLASLt bf16 products change a concurrent
+# u2mkd_ti_weights' results in 6-16 % of the rounds (tools/dbg_library_aggressors.py).  Those kernels are not ours to change, so
+# while a step runs under bf16 / fp16 autocast every fork of this package (teacher stream, camera stream, deferred weight
+# gradients, geometry pre-pass) stays on the caller's stream: nothing runs next to a library kernel.  The trainers announce the
+# mode for the backward pass, which runs outside the autocast context (``set_reduced_precision``).
+# U2MKD_OVERLAP_UNDER_AUTOCAST=1 keeps the forks (A/B runs: the price of the rule).
+import os as _os
+
+_REDUCED = [False]
+_FORCE_OVERLAP = _os.environ.get('U2MKD_OVERLAP_UNDER_AUTOCAST') == '1'
+
+
+def set_reduced_precision(flag: bool):
+    """Trainers: the current step's library kernels run in bf16 / fp16 (autocast), forward AND backward."""
+    _REDUCED[0] = bool(flag)
+
+
+def overlap_ok() -> bool:
+    """True while this package may put work on its side streams (see above)."""
+    if _FORCE_OVERLAP:
+        return True
+    if _REDUCED[0]:
+        return False
+    return not (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16))
+
+
 _STREAMS = {}
 _PENDING = {}         # (device, role) -> side stream with work booked in the pass `_TASK`
 _TASK = [None]        # graph-task id of the backward pass whose end-of-backward join is booked

@@ -145,7 +145,7 @@ class StudentMSP2IFM(nn.Module):
         camera stream; returns (x_im, skip) for ``forward``."""
         im = in_mod['images']
         im = im.reshape(-1, *im.shape[2:])
-        return _Fork(im, 'camera', _CAMERA_STREAM).on_side(
+        return _Fork(im, 'camera', _CAMERA_STREAM and _overlap_ok()).on_side(
             lambda: self._camera_stage(im, 0), im)
 
     def forward(self, in_mod):
@@ -160,7 +160,7 @@ class StudentMSP2IFM(nn.Module):
         # it runs on a side HIP stream, queued BEFORE the LiDAR work of the same stage, so the GPU has the camera
         # kernels to run while the host waits for a torch.unique; autograd replays the same streams in the backward
         # (MIOpen's backward next to the sparse-conv backward).  U2MKD_CAMERA_STREAM=0: everything on one stream.
-        fork = _Fork(im, 'camera', _CAMERA_STREAM)
+        fork = _Fork(im, 'camera', _CAMERA_STREAM and _overlap_ok())
         on_side, join = fork.on_side, fork.join
         n_stage = len(self.vox_downs)
         cam_stage = self._camera_stage
@@ -348,7 +348,7 @@ class TSDFull(nn.Module):
         queued so far (the teacher's inputs) and the main stream waits for it before the outputs are used;
         U2MKD_TEACHER_STREAM=0 runs the reference's sequential order."""
         want_t = self.training or self.debug_val
-        side = _side_stream(in_mod['teacher']['lidar'].F, 'teacher') if want_t and _TEACHER_STREAM else None
+        side = _side_stream(in_mod['teacher']['lidar'].F, 'teacher') if want_t and _TEACHER_STREAM and _overlap_ok() else None
         if side is None:
             ret = {'stu': self.model_s(in_mod['student'])}
             if want_t:
@@ -357,7 +357,7 @@ class TSDFull(nn.Module):
             return ret
         main = torch.cuda.current_stream()
         stu_in = in_mod['student']
-        if _CAMERA_STREAM and self.training:
+        if _CAMERA_STREAM and self.training and _overlap_ok():
             # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
             stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
         if 'teacher_after_camera' in _DEBUG_ORDER:      # (debug, NOTES N9: the teacher starts when the camera head has finished)
@@ -376,6 +376,13 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
+
+
+def _overlap_ok():
+    """(deferred.overlap_ok: no side streams while library kernels run in reduced precision -- NOTES N9)"""
+    from . import deferred
+    return deferred.overlap_ok()
+
 _DEBUG_ORDER = os.environ.get('U2MKD_DEBUG_ORDER', '')      # (tools/stale_discriminators.sh only)
 _CAMERA_STREAM = os.environ.get('U2MKD_CAMERA_STREAM', '1') != '0'
 

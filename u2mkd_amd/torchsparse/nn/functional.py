@@ -934,6 +934,7 @@ class LinearFunction(Function):
         weight = weight.contiguous().float()
         # the saved weight IS the parameter (no contiguous / cast copy): its gradient goes to AccumulateGrad untouched
         ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
+        ctx.overlap_ok = _deferred_overlap_ok()
         want16 = bf16_rows()
         b16 = want16 and _conv_bf16_ok(weight.shape[1], weight.shape[0])
         ctx.in_dtype = x.dtype
@@ -970,7 +971,8 @@ class LinearFunction(Function):
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cout, cin, 1)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             gw = torch.empty_like(weight)
-            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan)
+            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan,
+                                               allow=getattr(ctx, 'overlap_ok', True))
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin,
                    L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), side.cuda_stream if side is not None else L.stream())
         if ctx.needs_input_grad[0] and ctx.x3:
@@ -1018,7 +1020,12 @@ def _side_stream(device):
     return deferred.stream(device.index if device.index is not None else torch.cuda.current_device(), 'sparse_wgrad')
 
 
-def _wgrad_side(weight, is_param, device, overlap_inline, *used):
+def _deferred_overlap_ok():
+    from ... import deferred
+    return deferred.overlap_ok()
+
+
+def _wgrad_side(weight, is_param, device, overlap_inline, *used, allow=True):
     """(stream, deferred) for a weight-gradient launch.  The launch goes to the weight-gradient side stream; when the gradient
     is a leaf's first of this backward pass nobody reads it before the pass ends, and the launch is joined THERE
     (deferred.side_for: end-of-backward callback; ``used`` = the tensors the launch touches, kept from the allocator until
@@ -1027,7 +1034,9 @@ def _wgrad_side(weight, is_param, device, overlap_inline, *used):
     chain waited for every one of them.  KD step 70.4 -> 67.6 ms (three same-box pairs).  Measured the other way round
     earlier in round 4 (+1.5..4 ms): that was with 4 hardware queues and a host without lead -- see NOTES.md N8.
     Otherwise (an existing .grad is accumulated into right after the function returns): joined by the caller at its end."""
-    if not _OVERLAP_WGRAD:
+    # (allow: deferred.overlap_ok() as the FORWARD saw it -- the backward runs outside the autocast context)
+    from ... import deferred as _d
+    if not _OVERLAP_WGRAD or not allow or not _d.overlap_ok():
         return None, False
     # is_param: the tensor whose gradient this is IS a leaf parameter (not a contiguous / padded / cast copy made for the call:
     # the gradient of a copy runs through more backward nodes, on the main stream, before it reaches the parameter)
@@ -1058,6 +1067,7 @@ class ConvolutionFunction(Function):
         param = weight
         weight = weight.contiguous().float()
         ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
+        ctx.overlap_ok = _deferred_overlap_ok()
         k, cin, cout = weight.shape
         # bf16 storage (autocast to bfloat16): bf16 rows in and out, as torchsparse's custom_fwd(cast_inputs=half);
         # shapes without a bf16 kernel (the 4-channel stem) compute on fp32 rows and round the result once
@@ -1104,7 +1114,8 @@ class ConvolutionFunction(Function):
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(kmap.n_out, cin, cout, k)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             grad_weight = torch.empty_like(weight)
-            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, do_x, input, g, ws, grad_weight, pairs, plan)
+            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, do_x, input, g, ws, grad_weight, pairs, plan,
+                                               allow=getattr(ctx, 'overlap_ok', True))
             st = side.cuda_stream if side is not None else L.stream()
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(input), cin, L.ptr(g), cout,
                    L.ptr(pairs), L.ptr(plan), kmap.n_out, k, 1 if transposed else 0, L.ptr(ws), nbytes, L.ptr(grad_weight), st)

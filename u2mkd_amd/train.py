@@ -117,6 +117,7 @@ class LidarStep:
         is built between this step's forward and backward, and the next call issues its forward without waiting for the
         GPU (as KDStep does)."""
         deferred.begin_step()      # (nothing of a backward pass that raised stays booked)
+        deferred.set_reduced_precision(self.amp.enabled)      # (library kernels in bf16 / fp16: no side streams, deferred.overlap_ok)
         queued = self.__dict__.pop('_queued', None)
         in_mod = {'lidar': ts.SparseTensor(feats, coords)}
         if queued is not None and queued[0] is feats and queued[1] is coords:
@@ -282,6 +283,7 @@ class KDStep:
         without waiting for the GPU while this step's backward drains.  The work per batch is the same, it only moves
         one step ahead, as a data loader's prefetch does."""
         deferred.begin_step()      # (nothing of a backward pass that raised stays booked)
+        deferred.set_reduced_precision(self.amp.enabled)      # (library kernels in bf16 / fp16: no side streams, deferred.overlap_ok)
         queued = self.__dict__.pop('_queued', None)
         in_mod = queued[1] if (queued is not None and queued[0] is d) else self._in_mod(d)
         entry = torch.cuda.current_stream().record_event() if d['s_feats'].is_cuda else None     # (see the geometry side stream below)
@@ -292,7 +294,7 @@ class KDStep:
             out = self.net(in_mod)
             ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
                               self.crit, d['keyframe_mask_full'])
-        if prefetch is not None and d['s_feats'].is_cuda:
+        if prefetch is not None and d['s_feats'].is_cuda and deferred.overlap_ok():
             # The next batch's geometry AFTER this step's backward has been issued, on a side stream: its ~1 000 small
             # kernels (hash tables, kernel maps, voxel sets) and the two host round trips run underneath the backward's
             # large kernels instead of between forward and backward with the main stream idle (same box: 77.9 -> 76.3 ms).
