@@ -274,7 +274,7 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
     # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
     # only quoted when it was taken on the same map (same N and P)
     traffic = None
-    for name in ('r4_traffic.json',):
+    for name in ('r5_traffic.json', 'r4_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 tj = json.load(f)
@@ -728,9 +728,10 @@ def run_rank(args):
                     'point clouds) are inside the timed region (core/nusc_trainers.py:257-279)')
                 log('secondary kd_h2d done')
                 sec['kd_ddp_path_1rank'] = child_leg(
-                    args, ['--steps', str(args.steps), '--warmup', str(max(args.warmup, args.batches + 1))], {'U2MKD_FORCE_DDP': '1'},   # the headline's own K / W: short runs of this step scatter by +-3 ms
-                    'the default KD step on the N>1 code path (bucketed gradient averaging + SyncBatchNorm conversion over a '
-                    'ONE-rank RCCL group, U2MKD_FORCE_DDP=1): its price at N = 1, no communication partner')
+                    args, ['--steps', str(args.steps), '--warmup', str(max(args.warmup, args.batches + 1))], {'U2MKD_FORCE_DDP': '1', 'U2MKD_FORCE_SYNC_BN': '1'},   # the headline's own K / W: short runs of this step scatter by +-3 ms
+                    'the default KD step on the N>1 code path (bucketed gradient averaging + every student BatchNorm on the synchronising '
+                    'kernels: local statistics / merge / apply, with the exchanges of a ONE-rank RCCL group counted in '
+                    'distributed.collectives_per_step; U2MKD_FORCE_DDP=1 U2MKD_FORCE_SYNC_BN=1): its price at N = 1, no communication partner')
                 log('secondary kd_ddp_path_1rank done')
             result['secondary'] = sec
 

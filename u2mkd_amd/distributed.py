@@ -244,7 +244,14 @@ class BucketedGradientAverage(torch.nn.Module):
             self._launch_ready()
 
     def _launch_ready(self):
-        """Launch, in index order, every bucket whose predecessors have all been launched."""
+        """Launch, in index order, every bucket whose predecessors have all been launched.  Not while the step's library
+        kernels run in reduced precision (deferred.overlap_ok, NOTES N9): RCCL's reduction kernels would run next to MIOpen's
+        bf16 backward kernels, which change the results of concurrent kernels -- the buckets then all go at the end of the
+        backward (``_finish``), behind the last of them."""
+        if self._on_gpu:
+            from . import deferred
+            if not deferred.overlap_ok():
+                return
         while self._next < len(self._buckets) and self._buckets[self._next]['ready']:
             self._reduce(self._buckets[self._next])
             self._next += 1
