@@ -167,6 +167,17 @@ int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const v
                              const int32_t *items /*[<= 4 ceil(n_out/64)] or NULL*/,
                              const int32_t *n_items /*[1] device, or NULL*/, int64_t n_out, int32_t k,
                              int32_t kflip, int32_t arith, float *out /*[n_out,cout]*/, u2mkd_stream_t s);
+/* Inference form of the two conv schedules with an eval-mode BatchNorm (+ residual add, + ReLU) FOLDED into the store:
+ * out = relu?(conv * scale[col] + shift[col] (+ res[row][col])), scale = gamma / sqrt(running_var + eps), shift = beta -
+ * running_mean * scale -- spnn.Conv3d -> spnn.BatchNorm (eval) -> spnn.ReLU of core/models/build_blocks.py:25-31,59-71 as ONE
+ * launch (the frozen teacher of the KD step, tsd_full.py:590-596, and every evaluation pass).  fp32 rows only.               */
+int u2mkd_conv_forward_tiles_ep(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                                const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, int32_t arith,
+                                const float *scale /*[cout]*/, const float *shift /*[cout]*/, const float *res /*[n_out,cout] or NULL*/,
+                                int32_t relu, float *out, u2mkd_stream_t s);
+int u2mkd_pairs_gather_sum_ep(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, const float *scale,
+                              const float *shift, const float *res, int32_t relu, float *out, u2mkd_stream_t s);
 /* Tuning / A-B experiments only (tools/ab_*.py), NOT part of the drop-in boundary:
  * u2mkd_conv_forward_sorted with an explicit kernel choice.  variant 0 = the product heuristic,
  * waves*100 + kc = conv_os2, 3000 + rb*100 + kc = conv_os3 (see conv.hip).                   */

@@ -259,3 +259,53 @@ def test_teacher_only_step_masks_the_loss_to_key_frame_voxels(hip):
     # and the loss without the mask is a different number (the mask is not a no-op on this scene)
     full = MixLovaszCrossEntropy(ignore_index=0)(out.detach(), labels)
     assert abs(float(full) - float(want)) > 1e-4
+
+
+def test_eval_batchnorm_folded_into_the_convolution_equals_the_two_pass_form(hip):
+    """Inference (frozen teacher / evaluation): spnn.Conv3d -> eval-mode BatchNorm (-> ReLU | + residual -> ReLU) runs as one
+    convolution whose store applies scale / shift / residual / ReLU (functional.conv_eval_affine, build_blocks.py:25-31,59-71);
+    against the two-pass formulation (U2MKD_FOLD_EVAL_BN=0's path) on both conv schedules, strided and transposed convs."""
+    import torch
+    from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.lidar import blocks
+    from u2mkd_amd.synth import synth_batch
+    b = synth_batch(12000, 2, seed=17)
+    feats, coords = torch.from_numpy(b['feats']).cuda(), torch.from_numpy(b['coords']).cuda()
+    torch.manual_seed(5)
+    model = lidar.SPVCNN_SPFORMER(**lidar.spformer_kwargs(cr=2.0)).cuda().eval()
+    for m in model.modules():          # running statistics away from their initial (0, 1)
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.7, 1.3)
+            m.bias.data.normal_(0, 0.1)
+    calls = []
+    orig = blocks.spf.conv_eval_affine
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        calls.append(out is not None)
+        return out
+    blocks.spf.conv_eval_affine = spy
+    try:
+        with torch.no_grad():
+            folded = model({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+            n_folded = sum(calls)
+            blocks._FOLD_EVAL_BN = False
+            plain = model({'lidar': ts.SparseTensor(feats, coords)})['x_vox']
+    finally:
+        blocks._FOLD_EVAL_BN = True
+        blocks.spf.conv_eval_affine = orig
+    assert n_folded >= 30, (n_folded, len(calls))          # most of the 49 conv + BatchNorm pairs have a folded form
+    err = float((folded - plain).abs().max())
+    print('FOLDED-BN %d of %d pairs folded, max |logit difference| %.2e (range %.1f)' % (n_folded, len(calls), err, float(plain.abs().max())))
+    assert err < 2e-5 * max(1.0, float(plain.abs().max()))
+    # training mode / gradients enabled: never folded
+    calls.clear()
+    blocks.spf.conv_eval_affine = spy
+    try:
+        model.train()
+        model({'lidar': ts.SparseTensor(feats, coords)})
+    finally:
+        blocks.spf.conv_eval_affine = orig
+    assert not calls

@@ -44,6 +44,8 @@ SIGNATURES = {
     'u2mkd_weight_fragments': (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'u2mkd_weight_fragments_batch': (C.c_int, [_p, _i32, _i64, _p]),
     'u2mkd_conv_forward_tiles': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_conv_forward_tiles_ep': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_pairs_gather_sum_ep': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_debug_conv_tile_pairs_stamps': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_debug_wgrad_stamps': (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     'u2mkd_conv_forward_pairs': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),

@@ -871,7 +871,8 @@ static int launch_conv_pairs(int nb, dim3 grid, hipStream_t st, const float *in,
 // thread, a row's K slots are read first (contiguous), then all of its y rows are in flight.
 __global__ void __launch_bounds__(256)
 pairs_gather_sum_kernel(const float *__restrict__ y, const int32_t *__restrict__ pos, int64_t n_rows, int K, int c4,
-                        float *__restrict__ out) {
+                        float *__restrict__ out, const float *__restrict__ ep_scale = nullptr,
+                        const float *__restrict__ ep_shift = nullptr, const float *__restrict__ ep_res = nullptr, int ep_relu = 0) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_rows * c4) return;
     int64_t r = t / c4;
@@ -888,6 +889,15 @@ pairs_gather_sum_kernel(const float *__restrict__ y, const int32_t *__restrict__
             v[i] = p[i] >= 0 ? reinterpret_cast<const float4 *>(y)[(int64_t)p[i] * c4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    if (ep_scale) {      // folded eval-mode BatchNorm (+ residual, + ReLU), u2mkd_pairs_gather_sum_ep
+        const float4 sc = reinterpret_cast<const float4 *>(ep_scale)[c], sh = reinterpret_cast<const float4 *>(ep_shift)[c];
+        acc.x = fmaf(acc.x, sc.x, sh.x); acc.y = fmaf(acc.y, sc.y, sh.y); acc.z = fmaf(acc.z, sc.z, sh.z); acc.w = fmaf(acc.w, sc.w, sh.w);
+        if (ep_res) {
+            const float4 rs = reinterpret_cast<const float4 *>(ep_res)[r * c4 + c];
+            acc.x += rs.x; acc.y += rs.y; acc.z += rs.z; acc.w += rs.w;
+        }
+        if (ep_relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
     }
     reinterpret_cast<float4 *>(out)[r * c4 + c] = acc;
 }
@@ -1107,6 +1117,25 @@ int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const v
     return rc;
 }
 
+int u2mkd_conv_forward_tiles_ep(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                const int32_t *nbr_sorted, const int32_t *order, const int32_t *items,
+                                const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, int32_t arith,
+                                const float *scale, const float *shift, const float *res, int32_t relu, float *out,
+                                u2mkd_stream_t s) {
+    if (n_out <= 0) return 0;
+    U2_REQUIRE(in && wf && nbr_sorted && out && scale && shift, "u2mkd_conv_forward_tiles_ep: null pointer");
+    U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles_ep: kflip must be 0 or 1");
+    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_conv_forward_tiles_ep: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
+    U2_REQUIRE(n_in > 0 && n_in <= (1 << 25), "u2mkd_conv_forward_tiles_ep: %lld input rows out of range", (long long)n_in);
+    U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles_ep: items and n_items go together");
+    RowRange rr{n_out, 0, n_out, nullptr};
+    rr.ep_scale = scale; rr.ep_shift = shift; rr.ep_res = res; rr.ep_relu = (int)relu;
+    int rc = launch_conv_tp("u2mkd_conv_forward_tiles_ep", in, cin, reinterpret_cast<const float *>(wf), cout, nbr_sorted, order,
+                            rr, items, n_items, k, kflip, arith, out, as_stream(s));
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_tiles_ep: no instantiation for %d -> %d channels, kernel volume %d", cin, cout, k);
+    return rc;
+}
+
 int u2mkd_debug_conv_tile_pairs_stamps(const float *in, int64_t n_in, const void *wf, const int32_t *nbr_sorted,
                                        const int32_t *order, const int32_t *items, const int32_t *n_items, int64_t n_out,
                                        int32_t k, int32_t arith, float *out, uint64_t *stamps, u2mkd_stream_t s) {
@@ -1199,8 +1228,20 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, i
     const int c4 = cout / 4;
     const int64_t total = n_rows * c4;
     hipLaunchKernelGGL(pairs_gather_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), y, pos,
-                       n_rows, k, c4, out);
+                       n_rows, k, c4, out, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0);
     return check_launch("u2mkd_pairs_gather_sum");
+}
+
+int u2mkd_pairs_gather_sum_ep(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, const float *scale,
+                              const float *shift, const float *res, int32_t relu, float *out, u2mkd_stream_t s) {
+    if (n_rows == 0) return 0;
+    U2_REQUIRE(y && pos && out && scale && shift, "u2mkd_pairs_gather_sum_ep: null pointer");
+    U2_REQUIRE(cout > 0 && cout % 4 == 0 && k > 0, "u2mkd_pairs_gather_sum_ep: cout=%d must be a positive multiple of 4", cout);
+    const int c4 = cout / 4;
+    const int64_t total = n_rows * c4;
+    hipLaunchKernelGGL(pairs_gather_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), y, pos,
+                       n_rows, k, c4, out, scale, shift, res, (int)relu);
+    return check_launch("u2mkd_pairs_gather_sum_ep");
 }
 
 int u2mkd_conv_forward_pairs_bf16(const void *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,

@@ -52,6 +52,10 @@ __device__ __forceinline__ f32x4 mfma_bf16_k32(const V8 &a, const V8 &b, f32x4 c
 struct RowRange {
     int64_t ld, begin, end;
     const int32_t *tile_order;   // launch order of the 64-row tiles (heaviest first) or nullptr (offset-walking kernels)
+    // optional per-column epilogue of the tile-pair kernel (inference: an eval-mode BatchNorm (+ residual, + ReLU) folded into
+    // the convolution's store, u2mkd_conv_forward_tiles_ep): out = relu?(acc * ep_scale[col] + ep_shift[col] (+ ep_res[row][col]))
+    const float *ep_scale = nullptr, *ep_shift = nullptr, *ep_res = nullptr;
+    int ep_relu = 0;
 };
 
 // Tile-local pair schedule (conv_tp.hip); wf = weight fragments of launch_weight_fragments (same `arith`).

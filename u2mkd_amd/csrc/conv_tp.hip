@@ -593,7 +593,16 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         const int rid = s_rid[row];
         const int col = col0 + 4 * c4;
         if (rid >= 0 && col < cout) {
-            const float4 v = *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
+            float4 v = *reinterpret_cast<const float4 *>(s_out + row * OS + 4 * c4);
+            if (!B16 && rr_.ep_scale) {      // folded eval-mode BatchNorm (+ residual, + ReLU): fp32 rows only
+                const float4 sc = *reinterpret_cast<const float4 *>(rr_.ep_scale + col), sh = *reinterpret_cast<const float4 *>(rr_.ep_shift + col);
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                if (rr_.ep_res) {
+                    const float4 r = *reinterpret_cast<const float4 *>(rr_.ep_res + (size_t)rid * cout + col);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (rr_.ep_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
             if (B16) {
                 bf16x4 b;
                 b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;

@@ -31,6 +31,12 @@ class PointBatchNorm1d(nn.BatchNorm1d):
         return spf.batch_norm(input, self)
 
 
+# U2MKD_FOLD_EVAL_BN=0: inference runs spnn.Conv3d and its eval-mode BatchNorm as two passes (the formulation the folded one is
+# tested against)
+import os as _os
+_FOLD_EVAL_BN = _os.environ.get('U2MKD_FOLD_EVAL_BN', '1') != '0'
+_FOLDABLE_BN = ('BatchNorm', 'SparseSyncBatchNorm')      # (eval mode: a SyncBatchNorm uses its running statistics too)
+
 # BatchNorm flavours whose forward is spf.batch_norm (plain and the SyncBatchNorm conversions of point_voxel.py)
 _FUSABLE_BN = ('BatchNorm', 'PointBatchNorm1d', 'SparseSyncBatchNorm', 'PointSyncBatchNorm1d')
 
@@ -45,9 +51,23 @@ class FusedSequential(nn.Sequential):
         result is relu(sequence(x) + residual) with the add and the ReLU inside that BatchNorm's pass."""
         mods = list(self)
         i = 0
+        # inference: spnn.Conv3d -> eval-mode BatchNorm (-> ReLU | + residual -> ReLU) as ONE convolution whose store applies the
+        # folded affine (functional.conv_eval_affine): the frozen teacher's ~49 BatchNorm passes disappear
+        fold = _FOLD_EVAL_BN and isinstance(x, SparseTensor) and not torch.is_grad_enabled()
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if fold and isinstance(m, spnn.Conv3d) and type(nxt).__name__ in _FOLDABLE_BN and not nxt.training \
+                    and nxt.track_running_stats and nxt.running_mean is not None:
+                after = mods[i + 2] if i + 2 < len(mods) else None
+                last_bn = residual is not None and i + 1 == len(mods) - 1
+                relu = last_bn or type(after) in (spnn.ReLU, nn.ReLU)
+                scale, shift = spf.eval_bn_affine(nxt)
+                y = spf.conv_eval_affine(x, m, scale, shift, relu, residual if last_bn else None)
+                if y is not None:
+                    x = y
+                    i += 2 if last_bn or not relu else 3
+                    continue
             fusable = (type(m).__name__ in _FUSABLE_BN and type(nxt) in (spnn.ReLU, nn.ReLU))
             if residual is not None and i == len(mods) - 1:
                 assert type(m).__name__ in _FUSABLE_BN, type(m).__name__

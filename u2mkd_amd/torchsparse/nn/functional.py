@@ -495,10 +495,19 @@ class TileSchedule:
     def tiles(self):
         return self.nbr_s, self.order
 
-    def run(self, feats, weight, transpose, cout, kflip, out):
+    def run(self, feats, weight, transpose, cout, kflip, out, epilogue=None):
         """out[j] = sum_k feats[tbl[k][j]] @ B_k with B_k[col][ci] = weight[kk][ci][col] (transpose, the forward) or
-        weight[kk][col][ci] (the input gradient), kk = K-1-k if kflip else k; weight = `kernel` [K, cin, cout]."""
+        weight[kk][col][ci] (the input gradient), kk = K-1-k if kflip else k; weight = `kernel` [K, cin, cout].
+        ``epilogue`` = (scale [cout], shift [cout], residual [n, cout] or None, relu): a folded eval-mode BatchNorm
+        (conv_eval_affine); only where ``supports_epilogue`` says so."""
         n_in, cin = feats.shape
+        if epilogue is not None:
+            sc, sh, res, relu = epilogue
+            wf = _weight_layout(weight, transpose, True)
+            L.call('u2mkd_conv_forward_tiles_ep', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), 0, L.ptr(sc), L.ptr(sh),
+                   L.ptr(res), int(relu), L.ptr(out), L.stream())
+            return out
         if feats.dtype == torch.bfloat16:        # bf16 storage: rows in and out bf16, one bf16 weight plane
             wf = _weight_layout(weight, transpose, True, arith=3)
             L.call('u2mkd_conv_forward_tiles_bf16', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
@@ -550,7 +559,7 @@ class PairSchedule:
                    L.ptr(self.tile_k), L.ptr(self.meta), st)
         self.nbsizes = nbsizes
 
-    def run(self, feats, wt, cout, swap, out, variant=0, fragments=False):
+    def run(self, feats, wt, cout, swap, out, variant=0, fragments=False, epilogue=None):
         """swap = False: out[j] = sum_k feats[in_k(j)] @ B_k  (rows of out = the map's outputs)
         swap = True:  out[i] = sum_k feats[out_k(i)] @ B_k (rows of out = the map's inputs);
         B_k = wt[k] as [cout][cin], or (fragments) the arith-2 fragment layout of it for the bf16x3 kernel."""
@@ -571,6 +580,11 @@ class PairSchedule:
         else:
             L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
                    L.ptr(self.meta), self.cap, self.k, variant, L.ptr(y), st)
+        if epilogue is not None:      # folded eval-mode BatchNorm (+ residual, + ReLU) at the gather-sum's store
+            sc, sh, res, relu = epilogue
+            L.call('u2mkd_pairs_gather_sum_ep', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(sc), L.ptr(sh), L.ptr(res), int(relu),
+                   L.ptr(out), st)
+            return out
         L.call('u2mkd_pairs_gather_sum', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
         return out
 
@@ -720,7 +734,7 @@ def prefetch_kmaps(x: SparseTensor, specs, level_coords=None) -> None:
 
 
 # --------------------------------------------------------------------- conv
-def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
+def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip, epilogue=None):
     """out[j] = sum_k feats[tbl[k][j]] @ B_k, tbl = the kernel map's (inverse) neighbour table, B_k taken from
     `weight` = kernel [K, cin, cout]: B_k[col][ci] = weight[kk][ci][col] (transpose = True: the forward) or
     weight[kk][col][ci] (False: the input gradient), kk = K-1-k if kflip else k.  kflip = 1 is the input
@@ -734,12 +748,83 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip):
     if feats.dtype != torch.bfloat16 and _pairs_mode(feats.shape[1], cout, n_rows):
         x3 = _PAIRS_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(feats.shape[1], cout))
         wt = _weight_layout(weight, transpose, x3)
-        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3)
+        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3, epilogue=epilogue)
     if inverse and kmap.nbr_inv is None:      # symmetric map: the inverse table is the mirrored forward table
         inverse, kflip = False, 1 - int(kflip)
     sch = kmap.schedule(inverse)
     assert sch.n == n_rows
-    return sch.run(feats, weight, transpose, cout, kflip, out)
+    return sch.run(feats, weight, transpose, cout, kflip, out, epilogue=epilogue)
+
+
+def conv_epilogue_supported(feats, cin, cout, k, n_rows):
+    """True where conv_eval_affine can fold the affine into the convolution's store: fp32 rows on the tile-pair kernel
+    (u2mkd_conv_forward_tiles_ep) or on the pair schedule (u2mkd_pairs_gather_sum_ep)."""
+    if feats.dtype != torch.float32 or bf16_rows() or cin % 4 or cout % 4:
+        return False
+    if _pairs_mode(cin, cout, n_rows):
+        return True
+    return bool(L.load().u2mkd_conv_tiles_supported(cin, cout, k)) and conv_arith_is_default()
+
+
+def conv_arith_is_default():
+    return os.environ.get('U2MKD_CONV_SCHEDULE') in (None, 'tiles', 'pairs')
+
+
+def conv_eval_affine(input: SparseTensor, conv, scale, shift, relu, residual=None):
+    """INFERENCE: ``relu?(conv(input) * scale + shift (+ residual))`` with the affine, the add and the ReLU inside the
+    convolution's last pass -- spnn.Conv3d followed by an eval-mode spnn.BatchNorm (scale = gamma / sqrt(running_var + eps),
+    shift = beta - running_mean * scale; core/models/build_blocks.py:25-31,59-71) as one launch sequence instead of two: the
+    frozen teacher of the KD step and every evaluation pass.  Returns None where the shape has no folded form (the caller
+    then runs the two modules).  No autograd."""
+    kernel_size, stride, dilation = make_ntuple(conv.kernel_size, ndim=3), make_ntuple(conv.stride, ndim=3), make_ntuple(conv.dilation, ndim=3)
+    weight = conv.kernel
+    if conv.bias is not None or weight.dim() != 3 or kernel_size == (1, 1, 1):
+        return None
+    feats = input.feats
+    k, cin, cout = weight.shape
+    if not conv.transposed:
+        key = (input.stride, kernel_size, stride, dilation)
+        kmap = input.kmaps.get(key)
+        if kmap is None:
+            kmap = build_kmap(input.coords, input.stride, kernel_size, stride)
+            input.kmaps[key] = kmap
+        inverse, n_rows = False, kmap.n_out
+        out_coords, out_stride = kmap.out_coords, tuple(input.stride[i] * stride[i] for i in range(3))
+    else:
+        out_stride = tuple(input.stride[i] // stride[i] for i in range(3))
+        kmap = input.kmaps[(out_stride, kernel_size, stride, dilation)]
+        inverse, n_rows = True, kmap.n_in
+        out_coords = input.cmaps[out_stride]
+    if not conv_epilogue_supported(feats, cin, cout, k, n_rows) or feats.shape[1] != cin:
+        return None
+    res = None
+    if residual is not None:
+        res = (residual.F if isinstance(residual, SparseTensor) else residual).contiguous().float()
+    with torch.no_grad():
+        out = _conv_os(feats.contiguous(), weight.contiguous().float(), True, cout, kmap, inverse, n_rows, 0,
+                       epilogue=(scale, shift, res, bool(relu)))
+    output = SparseTensor(coords=out_coords, feats=out, stride=out_stride)
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(output.stride, output.coords)
+    output.kmaps = input.kmaps
+    return output
+
+
+def eval_bn_affine(bn):
+    """(scale, shift) of an eval-mode BatchNorm as fp32 device vectors, cached on the module until a parameter, a running
+    statistic or eps changes (versions of the five tensors)."""
+    key = (bn.running_mean._version, bn.running_var._version, None if bn.weight is None else bn.weight._version,
+           None if bn.bias is None else bn.bias._version, bn.eps, bn.running_mean.data_ptr())
+    hit = bn.__dict__.get('_u2mkd_affine')
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+        scale = inv * bn.weight.float() if bn.weight is not None else inv
+        shift = (bn.bias.float() if bn.bias is not None else 0.0) - bn.running_mean.float() * scale
+        scale, shift = scale.contiguous(), shift.contiguous()
+    bn.__dict__['_u2mkd_affine'] = (key, scale, shift)
+    return scale, shift
 
 
 _WEIGHT_EPOCH = [0]
