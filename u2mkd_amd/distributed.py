@@ -25,7 +25,7 @@ def init_from_env(backend: str | None = None):
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     rnk = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    configure_runtime()
+    configure_runtime(warn=False)      # (a launcher calls it itself before its first GPU call; here it may already be too late)
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         # (more local ranks than devices: only a gloo group can share a card -- tests on a one-GPU box; RCCL refuses)
@@ -43,7 +43,7 @@ def init_from_env(backend: str | None = None):
     return rnk, world_size, local
 
 
-def configure_runtime():
+def configure_runtime(warn=True):
     """Process-level HIP settings; must run before the process's first HIP call (the launchers -- bench.py,
     run_training.py -- call it on their first line; nothing is changed at ``import u2mkd_amd``): the runtime reads the
     variable at its initialisation only, so a late call warns and changes nothing.
@@ -59,6 +59,8 @@ def configure_runtime():
     if 'GPU_MAX_HW_QUEUES' in os.environ:       # the user's choice wins
         return
     if torch.cuda.is_initialized():
+        if not warn:
+            return
         import warnings
         warnings.warn('u2mkd_amd.distributed.configure_runtime() was called after the HIP runtime had been initialised: '
                       'GPU_MAX_HW_QUEUES keeps the runtime\'s default (4) and the step\'s fifth stream shares a hardware queue '
