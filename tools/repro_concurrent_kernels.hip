@@ -256,6 +256,16 @@ __global__ void ag_bf16_16x16x32_vgpr4(float *__restrict__ p, int iters) {
     }
     p[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0];
 }
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__global__ void ag_f16_16x16x16(float *__restrict__ p, int iters) {
+    f4 acc = {0, 0, 0, 0};
+    h4 a, b;
+    for (int k = 0; k < 4; ++k) { a[k] = (_Float16)1.0f; b[k] = (_Float16)1.0f; }
+    for (int it = 0; it < iters; ++it) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+    }
+    p[blockIdx.x * blockDim.x + threadIdx.x] = acc[0];
+}
 __global__ void ag_valu_fma(float *__restrict__ p, int iters) {
     float v = (float)threadIdx.x, a = 0.f;
     for (int it = 0; it < iters; ++it) {
@@ -373,7 +383,8 @@ int main(int argc, char **argv) {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         struct { const char *name; void (*k)(float *, int); double flop; int iters; } rates[] = {
             {"v_mfma_f32_16x16x32_bf16", ag_bf16_16x16x32, 2.0 * 16 * 16 * 32, 4096}, {"v_mfma_f32_16x16x16_bf16", ag_bf16_16x16x16_1k, 2.0 * 16 * 16 * 16, 8192},
-            {"v_mfma_f32_16x16x4_f32", ag_f32_16x16x4, 2.0 * 16 * 16 * 4, 4096}, {"v_mfma_f32_16x16x32_f16", ag_f16_16x16x32, 2.0 * 16 * 16 * 32, 4096}};
+            {"v_mfma_f32_16x16x4_f32", ag_f32_16x16x4, 2.0 * 16 * 16 * 4, 4096}, {"v_mfma_f32_16x16x32_f16", ag_f16_16x16x32, 2.0 * 16 * 16 * 32, 4096},
+            {"v_mfma_f32_16x16x16_f16", ag_f16_16x16x16, 2.0 * 16 * 16 * 16, 8192}};
         for (auto &r : rates) {
             hipLaunchKernelGGL(r.k, dim3(1024), dim3(256), 0, sa, scratch, r.iters);
             CK(hipEventRecord(e0, sa));
@@ -385,14 +396,15 @@ int main(int argc, char **argv) {
             printf("rate: %-28s %.1f TFLOP/s (dependent chain per wave, 4096 waves)\n", r.name, 1024.0 * 4 * r.iters * r.flop / (ms * 1e-3) / 1e12);
         }
     }
-    const int NA = 19;
+    const int NA = 20;
     const char *aname[NA] = {"nothing", "the same victim kernels", "exp/rcp/sqrt loop", "LDS + barriers", "MFMA 16x16x32 bf16 loop", "streaming copy",
                              "MFMA 16x16x4 f32 loop", "MFMA 32x32x16 bf16 loop", "MFMA 16x16x32 bf16, 64 workgroups only",
                              "64 wg: v_mfma_f32_16x16x32_bf16", "64 wg: v_mfma_f32_16x16x16_bf16 (gfx942 form)", "64 wg: v_mfma_f32_16x16x4_f32",
                              "64 wg: v_mfma_f32_32x32x2_f32", "64 wg: v_mfma_f32_16x16x32_f16", "64 wg: v_mfma_f32_16x16x32_bf16 + 16 idle cycles each",
                              "64 wg: plain VALU fma loop (no MFMA)", "64 wg: v_mfma_f32_16x16x32_bf16, accumulator in a[...] (AGPR)",
                              "64 wg: v_mfma_f32_16x16x32_bf16, 4 independent accumulators in a[...]",
-                             "64 wg: v_mfma_f32_16x16x32_bf16, 4 independent accumulators in v[...]"};
+                             "64 wg: v_mfma_f32_16x16x32_bf16, 4 independent accumulators in v[...]",
+                             "64 wg: v_mfma_f32_16x16x16_f16 (gfx942 form)"};
     std::vector<uint32_t> hout, href;
     for (int phase = 0; phase < NA; ++phase) {
         if (only_aggr >= 0 && phase < only_aggr) continue;
@@ -420,6 +432,7 @@ int main(int argc, char **argv) {
                 case 16: hipLaunchKernelGGL(ag_bf16_16x16x32_agpr, dim3(64), dim3(256), 0, sb, scratch, 2048); break;
                 case 17: hipLaunchKernelGGL(ag_bf16_16x16x32_agpr4, dim3(64), dim3(256), 0, sb, scratch, 512); break;
                 case 18: hipLaunchKernelGGL(ag_bf16_16x16x32_vgpr4, dim3(64), dim3(256), 0, sb, scratch, 512); break;
+                case 19: hipLaunchKernelGGL(ag_f16_16x16x16, dim3(64), dim3(256), 0, sb, scratch, 4096); break;
                 default: break;
                 }
                 if (rep == 0) {

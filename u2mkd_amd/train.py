@@ -330,6 +330,7 @@ class KDStep:
         reference, tensors stay on the device."""
         from .evaluate import voxel_logits_to_point_predictions as v2p
         assert not self.model.training, 'evaluate() is the eval branch: call model.eval() first (core/nusc_trainers.py:420-421)'
+        deferred.set_reduced_precision(self.amp.enabled)
         with self.amp.autocast():
             out = self.net(self._in_mod(d))
         vb = d['s_coords'][:, -1]
