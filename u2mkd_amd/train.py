@@ -326,11 +326,11 @@ class KDStep:
             # The next batch's geometry AFTER this step's backward has been issued, on a side stream: its ~1 000 small
             # kernels (hash tables, kernel maps, voxel sets) and the two host round trips run underneath the backward's
             # large kernels instead of between forward and backward with the main stream idle (same box: 77.9 -> 76.3 ms).
-            # Memory: the side stream's allocations are consumed on the other streams one step later and freed there,
-            # without record_stream -- safe because (a) the next forward waits for `_geo_done`, (b) a batch's geometry is
-            # kept alive for one more step (`_geo_keep`), and (c) the side stream starts a preparation only behind `entry`,
-            # the main stream's position when THIS call began: the next batch's tensors exist by then, the previous step
-            # is complete, and whatever the allocator hands the side stream again was last touched before that point.
+            # Memory: the side stream's allocations are consumed on the other streams one step later and freed there.
+            # Ordering: (a) the next forward waits for `_geo_done`, (b) a batch's geometry is kept alive for one more step
+            # (`_geo_keep`), (c) the side stream starts a preparation only behind `entry`, the main stream's position when
+            # THIS call began; and (round 5) every tensor of the prepared geometry is registered with its reader streams
+            # (record_stream, below), so the allocator itself holds a freed block until they have passed.
             self.amp.backward_and_step(ld['total'], self.opt)
             self.sched.step()
             geo = KD._side_stream(d['s_feats'], 'geo')
