@@ -195,12 +195,16 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
     pairs, _, plan = km.pairs_plan()
     nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
     st = L.stream()
+    # the arithmetic the product runs this layer's forward / input gradient in (torchsparse/nn/functional.py TileSchedule.run):
+    # 4 = f16x2 unless U2MKD_CONV_ARITH says otherwise
+    ar = int(lib.u2mkd_conv_tiles_arith(cin, cout, 27))
+    ar = ar if ar == 4 else 0
 
     def make_set():
         x = torch.randn(n, cin, device='cuda', generator=g)
         w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
         gy = torch.randn(n, cout, device='cuda', generator=g)
-        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty(2, lib.u2mkd_weight_fragments_bytes(27, cin, cout, 0), dtype=torch.uint8, device='cuda'), 'out': torch.empty(n, cout, device='cuda'),
+        s = {'x': x, 'w': w, 'gy': gy, 'wf': torch.empty(2, lib.u2mkd_weight_fragments_bytes(27, cin, cout, ar), dtype=torch.uint8, device='cuda'), 'out': torch.empty(n, cout, device='cuda'),
              'dx': torch.empty(n, cin, device='cuda'), 'dw': torch.empty_like(w),
              'ws': torch.empty(nbytes, dtype=torch.uint8, device='cuda'),
              # private copies of the map structures, so a cold launch also misses on the indices
@@ -209,11 +213,11 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
         # the weight's MFMA-fragment images (both orientations) exist before the step's convolutions run: the product re-lays
         # ALL trainable weights in one launch behind the optimizer step (functional.refresh_weight_fragments); that
         # launch is timed below (`fragments`) and this weight's share of it is added to the group
-        L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, 2, 0, L.ptr(s['wf']), st)
+        L.call('u2mkd_weight_fragments', L.ptr(s['w']), 27, cin, cout, 2, ar, L.ptr(s['wf']), st)
 
         def conv(s, a, frag, flip, o):
             L.call('u2mkd_conv_forward_tiles', L.ptr(a), n, cin, L.ptr(s['wf'][frag]), cout, L.ptr(s['nbr_s']), L.ptr(s['order']),
-                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, 0, L.ptr(o), st)
+                   L.ptr(sch.items), L.ptr(sch.n_items), n, 27, flip, ar, L.ptr(o), st)
         s['fwd'] = lambda s=s: conv(s, s['x'], 0, 0, s['out'])
         s['dgrad'] = lambda s=s: conv(s, s['gy'], 1, 1, s['dx'])
         s['wgrad'] = lambda s=s: L.call('u2mkd_conv_wgrad_pairs', L.ptr(s['x']), cin, L.ptr(s['gy']), cout, L.ptr(s['pairs']),
@@ -268,7 +272,7 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
     b_f, b_d, b_w = subm_algorithmic_bytes(n, p, cin, cout)
     total_b = b_f + b_d + b_w
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
-    frag = fragments_share()
+    frag = fragments_share(arith=ar)
     t_warm, t_cold = sum(warm.values()) + frag['share_ms'], sum(cold.values()) + frag['share_ms']
     flops = 6.0 * p * cin * cout
     # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
@@ -284,26 +288,32 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
         except Exception:
             pass
     r3 = lambda d: {k: round(v, 4) for k, v in d.items()}
+    # `achieved` / `frac` = the COLD figure (operand sets rotating through more than the 256 MiB Infinity Cache: what a
+    # training step sees, and what the HBM roofline is about); the warm one (one operand set re-launched) is the sub-field
+    products = 3 if ar == 4 else 6
+    issued = ((2 * products + 6) / 3.0)          # forward + input gradient in `products` partial products each, the weight gradient in bf16x3's six
     return {
-        'bound': 'hbm', 'achieved': round(gbs(total_b, t_warm), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4), 'traffic': traffic,
+        'bound': 'hbm', 'achieved': round(gbs(total_b, t_cold), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(gbs(total_b, t_cold) / HBM_PEAK_GBS, 4), 'traffic': traffic,
         'kernel': 'SubMConv3d fwd+dgrad+wgrad (conv_tp_kernel x2 + conv_wgrad_x3_kernel incl. its slab reduce + this weight\'s share of the per-step weight_fragments_batch launch), N=%d Cin=Cout=64 K=27' % n,
+        'arithmetic': ('forward / input gradient: f16x2 (two fp16 planes per fp32 operand, 3 partial products on v_mfma_f32_16x16x16_f16, '
+                       'per-row and per-tensor power-of-two scales); ' if ar == 4 else 'forward / input gradient: bf16x3; ') +
+                      'weight gradient: bf16x3 (three bf16 planes, 6 partial products on v_mfma_f32_16x16x16_bf16); fp32 accumulate',
         'N': n, 'P': p, 'kbar': round(p / n, 3), 'algorithmic_bytes': total_b,
-        'timing': 'HIP events on the launch stream over %d launches per kernel, behind ~25 ms of the same launches without a synchronisation (the GPU reaches its working clocks only after 10-20 ms of load: DESIGN.md section 5)' % iters,
-        'ms': dict(r3(warm), fragments_share=frag['share_ms'], total=round(t_warm, 4)),
+        'timing': 'HIP events on the launch stream over %d launches per kernel, behind ~25 ms of the same launches without a synchronisation (the GPU reaches its working clocks only after 10-20 ms of load: DESIGN.md section 5); cold: %d operand sets of %.0f MB launched round-robin (%.0f MB > 256 MiB Infinity Cache)' % (iters, cold_sets, set_bytes / 1e6, cold_sets * set_bytes / 1e6),
+        'ms': dict(r3(cold), fragments_share=frag['share_ms'], total=round(t_cold, 4)),
         'fragments': frag,
-        'GBps': {'fwd': round(gbs(b_f, warm['fwd']), 1), 'dgrad': round(gbs(b_d, warm['dgrad']), 1),
-                 'wgrad': round(gbs(b_w, warm['wgrad']), 1)},
-        'cold': {'ms': dict(r3(cold), total=round(t_cold, 4)), 'achieved': round(gbs(total_b, t_cold), 1),
-                 'frac': round(gbs(total_b, t_cold) / HBM_PEAK_GBS, 4),
-                 'note': '%d operand sets of %.0f MB launched round-robin (%.0f MB > 256 MiB Infinity Cache)'
-                         % (cold_sets, set_bytes / 1e6, cold_sets * set_bytes / 1e6)},
-        # the kernels multiply in bf16x3: every fp32 product = 6 bf16 MFMA products (3-way split, the 6 partial
-        # products above 2^-24), so the matrix pipe executes 6 x the algorithmic MACs against the bf16 dense peak
-        'mfma': {'algorithmic_tflops': round(flops / (t_warm * 1e-3) / 1e12, 2),
-                 'issued_bf16_tflops': round(6 * flops / (t_warm * 1e-3) / 1e12, 2), 'bf16_dense_peak_tflops': 2500.0,
-                 'utilisation': round(6 * flops / (t_warm * 1e-3) / 1e12 / 2500.0, 4),
-                 'note': 'bf16x3 emulation of fp32 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate'},
+        'GBps': {'fwd': round(gbs(b_f, cold['fwd']), 1), 'dgrad': round(gbs(b_d, cold['dgrad']), 1),
+                 'wgrad': round(gbs(b_w, cold['wgrad']), 1)},
+        'warm': {'ms': dict(r3(warm), total=round(t_warm, 4)), 'achieved': round(gbs(total_b, t_warm), 1),
+                 'frac': round(gbs(total_b, t_warm) / HBM_PEAK_GBS, 4),
+                 'note': 'one operand set (128 MB: inside the Infinity Cache) launched over and over'},
+        # every fp32 product = `products` 16-bit matrix products, so the matrix pipe executes that many times the algorithmic
+        # MACs against the 16-bit dense peak
+        'mfma': {'algorithmic_tflops': round(flops / (t_cold * 1e-3) / 1e12, 2),
+                 'issued_16bit_tflops': round(issued * flops / (t_cold * 1e-3) / 1e12, 2), 'dense_peak_tflops': 2500.0,
+                 'utilisation': round(issued * flops / (t_cold * 1e-3) / 1e12 / 2500.0, 4),
+                 'note': 'fp32 products emulated on the 16-bit matrix pipe (gfx942 instruction forms), fp32 accumulate; issued = %.1f x algorithmic' % issued},
         'bf16_storage': bf16_group(),
     }
 
@@ -329,15 +339,17 @@ def roofline_wide_leg(coords_dev, iters=60):
     gy = torch.randn(n, cout, device='cuda', generator=g)
     w = torch.randn(27, cin, cout, device='cuda', generator=g) / (27 * cin) ** 0.5
     ps = km.pair_schedule()
-    wf_f, wf_d = F._weight_layout(w, True, True), F._weight_layout(w, False, True)
+    f2 = F._pairs_f16x2(cin, cout)            # the arithmetic the product runs this layer in (f16x2 unless U2MKD_CONV_ARITH says otherwise)
+    wf_f, wf_d = F._weight_layout(w, True, True, arith=4 if f2 else 0), F._weight_layout(w, False, True, arith=4 if f2 else 0)
+    fr = 2 if f2 else True
     out, dx, dw = torch.empty(n, cout, device='cuda'), torch.empty(n, cin, device='cuda'), torch.empty_like(w)
     pairs, _, plan = km.pairs_plan()
     lib = L.load()
     nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 27)
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     st = L.stream()
-    t = {'fwd': time_events([lambda: ps.run(x, wf_f, cout, False, out, fragments=True)], iters),
-         'dgrad': time_events([lambda: ps.run(gy, wf_d, cin, True, dx, fragments=True)], iters),
+    t = {'fwd': time_events([lambda: ps.run(x, wf_f, cout, False, out, fragments=fr)], iters),
+         'dgrad': time_events([lambda: ps.run(gy, wf_d, cin, True, dx, fragments=fr)], iters),
          'wgrad': time_events([lambda: L.call('u2mkd_conv_wgrad_pairs', L.ptr(x), cin, L.ptr(gy), cout, L.ptr(pairs), L.ptr(plan), n, 27, 0,
                                               L.ptr(ws), nbytes, L.ptr(dw), st)], iters)}
     total = sum(t.values())
@@ -609,6 +621,7 @@ def timed_run(step, warmup, steps, world):
     for i in range(steps):
         loss = step()
         marks[i + 1].record()       # end of step i on the stream the step's last work (optimizer) was queued on; no host wait
+    timed_run.host_issue_ms = (time.perf_counter() - t0) / steps * 1e3     # the host's share: time to QUEUE a step (its own waits included)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -666,6 +679,7 @@ def run_rank(args):
             'dtype': DTYPE_LABEL[args.dtype], 'data': 'synthetic',
             'config': {'workload': desc, 'points_per_gpu': n_pts, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
                        'batches_rotated': args.batches,
+                       'host_issue_ms_per_step': round(timed_run.host_issue_ms, 3),
                        'fresh_tensors_per_step': 'every step runs on a new device copy of batch (i mod %d): kernel maps, '
                                                  'schedules, window and point<->pixel plans are rebuilt inside the timed '
                                                  'region (the voxel sets / kernel maps of batch i+1 during step i, between '

@@ -144,12 +144,20 @@ int u2mkd_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, const 
  *   2 = bf16x3: every fp32 operand is split exactly into three bf16 (8 + 8 + 8 significand bits), the six partial
  *       products above 2^-24 relative are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32 GEMM accuracy
  *       (not the bitwise fma chain) at 2.7x fewer matrix-pipe cycles; inputs and outputs stay fp32;
+ *   4 = f16x2 (tile kernel, fp32 rows, cin in {32, 64, 128}): every gathered row is scaled by the power of two that puts its
+ *       largest |x| into [2^14, 2^15) and split into two fp16 planes (11 + 11 significand bits, round to nearest), the weights
+ *       likewise with one scale per tensor (16-byte trailer {scale, 1/scale, 0, 0} behind each orientation's fragments); the
+ *       three partial products above 2^-24 relative are accumulated in fp32 by v_mfma_f32_16x16x16_f16 and the scales taken
+ *       out exactly -- the accuracy class of bf16x3 at half its matrix instructions; inputs and outputs stay fp32;
  *   0 = the library default (bf16x3; environment U2MKD_CONV_ARITH=f32 selects 1).
+ * u2mkd_conv_tiles_arith(cin, cout, k): the code the host side should pass for a layer of fp32 rows -- 4 where the f16x2
+ * form exists, else 2; U2MKD_CONV_ARITH=f32 / bf16x3 force 1 / 2; 0 = not a tile-kernel layer.
  * Work items (optional): a tile is a serial chain of MFMA blocks, so tiles with many blocks are cut
  * into halves / quarters: items[i] = tile << 4 | sub << 2 | lg  covers the 64 >> lg sorted rows from
  * 64 tile + (64 >> lg) sub, every row exactly once, listed heaviest first; *n_items (device memory,
  * never read by the host) of them.  NULL = one item per 64-row tile.                              */
 int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k);
+int32_t u2mkd_conv_tiles_arith(int32_t cin, int32_t cout, int32_t k);
 size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32_t arith);
 int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
                            void *wf, u2mkd_stream_t s);
@@ -158,7 +166,7 @@ int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols
  * behind the optimizer instead of one latency-bound launch per weight in front of its first convolution.
  * jobs: DEVICE int64 [n_jobs][8] = {w (device address of the fp32 [k,rows,cols] weight), wf (device address of
  * 2 x u2mkd_weight_fragments_bytes(k, rows, cols, arith) bytes: [transpose = 1 | transpose = 0]), first unit, k, rows,
- * cols, planes (3 for arith 2 = bf16x3, 1 for arith 3 = one bf16 plane), 0}; job j owns the units
+ * cols, planes (3 for arith 2 = bf16x3, 1 for arith 3 = one bf16 plane, 2 for arith 4 = f16x2), 0}; job j owns the units
  * [first_j, first_j + 2 k rows cols / 512), consecutive from 0; total_units = their sum.  Replaces nothing in the
  * reference (torchsparse reads `kernel` as it is); it is the price of the MFMA fragment order.            */
 int u2mkd_weight_fragments_batch(const int64_t *jobs, int32_t n_jobs, int64_t total_units, u2mkd_stream_t s);
@@ -226,6 +234,18 @@ int u2mkd_linear_forward(const float *x /*[n,cin]*/, int64_t n, int32_t cin, con
  * and cout as u2mkd_conv_pairs_x3_supported asks.  y holds exactly n rows.                                      */
 int u2mkd_linear_forward_x3(const float *x /*[n,cin]*/, int64_t n, int32_t cin, const void *wf, int32_t cout,
                             const float *bias /*[cout] or NULL*/, float *y /*[n,cout]*/, u2mkd_stream_t s);
+/* The pair-schedule product and the dense product in f16x2 arithmetic (csrc/conv_px3.hip, F2): the same kernels, schedules and
+ * arguments as u2mkd_conv_forward_pairs_x3 / u2mkd_linear_forward_x3 with wf = the arith-4 fragments of u2mkd_weight_fragments
+ * (two fp16 planes + the tensor's scale trailer); every 32-channel step of a gathered row carries its own power-of-two scale.
+ * Half the matrix instructions and two thirds of the weight-fragment bytes of bf16x3 at the same accuracy class.
+ * u2mkd_conv_pairs_f16x2_supported: cin, cout multiples of 32 and no U2MKD_CONV_ARITH=bf16x3 / f32 override.  Replace the same
+ * torchsparse v1.4.0 gather -> mm -> scatter-add and torch.nn.functional.linear as the _x3 entries. */
+int32_t u2mkd_conv_pairs_f16x2_supported(int32_t cin, int32_t cout);
+int u2mkd_conv_forward_pairs_f16x2(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                    const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                    int32_t k, float *y, u2mkd_stream_t s);
+int u2mkd_linear_forward_f16x2(const float *x, int64_t n, int32_t cin, const void *wf, int32_t cout, const float *bias,
+                               float *y, u2mkd_stream_t s);
 /* out[j] = sum_k y[pos[j][k]] (pos < 0: no pair), offsets in ascending order: the
  * deterministic replacement of torchsparse's scatter-add for the pair schedule.             */
 int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos /*[n_rows,k]*/, int64_t n_rows, int32_t k, int32_t cout,

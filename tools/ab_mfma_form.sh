@@ -24,6 +24,6 @@ for suf, name in (('', 'shipped: 2 x v_mfma_f32_16x16x16_bf16'), ('_k32', 'varia
         r, w = ko['roofline'], ko.get('roofline_wide', {})
         print('%-42s run %d: SubMConv3d 64->64 group %.1f us warm (frac %.3f) / %.1f us cold (frac %.3f); 512->512 group %s ms (%s TF fp32-eq); '
               'KD step %.2f ms (median %.2f), teacher deviating steps %s of %s'
-              % (name, rep, r['ms']['total'] * 1e3, r['frac'], r['cold']['ms']['total'] * 1e3, r['cold']['frac'], w.get('ms', {}).get('total'), w.get('achieved'),
+              % (name, rep, r['warm']['ms']['total'] * 1e3, r['warm']['frac'], r['ms']['total'] * 1e3, r['frac'], w.get('ms', {}).get('total'), w.get('achieved'),
                  kd['ms_per_step'], kd['ms_per_step_median'], kd['config']['teacher_deviating_steps'], kd['config']['teacher_steps_compared']))
 PY

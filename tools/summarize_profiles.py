@@ -39,7 +39,10 @@ def full(prefix, *templ):
     hits = [k for k in names if k.startswith(prefix) and all(t in k for t in templ)]
     assert len(hits) == 1, (prefix, templ, hits)
     return hits[0]
-K_TP32, K_TP16 = full('void u2mkd::conv_tp_kernel<4, 1, 64, false, 2'), full('void u2mkd::conv_tp_kernel<4, 1, 64, false, 3')
+# the fp32-row tile kernel of the run: f16x2 (AR = 4, the default) or bf16x3 (AR = 2, U2MKD_CONV_ARITH=bf16x3)
+K_TP32 = (full('void u2mkd::conv_tp_kernel<4, 1, 64, false, 4') if any(k.startswith('void u2mkd::conv_tp_kernel<4, 1, 64, false, 4') for k in names)
+          else full('void u2mkd::conv_tp_kernel<4, 1, 64, false, 2'))
+K_TP16 = full('void u2mkd::conv_tp_kernel<4, 1, 64, false, 3')
 K_WG32, K_WG16 = full('void u2mkd::conv_wgrad_x3_kernel<false>'), full('void u2mkd::conv_wgrad_x3_kernel<true>')
 K_RED, K_FRAG = full('u2mkd::wgrad_pairs_reduce_kernel'), full('u2mkd::weight_fragments_batch_kernel')
 meta = json.loads(line)['roofline']

@@ -40,6 +40,7 @@ SIGNATURES = {
     'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_debug_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_tiles_supported': (_i32, [_i32, _i32, _i32]),
+    'u2mkd_conv_tiles_arith': (_i32, [_i32, _i32, _i32]),
     'u2mkd_weight_fragments_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'u2mkd_weight_fragments': (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'u2mkd_weight_fragments_batch': (C.c_int, [_p, _i32, _i64, _p]),
@@ -61,6 +62,9 @@ SIGNATURES = {
     'u2mkd_bn2d_backward_local': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn2d_backward_apply': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_linear_forward_x3': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
+    'u2mkd_conv_pairs_f16x2_supported': (_i32, [_i32, _i32]),
+    'u2mkd_conv_forward_pairs_f16x2': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _p, _p]),
+    'u2mkd_linear_forward_f16x2': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     'u2mkd_pairs_capacity': (_i64, [_i64, _i64, _i32]),
     'u2mkd_pairs_build': (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'u2mkd_pairs_gather_sum': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

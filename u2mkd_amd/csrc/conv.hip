@@ -1079,6 +1079,19 @@ int u2mkd_debug_conv_forward_sorted(const float *in, int64_t n_in, int32_t cin, 
 
 int32_t u2mkd_conv_tiles_supported(int32_t cin, int32_t cout, int32_t k) { return conv_tp_supported(cin, cout, k) ? 1 : 0; }
 
+/* the arithmetic (u2mkd_weight_fragments' codes) the tile kernel runs a cin -> cout layer in when asked for the default with
+ * fp32 rows: 4 (f16x2) where its row scaling has an instantiation, else 2 (bf16x3); 1 under U2MKD_CONV_ARITH=f32; bf16x3
+ * everywhere under U2MKD_CONV_ARITH=bf16x3.  0: the layer is not the tile kernel's. */
+int32_t u2mkd_conv_tiles_arith(int32_t cin, int32_t cout, int32_t k) {
+    if (!conv_tp_supported(cin, cout, k)) return 0;
+    static const int pref = [] {
+        const char *e = getenv("U2MKD_CONV_ARITH");
+        return (e && e[0] == 'f' && e[1] == '3') ? 1 : (e && e[0] == 'b') ? 2 : 4;
+    }();
+    if (pref == 4) return conv_tp_f16x2_supported(cin) ? 4 : 2;
+    return pref;
+}
+
 size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32_t arith) {
     return weight_fragments_bytes(k, rows, cols, arith);
 }
@@ -1086,7 +1099,7 @@ size_t u2mkd_weight_fragments_bytes(int32_t k, int32_t rows, int32_t cols, int32
 int u2mkd_weight_fragments(const float *w, int32_t k, int32_t rows, int32_t cols, int32_t transpose, int32_t arith,
                            void *wf, u2mkd_stream_t s) {
     U2_REQUIRE(w && wf, "u2mkd_weight_fragments: null pointer");
-    U2_REQUIRE(arith >= 0 && arith <= 3, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32), 2 (bf16x3) or 3 (bf16 storage)");
+    U2_REQUIRE(arith >= 0 && arith <= 4, "u2mkd_weight_fragments: arith must be 0 (default), 1 (f32), 2 (bf16x3), 3 (bf16 storage) or 4 (f16x2)");
     U2_REQUIRE(k > 0 && rows > 0 && cols > 0 && rows % 32 == 0 && cols % 32 == 0,
                "u2mkd_weight_fragments: [%d, %d, %d]: rows and cols must be positive multiples of 32", k, rows, cols);
     U2_REQUIRE(transpose >= 0 && transpose <= 2, "u2mkd_weight_fragments: transpose must be 0, 1 or 2 (both)");
@@ -1106,7 +1119,7 @@ int u2mkd_conv_forward_tiles(const float *in, int64_t n_in, int32_t cin, const v
     if (n_out <= 0) return 0;
     U2_REQUIRE(in && wf && nbr_sorted && out, "u2mkd_conv_forward_tiles: null pointer");
     U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles: kflip must be 0 or 1");
-    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_conv_forward_tiles: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
+    U2_REQUIRE((arith >= 0 && arith <= 2) || arith == 4, "u2mkd_conv_forward_tiles: arith must be 0 (default), 1 (f32), 2 (bf16x3) or 4 (f16x2)");
     U2_REQUIRE(n_in > 0, "u2mkd_conv_forward_tiles: empty input");
     U2_REQUIRE(n_in <= (1 << 25), "u2mkd_conv_forward_tiles: %lld input rows, the tile kernel packs row indices into 25 bits", (long long)n_in);
     U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles: items and n_items go together");
@@ -1125,7 +1138,7 @@ int u2mkd_conv_forward_tiles_ep(const float *in, int64_t n_in, int32_t cin, cons
     if (n_out <= 0) return 0;
     U2_REQUIRE(in && wf && nbr_sorted && out && scale && shift, "u2mkd_conv_forward_tiles_ep: null pointer");
     U2_REQUIRE(kflip == 0 || kflip == 1, "u2mkd_conv_forward_tiles_ep: kflip must be 0 or 1");
-    U2_REQUIRE(arith >= 0 && arith <= 2, "u2mkd_conv_forward_tiles_ep: arith must be 0 (default), 1 (f32) or 2 (bf16x3)");
+    U2_REQUIRE((arith >= 0 && arith <= 2) || arith == 4, "u2mkd_conv_forward_tiles_ep: arith must be 0 (default), 1 (f32), 2 (bf16x3) or 4 (f16x2)");
     U2_REQUIRE(n_in > 0 && n_in <= (1 << 25), "u2mkd_conv_forward_tiles_ep: %lld input rows out of range", (long long)n_in);
     U2_REQUIRE((items == nullptr) == (n_items == nullptr), "u2mkd_conv_forward_tiles_ep: items and n_items go together");
     RowRange rr{n_out, 0, n_out, nullptr};
@@ -1187,6 +1200,38 @@ int u2mkd_conv_forward_pairs_x3(const float *in, int64_t n_in, int32_t cin, cons
                              tile_k, meta + 1, capacity, y, as_stream(s));
     U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_pairs_x3: cin=%d and cout=%d must be multiples of 32 "
                "(ask u2mkd_conv_pairs_x3_supported first)", cin, cout);
+    return rc;
+}
+
+/* the pair-schedule product / the dense product in f16x2 arithmetic: wf = the arith-4 fragments (u2mkd_weight_fragments) */
+int32_t u2mkd_conv_pairs_f16x2_supported(int32_t cin, int32_t cout) {
+    static const int pref = [] {
+        const char *e = getenv("U2MKD_CONV_ARITH");
+        return (e && (e[0] == 'b' || (e[0] == 'f' && e[1] == '3'))) ? 0 : 1;      // bf16x3 / f32 asked for
+    }();
+    return (pref && conv_px3_supported(cin, cout)) ? 1 : 0;
+}
+
+int u2mkd_conv_forward_pairs_f16x2(const float *in, int64_t n_in, int32_t cin, const void *wf, int32_t cout,
+                                    const int32_t *pair_idx, const int32_t *tile_k, const int32_t *meta, int64_t capacity,
+                                    int32_t k, float *y, u2mkd_stream_t s) {
+    if (capacity == 0) return 0;
+    U2_REQUIRE(in && wf && pair_idx && tile_k && meta && y, "u2mkd_conv_forward_pairs_f16x2: null pointer");
+    U2_REQUIRE(k > 0 && n_in > 0 && capacity % 64 == 0, "u2mkd_conv_forward_pairs_f16x2: the capacity must be a multiple of 64");
+    int rc = launch_conv_px3("u2mkd_conv_forward_pairs_f16x2", in, cin, reinterpret_cast<const float *>(wf), cout, pair_idx,
+                             tile_k, meta + 1, capacity, y, as_stream(s), false, k);
+    U2_REQUIRE(rc >= 0, "u2mkd_conv_forward_pairs_f16x2: cin=%d and cout=%d must be multiples of 32", cin, cout);
+    return rc;
+}
+
+int u2mkd_linear_forward_f16x2(const float *x, int64_t n, int32_t cin, const void *wf, int32_t cout, const float *bias,
+                               float *y, u2mkd_stream_t s) {
+    if (n == 0) return 0;
+    U2_REQUIRE(x && wf && y, "u2mkd_linear_forward_f16x2: null pointer");
+    U2_REQUIRE(n > 0 && n < ((int64_t)1 << 31) - 64, "u2mkd_linear_forward_f16x2: %lld rows out of range", (long long)n);
+    int rc = launch_linear_px3("u2mkd_linear_forward_f16x2", x, n, cin, reinterpret_cast<const float *>(wf), cout, bias, y,
+                               as_stream(s), false, true);
+    U2_REQUIRE(rc >= 0, "u2mkd_linear_forward_f16x2: cin=%d and cout=%d must be multiples of 32", cin, cout);
     return rc;
 }
 

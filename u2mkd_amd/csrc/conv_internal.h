@@ -47,6 +47,37 @@ __device__ __forceinline__ f32x4 mfma_bf16_k32(const V8 &a, const V8 &b, f32x4 c
 #endif
 }
 
+// ---- fp32 through TWO fp16 operands ("f16x2") ------------------------------------------------------------------------------------
+// x * s = h + l (+ a rest below 2^-23 |x s|) with h = fp16(x s), l = fp16(x s - h), s a power of two that puts the largest |x| of
+// the scaled set (a gathered row; a weight tensor) into [2^14, 2^15): both planes stay inside fp16's range whatever the magnitude
+// of the fp32 data, and the result is scaled back exactly.  a * b = hh + hl + lh (+ ll, below 2^-24 |a b|, dropped): THREE
+// products instead of bf16x3's six at the same accuracy class (round-to-nearest planes: ~2^-23 per product), on
+// v_mfma_f32_16x16x16_f16 -- a gfx942 form, clean next to other streams (see above), same rate as the bf16 one.
+typedef _Float16 u2_h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 u2_h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 u2_h16x2 __attribute__((ext_vector_type(2)));
+template <int H, class V8>
+__device__ __forceinline__ f32x4 mfma_f16_k32_half(const V8 &a, const V8 &b, f32x4 c) {
+    static_assert(sizeof(V8) == 16, "mfma_f16_k32_half: 8 fp16 per lane");
+    const u2_h16x8 a8 = __builtin_bit_cast(u2_h16x8, a), b8 = __builtin_bit_cast(u2_h16x8, b);
+    return H == 0 ? __builtin_amdgcn_mfma_f32_16x16x16f16(a8.lo, b8.lo, c, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x16f16(a8.hi, b8.hi, c, 0, 0, 0);
+}
+// the power of two s (and 1 / s) that puts m >= 0 into [2^14, 2^15); exponents clamped so that both stay normal floats
+__device__ __forceinline__ void f16x2_scale(float m, float &s, float &inv) {
+    unsigned e = __float_as_uint(m) >> 23;
+    e = e < 15u ? 15u : (e > 253u ? 253u : e);
+    s = __uint_as_float((268u - e) << 23);
+    inv = __uint_as_float((e - 14u) << 23);
+}
+// two scaled values -> their packed h and l planes
+__device__ __forceinline__ void f16x2_split2(float a, float b, uint32_t &h, uint32_t &l) {
+    const u2_h16x2 hv = {(_Float16)a, (_Float16)b};
+    const u2_h16x2 lv = {(_Float16)(a - (float)hv[0]), (_Float16)(b - (float)hv[1])};
+    h = __builtin_bit_cast(uint32_t, hv);
+    l = __builtin_bit_cast(uint32_t, lv);
+}
+
 // Rows a table-walking forward launch covers: sorted rows [begin, end) of the neighbour table
 // nbr[k * ld + row].
 struct RowRange {
@@ -64,6 +95,7 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
                    const int32_t *order, RowRange rr, const int32_t *items, const int32_t *n_items, int k, int kflip,
                    int arith, float *out, hipStream_t st, unsigned long long *stamps = nullptr);
 bool conv_tp_supported(int cin, int cout, int k);
+bool conv_tp_f16x2_supported(int cin);
 int conv_tp_arith(int arith);
 size_t weight_fragments_bytes(int k, int rows, int cols, int arith);
 int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st);
@@ -72,10 +104,11 @@ int launch_weight_fragments_batch(const int64_t *jobs, int n_jobs, int64_t total
 // Global pair schedule in bf16x3 arithmetic (conv_px3.hip); wf = arith-2 fragments.  -1 = shape not supported.
 bool conv_px3_supported(int cin, int cout);
 int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
-                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16 = false);
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16 = false,
+                    int f16x2_k = 0 /* > 0: wf = the arith-4 (f16x2) fragments of a weight with this many offsets */);
 // the same kernel with the identity pair list: y[n_rows, cout] = in x B (+ bias), one offset (nn.Linear)
 int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
-                      const float *bias, float *y, hipStream_t st, bool b16 = false);
+                      const float *bias, float *y, hipStream_t st, bool b16 = false, bool f16x2 = false);
 
 // Weight gradient in bf16x3 arithmetic (conv_wgrad_x3.hip): 64 x 64-channel tiles, slabs as the f32 kernel.
 bool conv_wgrad_x3_supported(int ca, int cb, int k);

@@ -65,13 +65,24 @@ __device__ __forceinline__ px_bf16x8 px_bf8(const float4 &x) {
 // through the vector L1 (weight fragments from L2 / Infinity Cache + gathered rows: ~7 TB/s chip-wide at 512 -> 512), and
 // per 128 pairs x 256 columns x 32 channels those are 2 x (48 KB weights + 8 KB rows) = 112 KB with TL = 1 and 256-column
 // tiles (NBW = 4), 2 x (24 + 16) = 80 KB with TL = 2 and 128-column tiles (NBW = 2) at the same 64 accumulator registers.
-template <int NW, int NBW, bool DENSE = false, bool B16 = false, int SC = 32, int TL = 1>
+// F2: fp32 rows in f16x2 arithmetic (conv_internal.h) instead of bf16x3: the 32 channels of a row's step are scaled by the power of
+// two that puts their largest |x| into [2^14, 2^15) and split into two fp16 planes (the third plane's place in the LDS row holds
+// 1 / (row scale x weight scale)); a step's three partial products start from zero and join the accumulators through one fma per
+// register that takes the scales out again -- half the matrix instructions and two thirds of the weight-fragment bytes of bf16x3.
+// wf = the arith-4 fragments, `k_total` = the weight's number of offsets (the scale trailer sits behind all of them).
+template <int CTRL>
+__device__ __forceinline__ float px_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int NW, int NBW, bool DENSE = false, bool B16 = false, int SC = 32, int TL = 1, bool F2 = false>
 __global__ void __launch_bounds__(64 * NW)
 conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__ wf, int cout,
                 const int32_t *__restrict__ pair_idx, const int32_t *__restrict__ tile_k,
                 const int32_t *__restrict__ n_tiles, float *__restrict__ y, const float *__restrict__ bias = nullptr,
-                int n_rows = 0) {
+                int n_rows = 0, int k_total = 1) {
     static_assert(B16 ? (SC == 32 || SC == 64) : SC == 32, "step width");
+    static_assert(!(F2 && B16), "f16x2 is an arithmetic of fp32 rows");
     constexpr int NT = 64 * NW, TN = 16 * NW * NBW;
     // bytes per row of the LDS image: 3 planes x 32 bf16 (or up to 64 bf16), NO pad; the 16-byte chunk c of a 64-byte plane
     // segment of tile row `row` sits at chunk c ^ 2 * bit 3 of row.  A ds_read_b128 is served in four 16-lane groups (rows
@@ -85,7 +96,8 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
     constexpr int RU = 64 * TL, RB = 4 * TL;      // rows / 16-row blocks of a unit
     constexpr int NCH = RU * CH;                  // chunks per step
     constexpr int LPT = (NCH + NT - 1) / NT;      // 16-byte chunks a thread gathers per step
-    constexpr int NWF = B16 ? SC / 32 : 3;        // weight / row fragments per (column block, step): k-steps or planes
+    constexpr int NWF = B16 ? SC / 32 : F2 ? 2 : 3;        // weight / row fragments per (column block, step): k-steps or planes
+    const float wsc = F2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(wf) + (size_t)k_total * cin * cout * 4)[1] : 1.f;
     const int esz = B16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][RU][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,6 +186,23 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
             if (B16) {
                 if (tid + l * NT < NCH)
                     *reinterpret_cast<f32x4 *>(smem + (slot * RU + crow[l]) * RS + 16 * (cch[l] ^ ((crow[l] >> 2) & 2))) = gg[l];
+            } else if (F2) {
+                // the step's largest |x| of the row: its 8 lanes (every lane of the wave takes part: NCH is a multiple of 64)
+                float m = fmaxf(fmaxf(fabsf(gg[l][0]), fabsf(gg[l][1])), fmaxf(fabsf(gg[l][2]), fabsf(gg[l][3])));
+                m = fmaxf(m, px_dpp<0xB1>(m));                  // quad_perm [1, 0, 3, 2]
+                m = fmaxf(m, px_dpp<0x4E>(m));                  // quad_perm [2, 3, 0, 1]
+                m = fmaxf(m, px_dpp<0x141>(m));                 // row_half_mirror: the other quad of the 8
+                float rs, rinv;
+                f16x2_scale(m, rs, rinv);
+                if (tid + l * NT < NCH) {
+                    uint32_t h01, l01, h23, l23;
+                    f16x2_split2(gg[l][0] * rs, gg[l][1] * rs, h01, l01);
+                    f16x2_split2(gg[l][2] * rs, gg[l][3] * rs, h23, l23);
+                    char *row = smem + (slot * RU + crow[l]) * RS + 8 * (cch[l] ^ ((crow[l] >> 1) & 4));
+                    *reinterpret_cast<uint2 *>(row) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2 *>(row + 64) = make_uint2(l01, l23);
+                    if (cch[l] == 0) *reinterpret_cast<float *>(smem + (slot * RU + crow[l]) * RS + 128) = rinv * wsc;
+                }
             } else if (tid + l * NT < NCH) {
                 // split by truncation (x & 0xffff0000; exact residuals), two bf16 packed per dword by a byte permute
                 uint32_t hb[4], mb[4], lb[4];
@@ -259,6 +288,31 @@ conv_px3_kernel(const float *__restrict__ in, int cin, const float *__restrict__
                 }
                 continue;
             }
+            if (F2) {      // three partial products from zero, the column blocks' chains interleaved; then the scales out
+                const float osc = *reinterpret_cast<const float *>(smem + (u * RU + 16 * rb + r) * RS + 128);
+                const float4 xh = a[rb & 1][0], xl = a[rb & 1][NWF - 1];
+                f32x4 c[NBW];
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<0>(bw[u][NWF * n + NWF - 1], xh, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<1>(bw[u][NWF * n + NWF - 1], xh, c[n]);
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<0>(bw[u][NWF * n], xl, c[n]);
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<1>(bw[u][NWF * n], xl, c[n]);
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<0>(bw[u][NWF * n], xh, c[n]);
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) c[n] = mfma_f16_k32_half<1>(bw[u][NWF * n], xh, c[n]);
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    acc[rb][n][0] = fmaf(c[n][0], osc, acc[rb][n][0]);
+                    acc[rb][n][1] = fmaf(c[n][1], osc, acc[rb][n][1]);
+                    acc[rb][n][2] = fmaf(c[n][2], osc, acc[rb][n][2]);
+                    acc[rb][n][3] = fmaf(c[n][3], osc, acc[rb][n][3]);
+                }
+                continue;
+            }
             const px_bf16x8 xh = px_bf8(a[rb & 1][0]), xm = px_bf8(a[rb & 1][NWF / 2]), xl = px_bf8(a[rb & 1][NWF - 1]);
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
@@ -338,14 +392,14 @@ static Px3Shape px3_shape(int cin, int cout) {
     return p;
 }
 
-template <bool DENSE, bool B16, int SC>
+template <bool DENSE, bool B16, int SC, bool F2 = false>
 static void px3_launch(const Px3Shape &p, dim3 grid, hipStream_t st, const float *in, int cin, const float *wf, int cout,
                        const int32_t *pair_idx, const int32_t *tile_k, const int32_t *n_tiles, float *y, const float *bias,
-                       int n_rows) {
+                       int n_rows, int k_total = 1) {
     const size_t lds = (size_t)2 * 64 * p.tl * 192;
 #define U2_PX3(NW_, NBW_, TL_)                                                                                                  \
-    hipLaunchKernelGGL((conv_px3_kernel<NW_, NBW_, DENSE, B16, SC, TL_>), grid, dim3(64 * NW_), lds, st, in, cin, wf, cout, pair_idx, \
-                       tile_k, n_tiles, y, bias, n_rows)
+    hipLaunchKernelGGL((conv_px3_kernel<NW_, NBW_, DENSE, B16, SC, TL_, F2>), grid, dim3(64 * NW_), lds, st, in, cin, wf, cout, pair_idx, \
+                       tile_k, n_tiles, y, bias, n_rows, k_total)
     if (p.tl == 2) {
         if (p.w3) U2_PX3(3, 2, 2); else U2_PX3(4, 2, 2);
     } else if (p.nbw == 4) {
@@ -358,7 +412,8 @@ static void px3_launch(const Px3Shape &p, dim3 grid, hipStream_t st, const float
 
 // b16: `in` and `y` are bf16 rows, wf = the arith-3 (one bf16 plane) fragments
 int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, int cout, const int32_t *pair_idx,
-                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16) {
+                    const int32_t *tile_k, const int32_t *n_tiles, int64_t capacity, float *y, hipStream_t st, bool b16,
+                    int f16x2_k) {
     if (!conv_px3_supported(cin, cout)) return -1;
     const Px3Shape p = px3_shape(cin, cout);
     // ONE resident wave of workgroups (registers: 2 or 3 per CU), a multiple of 8 = the same number per XCD; fewer when the
@@ -368,7 +423,8 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
     int64_t gx = std::min<int64_t>(cap_x, ceil_div(capacity / (64 * p.tl) * gy, 8) * 8);
     if (gx < 8) gx = 8;
     dim3 grid((unsigned)gx);
-    if (!b16) px3_launch<false, false, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
+    if (f16x2_k > 0) px3_launch<false, false, 32, true>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0, f16x2_k);
+    else if (!b16) px3_launch<false, false, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     else if (cin % 64 == 0) px3_launch<false, true, 64>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     else px3_launch<false, true, 32>(p, grid, st, in, cin, wf, cout, pair_idx, tile_k, n_tiles, y, nullptr, 0);
     return check_launch(who);
@@ -376,7 +432,7 @@ int launch_conv_px3(const char *who, const float *in, int cin, const float *wf, 
 
 // y[n_rows, cout] = in[n_rows, cin] x B (+ bias), B in the arith-2 (b16: arith-3) fragment order of ONE offset
 int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin, const float *wf, int cout,
-                      const float *bias, float *y, hipStream_t st, bool b16) {
+                      const float *bias, float *y, hipStream_t st, bool b16, bool f16x2) {
     if (!conv_px3_supported(cin, cout)) return -1;
     const Px3Shape p = px3_shape(cin, cout);
     const int gy = (int)ceil_div(cout, p.tn);
@@ -384,7 +440,8 @@ int launch_linear_px3(const char *who, const float *in, int64_t n_rows, int cin,
     int64_t gx = std::min<int64_t>(cap_x, ceil_div(ceil_div(n_rows, 64 * p.tl) * gy, 8) * 8);
     if (gx < 8) gx = 8;
     dim3 grid((unsigned)gx);
-    if (!b16) px3_launch<true, false, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
+    if (f16x2) px3_launch<true, false, 32, true>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows, 1);
+    else if (!b16) px3_launch<true, false, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     else if (cin % 64 == 0) px3_launch<true, true, 64>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     else px3_launch<true, true, 32>(p, grid, st, in, cin, wf, cout, nullptr, nullptr, nullptr, y, bias, (int)n_rows);
     return check_launch(who);

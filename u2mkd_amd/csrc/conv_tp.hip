@@ -102,7 +102,7 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
     if (t >= total) return;
     if (transpose == 2) {      // both orientations in one launch: [transpose = 1 | transpose = 0]
         transpose = 1 - (int)blockIdx.y;
-        wf += (size_t)blockIdx.y * total * PLANES;
+        wf += (size_t)blockIdx.y * (total * PLANES + (PLANES == 2 ? 1 : 0));     // (f16x2: + the 16-byte scale trailer)
     }
     const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
     const int lane = (int)(t & 63);
@@ -122,6 +122,18 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
         const float4 a = p[0], b = p[1];
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
     }
+    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * PLANES * 64 + lane;
+    if (PLANES == 2) {      // f16x2: h | l planes of w * scale, scale = the tensor's (trailer, weight_absmax_kernel)
+        const float sc = reinterpret_cast<const float *>(wf + total * PLANES)[0];
+        uint4 vh4, vl4;
+        f16x2_split2(x[0] * sc, x[1] * sc, vh4.x, vl4.x);
+        f16x2_split2(x[2] * sc, x[3] * sc, vh4.y, vl4.y);
+        f16x2_split2(x[4] * sc, x[5] * sc, vh4.z, vl4.z);
+        f16x2_split2(x[6] * sc, x[7] * sc, vh4.w, vl4.w);
+        o[0] = __builtin_bit_cast(bf16x8, vh4);
+        o[64] = __builtin_bit_cast(bf16x8, vl4);
+        return;
+    }
     bf16x8 vh, vm, vl;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -129,11 +141,44 @@ __global__ void weight_fragments_x3_kernel(const float *__restrict__ w, int rows
         split3(x[i], h, m, l);
         vh[i] = h; vm[i] = m; vl[i] = l;
     }
-    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * PLANES * 64 + lane;
     o[0] = vh;              // PLANES == 1 (bf16 storage): the weights rounded to bf16
     if (PLANES == 3) {
         o[64] = vm;
         o[128] = vl;
+    }
+}
+
+// f16x2 fragments: the power-of-two scale of a whole weight tensor (largest |w| -> [2^14, 2^15)), written as {scale, 1 / scale, 0, 0}
+// into the 16-byte trailer behind the fragments of each orientation.  One workgroup per weight: jobs == nullptr: the one tensor
+// (w, elems, trailer0, trailer1); else job blockIdx.x of the batch table (only jobs with planes == 2 do anything).
+__global__ void __launch_bounds__(1024)
+weight_absmax_kernel(const int64_t *__restrict__ jobs, const float *w, int64_t elems, float *t0, float *t1) {
+    if (jobs) {
+        const int64_t *jb = jobs + (size_t)blockIdx.x * 8;
+        if (jb[6] != 2) return;
+        w = reinterpret_cast<const float *>(jb[0]);
+        elems = jb[3] * jb[4] * jb[5];
+        char *base = reinterpret_cast<char *>(jb[1]);
+        t0 = reinterpret_cast<float *>(base + (size_t)elems * 4);                 // 2 planes x 2 bytes per element
+        t1 = reinterpret_cast<float *>(base + (size_t)elems * 8 + 16);
+    }
+    __shared__ float s_m[16];
+    float m = 0.f;
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    for (int64_t e = threadIdx.x; e < elems / 4; e += 1024) {      // (elems is a multiple of 1024: rows, cols multiples of 32)
+        const float4 v = w4[e];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, s_m[i]);
+        float sc, inv;
+        f16x2_scale(m, sc, inv);
+        t0[0] = sc; t0[1] = inv; t0[2] = 0.f; t0[3] = 0.f;
+        t1[0] = sc; t1[1] = inv; t1[2] = 0.f; t1[3] = 0.f;
     }
 }
 
@@ -161,7 +206,7 @@ weight_fragments_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs) {
     const int64_t per = jb[3] * rows * cols / 512;           // units per orientation
     int64_t u = unit - jb[2];
     const int transpose = u < per ? 1 : 0;
-    if (!transpose) { u -= per; wf += (size_t)per * 64 * planes; }
+    if (!transpose) { u -= per; wf += (size_t)per * 64 * planes + (planes == 2 ? 1 : 0); }      // (f16x2: + the scale trailer)
     const int ncol = transpose ? cols : rows, nred = transpose ? rows : cols;
     const int ns = nred / 32, ncb = ncol / 16;
     const int sstep = (int)(u % ns);
@@ -178,6 +223,18 @@ weight_fragments_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs) {
         const float4 a = p[0], b = p[1];
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
     }
+    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * planes * 64 + lane;
+    if (planes == 2) {      // f16x2 (the scale: weight_absmax_kernel, launched in front of this kernel)
+        const float sc = reinterpret_cast<const float *>(wf + (size_t)per * 64 * planes)[0];
+        uint4 vh4, vl4;
+        f16x2_split2(x[0] * sc, x[1] * sc, vh4.x, vl4.x);
+        f16x2_split2(x[2] * sc, x[3] * sc, vh4.y, vl4.y);
+        f16x2_split2(x[4] * sc, x[5] * sc, vh4.z, vl4.z);
+        f16x2_split2(x[6] * sc, x[7] * sc, vh4.w, vl4.w);
+        o[0] = __builtin_bit_cast(bf16x8, vh4);
+        o[64] = __builtin_bit_cast(bf16x8, vl4);
+        return;
+    }
     bf16x8 vh, vm, vl;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -185,7 +242,6 @@ weight_fragments_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs) {
         split3(x[i], h, m, l);
         vh[i] = h; vm[i] = m; vl[i] = l;
     }
-    bf16x8 *o = wf + (((size_t)k * ncb + cb) * ns + sstep) * planes * 64 + lane;
     o[0] = vh;
     if (planes == 3) {
         o[64] = vm;
@@ -196,6 +252,11 @@ weight_fragments_batch_kernel(const int64_t *__restrict__ jobs, int n_jobs) {
 __device__ __forceinline__ bf16x8 as_bf8(const float4 &x) {
     f32x4 v = (f32x4){x.x, x.y, x.z, x.w};
     return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
 template <int NW, int NBW, int CIN, bool STAMP, int AR, bool SB = true>
@@ -212,7 +273,9 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // AR: 1 = fp32 rows, f32 MFMA; 2 = fp32 rows, bf16x3; 3 = BF16 STORAGE: `in` and `out` are bf16 rows, wf = one bf16
     // plane (u2mkd_weight_fragments arith 3), one v_mfma_f32_16x16x32_bf16 per 32-channel step, fp32 accumulation in the
     // LDS tile, outputs rounded to bf16 once (BASELINE.json configs[4]: half the gather bytes, no run-time split)
-    constexpr bool X3 = AR == 2, B16 = AR == 3;
+    // 4 = fp32 rows, f16x2: two fp16 planes of every gathered row scaled by a per-row power of two, three products per 16 channels
+    // (conv_internal.h), the row's and the weight tensor's scales taken out again when the block's products join the output tile
+    constexpr bool X3 = AR == 2, B16 = AR == 3, F2 = AR == 4;
     constexpr int T = 64, NT = 64 * NW, TN = 16 * NW * NBW, NJ = CIN / 16;
     constexpr int OS = TN + 4;                    // output tile row stride (floats)
     // gathered-row image: fp32 rows, or (X3) three bf16 planes h | m | l of CIN elements per row; + 16 B pad
@@ -221,7 +284,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     // if their 16 x 4 dwords hit 64 different banks: AS / 4 even and = 2 (mod 4).  (Rounds 2-3 ran data + 4: every fragment read
     // was a 2-way conflict, 96 of the ~400 LDS cycles of a block.)
     constexpr int AS = (X3 ? 6 * CIN / 4 : B16 ? 2 * CIN / 4 : CIN) + kTpPad;
-    constexpr int NF = X3 ? CIN / 32 * 3 : B16 ? CIN / 32 : CIN / 16;   // 16-byte operand fragments per lane per block
+    constexpr int NF = X3 ? CIN / 32 * 3 : F2 ? CIN / 32 * 2 : B16 ? CIN / 32 : CIN / 16;   // 16-byte operand fragments per lane per block
     constexpr int CPR = B16 ? CIN / 8 : CIN / 4;  // 16-byte chunks per gathered row
     constexpr int LPT = (16 * CPR + NT - 1) / NT; // chunks a thread moves per block
     constexpr int KPW = (32 + NW - 1) / NW;       // offsets a wave compacts (K <= 32)
@@ -232,6 +295,9 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
     int *s_cnt = s_idx + (K + 1) * T;                                         // [32] pairs per offset
     int *s_rid = s_cnt + 32;                                                  // [T] original output row
     int *s_blk = s_rid + T;                                                   // [4K + 8] block descriptors
+    float *s_sc = reinterpret_cast<float *>(s_blk + 4 * K + 8);               // (F2) [2][16] 1 / (row scale x weight scale) of the row image's rows
+    // (F2) 1 / scale of the weight tensor: the trailer behind this orientation's fragments
+    const float wsc = F2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(wf) + (size_t)K * cout * CIN * 4)[1] : 1.f;
 
     const int col0 = blockIdx.y * TN;
     const int64_t n_out = rr_.end, ld = rr_.ld;
@@ -420,8 +486,26 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
         for (int i = 0; i < LPT; ++i) {
             const int e = tid + i * NT;
             const int pr = e / CPR, ch = e - pr * CPR;
+            float rs = 1.f, rinv = 1.f;
+            if (F2) {      // the row's largest |x| over its CPR lanes (all lanes of the wave take part: 16 * CPR is a multiple of 64)
+                float m = fmaxf(fmaxf(fabsf(gg[i][0]), fabsf(gg[i][1])), fmaxf(fabsf(gg[i][2]), fabsf(gg[i][3])));
+                m = fmaxf(m, dpp_f<0xB1>(m));                  // quad_perm [1, 0, 3, 2]
+                m = fmaxf(m, dpp_f<0x4E>(m));                  // quad_perm [2, 3, 0, 1]
+                m = fmaxf(m, dpp_f<0x141>(m));                 // row_half_mirror: the other quad of the 8
+                if (CPR >= 16) m = fmaxf(m, dpp_f<0x140>(m));  // row_mirror: the other half of the 16
+                if (CPR >= 32) m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), 0x401F)));   // lane ^ 16
+                f16x2_scale(m, rs, rinv);
+            }
             if (e < 16 * CPR) {
-                if (X3) {      // split the 4 channels into the three bf16 planes of the row image
+                if (F2) {      // the two fp16 planes of the scaled row: h | l, CIN elements each
+                    uint32_t h01, l01, h23, l23;
+                    f16x2_split2(gg[i][0] * rs, gg[i][1] * rs, h01, l01);
+                    f16x2_split2(gg[i][2] * rs, gg[i][3] * rs, h23, l23);
+                    char *row = reinterpret_cast<char *>(s_a + (slot * 16 + pr) * AS) + 8 * ch;
+                    *reinterpret_cast<uint2 *>(row) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2 *>(row + 2 * CIN) = make_uint2(l01, l23);
+                    if (ch == 0) s_sc[slot * 16 + pr] = rinv * wsc;
+                } else if (X3) {      // split the 4 channels into the three bf16 planes of the row image
                     // by TRUNCATION (x & 0xffff0000, exact residuals: h + m + l = x as with the rounding split of the
                     // weights, fewer instructions: 2 and + 2 sub per element, one byte-permute per two elements and plane)
                     uint32_t hb[4], mb[4], lb[4];
@@ -452,6 +536,9 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             if (X3)    // fragment j = 3 s + p: 8 consecutive channels 32 s + 8 q .. of plane p
                 aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) +
                                                           (j % 3) * 2 * CIN + 64 * (j / 3) + 16 * q);
+            else if (F2)   // fragment j = 2 s + p
+                aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) +
+                                                          (j % 2) * 2 * CIN + 64 * (j / 2) + 16 * q);
             else if (B16)   // fragment j: 8 consecutive bf16 channels 32 j + 8 q ..
                 aa[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_a + (slot * 16 + r) * AS) + 64 * j + 16 * q);
             else
@@ -479,6 +566,7 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
             constexpr int u = decltype(U)::value;
                 // -- issue everything later steps need
             read_frag(u & 1, a);                                     // block t (stored at step t-1, barrier since)
+            const float osc = F2 ? s_sc[(u & 1) * 16 + r] : 1.f;
             if (!SB) issue_B(d1, bw[SB ? 0 : ((u + 1) & 1)]);       // block t+1
             issue_G(g[u % 3]);                                       // block t+3 (block t left these registers at step t-1)
             read_gix(d4);                                            // block t+4
@@ -527,6 +615,20 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                         acc1 = mfma_bf16_k32_half<1>(wh, xh, acc1);
 #endif
                     }
+                } else if (F2) {
+                    // three partial products per 32-channel step (hl, lh, hh: low order first), six K = 16 instructions on
+                    // two alternating accumulation chains
+#pragma unroll
+                    for (int sk = 0; sk < CIN / 32; ++sk) {
+                        const float4 wh = bw[SB ? 0 : (u & 1)][2 * sk][n], wl = bw[SB ? 0 : (u & 1)][2 * sk + 1][n];
+                        const float4 xh = a[2 * sk], xl = a[2 * sk + 1];
+                        acc0 = mfma_f16_k32_half<0>(wl, xh, acc0);
+                        acc1 = mfma_f16_k32_half<0>(wh, xl, acc1);
+                        acc0 = mfma_f16_k32_half<1>(wl, xh, acc0);
+                        acc1 = mfma_f16_k32_half<1>(wh, xl, acc1);
+                        acc0 = mfma_f16_k32_half<0>(wh, xh, acc0);
+                        acc1 = mfma_f16_k32_half<1>(wh, xh, acc1);
+                    }
                 } else if (B16) {
 #pragma unroll
                     for (int sk = 0; sk < CIN / 32; ++sk) {
@@ -549,10 +651,17 @@ conv_tp_kernel(const float *__restrict__ in, const float *__restrict__ wf, int c
                 // the store, every step)
                 asm volatile("" : "+v"(o[n].x), "+v"(o[n].y), "+v"(o[n].z), "+v"(o[n].w));
                 if (live) {
-                    o[n].x += acc0[0] + acc1[0];
-                    o[n].y += acc0[1] + acc1[1];
-                    o[n].z += acc0[2] + acc1[2];
-                    o[n].w += acc0[3] + acc1[3];
+                    if (F2) {      // the row's and the weights' scales out again (a power of two: exact)
+                        o[n].x = fmaf(acc0[0] + acc1[0], osc, o[n].x);
+                        o[n].y = fmaf(acc0[1] + acc1[1], osc, o[n].y);
+                        o[n].z = fmaf(acc0[2] + acc1[2], osc, o[n].z);
+                        o[n].w = fmaf(acc0[3] + acc1[3], osc, o[n].w);
+                    } else {
+                        o[n].x += acc0[0] + acc1[0];
+                        o[n].y += acc0[1] + acc1[1];
+                        o[n].z += acc0[2] + acc1[2];
+                        o[n].w += acc0[3] + acc1[3];
+                    }
                     *po[n] = o[n];
                 }
             }
@@ -643,7 +752,7 @@ static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const f
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
     const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * ((AR == 2 ? 6 * CIN : AR == 3 ? 2 * CIN : 4 * CIN) + 4 * kTpPad) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
-                       (size_t)(4 * K + 8) * 4;
+                       (size_t)(4 * K + 8) * 4 + (AR == 4 ? 2 * 16 * 4 : 0);
     const int n_tiles = (int)ceil_div(rr.end - rr.begin, 64);
     // one resident wave of workgroups at most (they deal the items among themselves, lightest first)
     static int occ_by_k[33];                         // resident workgroups per CU of THIS instantiation at kernel volume K
@@ -678,13 +787,16 @@ bool conv_tp_supported(int cin, int cout, int k) {
     return cin * nbw <= 128;      // weight fragment (double-buffered) + gathered rows stay in registers
 }
 
+// f16x2 (arith 4): a gathered row's 16-byte chunks must fill whole 16-lane groups (the in-register row maximum)
+bool conv_tp_f16x2_supported(int cin) { return cin == 32 || cin == 64 || cin == 128; }
+
 // arithmetic of the tile-pair kernel: 1 = f32 MFMA (bitwise fma chain), 2 = bf16x3 (fp32 accuracy, 2.7x fewer
 // matrix-pipe cycles); 0 = the library default (U2MKD_CONV_ARITH=f32|bf16x3, default bf16x3)
 int conv_tp_arith(int arith) {
-    if (arith == 1 || arith == 2 || arith == 3) return arith;
+    if (arith >= 1 && arith <= 4) return arith;
     static const int dflt = [] {
         const char *e = getenv("U2MKD_CONV_ARITH");
-        return (e && e[0] == 'f') ? 1 : 2;
+        return (e && e[0] == 'f' && e[1] == '3') ? 1 : 2;      // ("f16x2" concerns the tile kernel only: u2mkd_conv_tiles_arith)
     }();
     return dflt;
 }
@@ -696,12 +808,14 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
     int nw = 0, nbw = 0;
     tp_split(cout, nw, nbw);
     const int ar = conv_tp_arith(arith);
+    if (ar == 4 && !conv_tp_f16x2_supported(cin)) return -1;
     const bool x3 = ar == 2;
     const int64_t n_rows = rr.end - rr.begin;
     dim3 grid((unsigned)(ceil_div(n_rows, 64) * (items ? 4 : 1)), 1);     // <= 4 items per 64-row tile; launch_tp clamps it
 #define U2_TP(NW_, NBW_, CIN_)                                                                                          \
     do {                                                                                                                \
         if (ar == 3) launch_tp<NW_, NBW_, CIN_, false, 3>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
+        else if (ar == 4 && CIN_ != 96) launch_tp<NW_, NBW_, (CIN_ != 96 ? CIN_ : 64), false, 4>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
         else if (x3) launch_tp<NW_, NBW_, CIN_, false, 2>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);  \
         else launch_tp<NW_, NBW_, CIN_, false, 1>(grid, k, st, in, wf, cout, nbr, order, rr, items, n_items, kflip, out);    \
     } while (0)
@@ -724,20 +838,27 @@ int launch_conv_tp(const char *who, const float *in, int cin, const float *wf, i
 
 size_t weight_fragments_bytes(int k, int rows, int cols, int arith) {
     const int ar = conv_tp_arith(arith);
-    return (size_t)k * rows * cols * (ar == 2 ? 6 : ar == 3 ? 2 : 4);
+    return (size_t)k * rows * cols * (ar == 2 ? 6 : ar == 3 ? 2 : 4) + (ar == 4 ? 16 : 0);      // (f16x2: two fp16 planes + the scale trailer)
 }
 
 int launch_weight_fragments(const float *w, int k, int rows, int cols, int transpose, int arith, float *wf, hipStream_t st) {
     const int64_t elems = (int64_t)k * rows * cols;
     if (elems == 0) return 0;
     const int ar = conv_tp_arith(arith);
-    if (ar == 2 || ar == 3) {
+    if (ar == 2 || ar == 3 || ar == 4) {
         const int64_t total = elems / 8;          // one thread per (offset, column, 8 reduction channels)
         // one-wave workgroups: the kernel is a single round of loads and stores per thread (latency-bound), and 27 x 64 x 64
         // weights are only 432 waves -- as 256-thread workgroups they sat on 108 of the 256 CUs
         constexpr int bt = 64;
         const dim3 grid((unsigned)ceil_div(total, bt), transpose == 2 ? 2 : 1);
-        if (ar == 2)
+        if (ar == 4) {
+            char *base = reinterpret_cast<char *>(wf);
+            float *t0 = reinterpret_cast<float *>(base + (size_t)elems * 4);
+            float *t1 = transpose == 2 ? reinterpret_cast<float *>(base + (size_t)elems * 8 + 16) : t0;
+            hipLaunchKernelGGL(weight_absmax_kernel, dim3(1), dim3(1024), 0, st, (const int64_t *)nullptr, w, elems, t0, t1);
+            hipLaunchKernelGGL(weight_fragments_x3_kernel<2>, grid, dim3(bt), 0, st, w, rows, cols, transpose,
+                               reinterpret_cast<bf16x8 *>(wf), total);
+        } else if (ar == 2)
             hipLaunchKernelGGL(weight_fragments_x3_kernel<3>, grid, dim3(bt), 0, st, w, rows, cols, transpose,
                                reinterpret_cast<bf16x8 *>(wf), total);
         else
@@ -752,6 +873,9 @@ int launch_weight_fragments(const float *w, int k, int rows, int cols, int trans
 
 int launch_weight_fragments_batch(const int64_t *jobs, int n_jobs, int64_t total_units, hipStream_t st) {
     if (n_jobs == 0 || total_units == 0) return 0;
+    // (jobs without f16x2 planes leave at once)
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3((unsigned)n_jobs), dim3(1024), 0, st, jobs, (const float *)nullptr, (int64_t)0,
+                       (float *)nullptr, (float *)nullptr);
     hipLaunchKernelGGL(weight_fragments_batch_kernel, dim3((unsigned)total_units), dim3(64), 0, st, jobs, n_jobs);
     return check_launch("u2mkd_weight_fragments_batch");
 }

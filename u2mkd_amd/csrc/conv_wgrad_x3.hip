@@ -19,6 +19,13 @@
 //   * ONE LDS image per workgroup (27 KB: 4 workgroups per CU) filled between two barriers, the gathered rows of the
 //     next two chunks in registers -- the other workgroups of the CU cover the fill.
 // Same plan, slabs and fixed-order reduction as the f32 kernel (deterministic); 64 x 64-channel tiles.
+//
+// (Tried and rejected, round 5: this kernel in the f16x2 arithmetic of conv_tp.hip / conv_px3.hip -- two fp16 planes, three
+// products.  The pairs are the reduction dimension, so a scale has to be common to a 32-pair chunk: row a_p scaled by its own
+// power of two, b_p by the inverse, then ONE scale per chunk from the largest |b'|, exchanged between the four waves through
+// LDS in front of the barrier that frees the image.  Half the matrix instructions, a third less LDS -- and 41 us instead of 36
+// at 64 x 64 on the 80k scene: the row maxima make every wave wait for its gathered rows BEFORE the multiply of the chunk in
+// the image instead of after it, which is exactly the latency the pipeline was built to hide.  bf16x3 stays.)
 #include <type_traits>
 
 #include "conv_internal.h"

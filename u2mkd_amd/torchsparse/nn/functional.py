@@ -501,11 +501,13 @@ class TileSchedule:
         ``epilogue`` = (scale [cout], shift [cout], residual [n, cout] or None, relu): a folded eval-mode BatchNorm
         (conv_eval_affine); only where ``supports_epilogue`` says so."""
         n_in, cin = feats.shape
+        # fp32 rows: f16x2 (arith 4) where the tile kernel has it, else the library default (bf16x3 / f32)
+        ar = 4 if feats.dtype == torch.float32 and _tiles_arith(cin, cout, self.k) == 4 else 0
         if epilogue is not None:
             sc, sh, res, relu = epilogue
-            wf = _weight_layout(weight, transpose, True)
+            wf = _weight_layout(weight, transpose, True, arith=ar)
             L.call('u2mkd_conv_forward_tiles_ep', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
-                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), 0, L.ptr(sc), L.ptr(sh),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), ar, L.ptr(sc), L.ptr(sh),
                    L.ptr(res), int(relu), L.ptr(out), L.stream())
             return out
         if feats.dtype == torch.bfloat16:        # bf16 storage: rows in and out bf16, one bf16 weight plane
@@ -514,9 +516,9 @@ class TileSchedule:
                    L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), L.ptr(out),
                    L.stream())
         elif L.load().u2mkd_conv_tiles_supported(cin, cout, self.k):
-            wf = _weight_layout(weight, transpose, True)
+            wf = _weight_layout(weight, transpose, True, arith=ar)
             L.call('u2mkd_conv_forward_tiles', L.ptr(feats), n_in, cin, L.ptr(wf), cout, L.ptr(self.nbr_s),
-                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), 0, L.ptr(out),
+                   L.ptr(self.order), L.ptr(self.items), L.ptr(self.n_items), self.n, self.k, int(kflip), ar, L.ptr(out),
                    L.stream())
         else:
             wt = _weight_layout(weight, transpose, False)
@@ -562,7 +564,8 @@ class PairSchedule:
     def run(self, feats, wt, cout, swap, out, variant=0, fragments=False, epilogue=None):
         """swap = False: out[j] = sum_k feats[in_k(j)] @ B_k  (rows of out = the map's outputs)
         swap = True:  out[i] = sum_k feats[out_k(i)] @ B_k (rows of out = the map's inputs);
-        B_k = wt[k] as [cout][cin], or (fragments) the arith-2 fragment layout of it for the bf16x3 kernel."""
+        B_k = wt[k] as [cout][cin], or (fragments) the arith-2 fragment layout of it for the bf16x3 kernel (fragments = 2: the
+        arith-4 layout, the same kernel in f16x2 arithmetic)."""
         n, cin = feats.shape
         st = L.stream()
         idx, pos, n_rows = (self.pair_out, self.pos_in, self.n_in) if swap else (self.pair_in, self.pos_out, self.n_out)
@@ -575,7 +578,7 @@ class PairSchedule:
             L.call('u2mkd_pairs_gather_sum_bf16', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
             return out
         if fragments:
-            L.call('u2mkd_conv_forward_pairs_x3', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
+            L.call('u2mkd_conv_forward_pairs_f16x2' if fragments == 2 else 'u2mkd_conv_forward_pairs_x3', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
                    L.ptr(self.meta), self.cap, self.k, L.ptr(y), st)
         else:
             L.call('u2mkd_conv_forward_pairs', L.ptr(feats), n, cin, L.ptr(wt), cout, L.ptr(idx), L.ptr(self.tile_k),
@@ -747,8 +750,9 @@ def _conv_os(feats, weight, transpose, cout, kmap, inverse, n_rows, kflip, epilo
         return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out)
     if feats.dtype != torch.bfloat16 and _pairs_mode(feats.shape[1], cout, n_rows):
         x3 = _PAIRS_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(feats.shape[1], cout))
-        wt = _weight_layout(weight, transpose, x3)
-        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=x3, epilogue=epilogue)
+        f2 = x3 and _pairs_f16x2(feats.shape[1], cout)          # the same kernel in f16x2 arithmetic (arith-4 fragments)
+        wt = _weight_layout(weight, transpose, x3, arith=4 if f2 else 0)
+        return kmap.pair_schedule().run(feats, wt, cout, bool(inverse) or bool(kflip), out, fragments=2 if f2 else x3, epilogue=epilogue)
     if inverse and kmap.nbr_inv is None:      # symmetric map: the inverse table is the mirrored forward table
         inverse, kflip = False, 1 - int(kflip)
     sch = kmap.schedule(inverse)
@@ -764,6 +768,30 @@ def conv_epilogue_supported(feats, cin, cout, k, n_rows):
     if _pairs_mode(cin, cout, n_rows):
         return True
     return bool(L.load().u2mkd_conv_tiles_supported(cin, cout, k)) and conv_arith_is_default()
+
+
+_TILES_ARITH = {}
+_PAIRS_F16X2 = {}
+
+
+def _pairs_f16x2(cin, cout):
+    """u2mkd_conv_pairs_f16x2_supported, cached: the pair-schedule / dense kernels run this shape in f16x2 arithmetic."""
+    key = (cin, cout)
+    hit = _PAIRS_F16X2.get(key)
+    if hit is None:
+        hit = _PAIRS_F16X2[key] = bool(L.load().u2mkd_conv_pairs_f16x2_supported(cin, cout))
+    return hit
+
+
+
+def _tiles_arith(cin, cout, k):
+    """u2mkd_conv_tiles_arith, cached: the arithmetic code the tile kernel runs a layer of fp32 rows in (4 = f16x2, 2 = bf16x3,
+    1 = f32, 0 = not a tile-kernel layer)."""
+    key = (cin, cout, k)
+    hit = _TILES_ARITH.get(key)
+    if hit is None:
+        hit = _TILES_ARITH[key] = int(L.load().u2mkd_conv_tiles_arith(cin, cout, k))
+    return hit
 
 
 def conv_arith_is_default():
@@ -846,9 +874,11 @@ _FRAG_TABLE = [None, 0]            # (device job table int64 [n, 8] or None = re
 
 
 def _register_fragments(weight, slot, both, k, r, c, arith):
-    planes = L.load().u2mkd_weight_fragments_bytes(1, 32, 32, arith) // (32 * 32 * 2)
-    if planes not in (1, 3):       # f32 fragments (U2MKD_CONV_ARITH=f32): per-weight launches only
+    planes = L.load().u2mkd_weight_fragments_bytes(1, 32, 32, arith) // (32 * 32 * 2)      # (f16x2: 2, + the scale trailer)
+    if planes not in (1, 2, 3):    # f32 fragments (U2MKD_CONV_ARITH=f32): per-weight launches only
         return
+    if planes == 2 and arith != 4:
+        return                     # (f32 fragments are 2 x 2 bytes per element too)
     _FRAG_JOBS[(id(weight), slot)] = [weakref.ref(weight), slot, both, k, r, c, planes, weight.data_ptr()]
     _FRAG_TABLE[0] = None
 
@@ -923,8 +953,8 @@ def _weight_layout(weight, transpose, fragments, arith=0):
             and weight.is_contiguous() and base.requires_grad == weight.requires_grad:
         holder, tag = base, ':%dx%dx%d' % (k, r, c)
     if fragments:
-        # arith 0 = the library's fp32-row arithmetic (bf16x3 / f32), 3 = ONE bf16 plane (bf16 storage)
-        slot = ('_u2mkd_wfrag3' if arith == 3 else '_u2mkd_wfrag') + tag
+        # arith 0 = the library's fp32-row arithmetic (bf16x3 / f32), 3 = ONE bf16 plane (bf16 storage), 4 = f16x2 (tile kernel)
+        slot = {3: '_u2mkd_wfrag3', 4: '_u2mkd_wfrag4'}.get(arith, '_u2mkd_wfrag') + tag
         hit = holder.__dict__.get(slot)
         if hit is None or hit[0] != stamp:
             nbytes = L.load().u2mkd_weight_fragments_bytes(k, r, c, arith)
@@ -992,10 +1022,11 @@ def _dense_x3(x, weight, forward, bias=None):
     n = x.shape[0]
     cout = weight.shape[0] if forward else weight.shape[1]
     b16 = x.dtype == torch.bfloat16
-    wf = _weight_layout(weight, not forward, True, arith=3 if b16 else 0)
+    f2 = not b16 and _pairs_f16x2(x.shape[1], cout)
+    wf = _weight_layout(weight, not forward, True, arith=3 if b16 else (4 if f2 else 0))
     y = torch.empty(n, cout, dtype=x.dtype, device=x.device)
-    L.call('u2mkd_linear_forward_bf16' if b16 else 'u2mkd_linear_forward_x3', L.ptr(x), n, x.shape[1], L.ptr(wf), cout,
-           L.ptr(bias), L.ptr(y), L.stream())
+    L.call('u2mkd_linear_forward_bf16' if b16 else ('u2mkd_linear_forward_f16x2' if f2 else 'u2mkd_linear_forward_x3'), L.ptr(x), n,
+           x.shape[1], L.ptr(wf), cout, L.ptr(bias), L.ptr(y), L.stream())
     return y
 
 
