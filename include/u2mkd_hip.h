@@ -564,6 +564,19 @@ int u2mkd_bn_backward_apply_res_bf16(const void *dy, const void *x, const void *
                                      const float *mean, const float *invstd, const float *gamma, const float *beta,
                                      int32_t relu, const float *sums, void *dx, void *dres, u2mkd_stream_t s);
 
+/* Two launches fewer per synchronising BatchNorm and pass (113 such layers per KD step at N > 1):
+ * u2mkd_bn_merge_stats_counted = u2mkd_bn_merge_stats + nn.BatchNorm's `num_batches_tracked += 1` (int64 device scalar, may be
+ * NULL) in the same launch (torch.nn.SyncBatchNorm bumps it with an add_ of its own, torch/nn/modules/batchnorm.py);
+ * u2mkd_bn_backward_local_keep = u2mkd_bn_backward_local(_res)(_bf16) writing the local sums TWICE: `sums` [2c] goes into the
+ * all_reduce in place, `keep` [2c] stays this rank's (the parameter gradients, which DDP averages) -- replaces the copy
+ * between the two.  bf16_rows != 0: dy, x, res are bf16 rows; res may be NULL (no residual branch). */
+int u2mkd_bn_merge_stats_counted(const float *gathered /*[world,2c+1]*/, int32_t world, int32_t c, float eps, float momentum,
+                                 float *running_mean, float *running_var, float *mean, float *invstd, float *total,
+                                 int64_t *num_batches_tracked, u2mkd_stream_t s);
+int u2mkd_bn_backward_local_keep(const void *dy, const void *x, const void *res, int32_t bf16_rows, int64_t n, int32_t c,
+                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                 float *partial, float *sums /*[2c]*/, float *keep /*[2c]*/, u2mkd_stream_t s);
+
 /* The BatchNorm entries above on BF16 ROWS (BASELINE.json configs[4]; under autocast the reference's nn.BatchNorm1d takes
  * and returns half rows while its statistics stay fp32): x, res, y, dy, dx, dres are bf16 [n, c]; gamma, beta, running
  * statistics, mean, invstd, partial, dgamma, dbeta, stats and sums are fp32 exactly as above; every value is rounded to
@@ -758,6 +771,10 @@ int u2mkd_bn2d_apply(const float *x, const float *res, int64_t b, int32_t c, int
 int u2mkd_bn2d_backward_local(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
                               const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
                               void *workspace, float *sums /*[2c]*/, u2mkd_stream_t s);
+/* u2mkd_bn2d_backward_local with a second copy `keep` [2c] of the sums (as u2mkd_bn_backward_local_keep) */
+int u2mkd_bn2d_backward_local_keep(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                                   const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                   void *workspace, float *sums /*[2c]*/, float *keep /*[2c]*/, u2mkd_stream_t s);
 int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
                               const float *total_n /*[1] device*/, const float *mean, const float *invstd, const float *gamma,
                               const float *beta, int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx,

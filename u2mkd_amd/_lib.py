@@ -60,6 +60,7 @@ SIGNATURES = {
     'u2mkd_bn2d_local_stats': (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p]),
     'u2mkd_bn2d_apply': (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_bn2d_backward_local': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    'u2mkd_bn2d_backward_local_keep': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_bn2d_backward_apply': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_linear_forward_x3': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p]),
     'u2mkd_conv_pairs_f16x2_supported': (_i32, [_i32, _i32]),
@@ -93,6 +94,8 @@ SIGNATURES = {
     'u2mkd_bn_backward': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_local_stats': (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     'u2mkd_bn_merge_stats': (C.c_int, [_p, _i32, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_merge_stats_counted': (C.c_int, [_p, _i32, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_backward_local_keep': (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_bn_apply': (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_bn_backward_local': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_apply': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),

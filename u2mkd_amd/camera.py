@@ -234,19 +234,19 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
         ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=dev)
         stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
         L.call('u2mkd_bn2d_local_stats', L.ptr(x), b, c, hw, L.ptr(ws), L.ptr(stats), st)
-        gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
         note_collective('all_gather', stats)
         if world > 1:
+            gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
             _gather_rows(gathered, stats, group)
         else:
-            gathered.copy_(stats.view(1, -1))
-        mean = torch.empty(c, dtype=torch.float32, device=dev)
-        invstd = torch.empty_like(mean)
-        total = torch.empty(1, dtype=torch.float32, device=dev)
+            gathered = stats.view(1, -1)          # (a one-rank group: the row is its own gathering)
+        mit = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+        mean, invstd, total = mit[:c], mit[c:2 * c], mit[2 * c:]
         track = bn.running_mean is not None
-        L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(bn.eps), float(bn.momentum if track else 0.0),
+        # (the step counter is bumped inside the merge launch)
+        L.call('u2mkd_bn_merge_stats_counted', L.ptr(gathered), world, c, float(bn.eps), float(bn.momentum if track else 0.0),
                L.ptr(bn.running_mean if track else None), L.ptr(bn.running_var if track else None), L.ptr(mean),
-               L.ptr(invstd), L.ptr(total), L.stream())
+               L.ptr(invstd), L.ptr(total), L.ptr(bn.num_batches_tracked if track else None), L.stream())
         y = torch.empty_like(x)
         L.call('u2mkd_bn2d_apply', L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd), L.ptr(weight), L.ptr(bias),
                int(relu), L.ptr(y), L.stream())
@@ -264,10 +264,10 @@ class _SyncBatchNorm2dFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dev = x.device
         ws = torch.empty(max(L.load().u2mkd_bn2d_workspace_bytes(b, c, hw), 16), dtype=torch.uint8, device=dev)
-        sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        L.call('u2mkd_bn2d_backward_local', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd),
-               L.ptr(weight), L.ptr(bias), int(ctx.relu), L.ptr(ws), L.ptr(sums), L.stream())
-        local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        both = torch.empty(2, 2 * c, dtype=torch.float32, device=dev)
+        sums, local = both[0], both[1]            # `sums` into the all_reduce in place; `local` = this rank's parameter gradients (DDP averages them)
+        L.call('u2mkd_bn2d_backward_local_keep', L.ptr(dy), L.ptr(x), L.ptr(res), b, c, hw, L.ptr(mean), L.ptr(invstd),
+               L.ptr(weight), L.ptr(bias), int(ctx.relu), L.ptr(ws), L.ptr(sums), L.ptr(local), L.stream())
         note_collective('all_reduce', sums)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
@@ -292,8 +292,6 @@ class SyncBatchNorm2d(nn.SyncBatchNorm):
                 and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape))):
             if residual is not None:
                 residual = residual.contiguous()
-            if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
             return _SyncBatchNorm2dFunction.apply(x, self.weight, self.bias, residual, self, relu, sync[0], sync[1])
         if (sync is None and _HIP_BN2D and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
                 and x.numel() > 0 and not torch.is_autocast_enabled() and (self.momentum is not None or not self.training)

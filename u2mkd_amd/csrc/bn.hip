@@ -284,7 +284,7 @@ bn_bwd_partial_kernel(const T *__restrict__ dy, const T *__restrict__ x, int64_t
 
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, float *__restrict__ dbeta,
-                       float *__restrict__ dgamma) {
+                       float *__restrict__ dgamma, float *__restrict__ keep = nullptr) {
     __shared__ float s_1[kBnFinLanes][kBnFinCh], s_2[kBnFinLanes][kBnFinCh];
     const int cl = threadIdx.x & (kBnFinCh - 1), g = threadIdx.x / kBnFinCh;
     const int ch = blockIdx.x * kBnFinCh + cl;
@@ -308,6 +308,7 @@ bn_bwd_finalize_kernel(const float *__restrict__ partial, int nslab, int c, floa
     for (int i = 1; i < kBnFinLanes; ++i) { s1 += s_1[i][cl]; s2 += s_2[i][cl]; }
     dbeta[ch] = s1;
     dgamma[ch] = s2;
+    if (keep) { keep[ch] = s1; keep[c + ch] = s2; }      // a second copy: the first one is summed over the ranks in place
 }
 
 template <typename T>
@@ -384,8 +385,9 @@ __global__ void bn_invstd_kernel(const float *__restrict__ var, int c, float eps
 __global__ void bn_sync_merge_kernel(const float *__restrict__ gathered, int world, int c, float eps, float momentum,
                                      float *__restrict__ running_mean, float *__restrict__ running_var,
                                      float *__restrict__ mean_out, float *__restrict__ invstd_out,
-                                     float *__restrict__ total_out) {
+                                     float *__restrict__ total_out, int64_t *__restrict__ num_batches_tracked = nullptr) {
     int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (num_batches_tracked && ch == 0) *num_batches_tracked += 1;      // nn.BatchNorm's step counter (no launch of its own)
     if (ch >= c) return;
     const int row = 2 * c + 1;
     float na = 0.f, mean = 0.f, m2 = 0.f;
@@ -508,12 +510,13 @@ static int bn_apply_impl(const T *x, int64_t n, int32_t c, const float *mean, co
 template <typename T>
 static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c, const float *mean, const float *invstd,
                                   const float *gamma, const float *beta, int32_t relu, float *partial, float *sums,
-                                  u2mkd_stream_t s, const T *res = nullptr) {
+                                  u2mkd_stream_t s, const T *res = nullptr, float *keep = nullptr) {
     U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_backward_local: c=%d must be a multiple of 4 in 4..1024", c);
     U2_REQUIRE(sums, "u2mkd_bn_backward_local: null pointer");
     hipStream_t st = as_stream(s);
     if (n == 0) {
         (void)hipMemsetAsync(sums, 0, (size_t)2 * c * sizeof(float), st);
+        if (keep) (void)hipMemsetAsync(keep, 0, (size_t)2 * c * sizeof(float), st);
         return check_launch("u2mkd_bn_backward_local");
     }
     U2_REQUIRE(dy && x && mean && invstd && partial, "u2mkd_bn_backward_local: null pointer");
@@ -521,7 +524,7 @@ static int bn_backward_local_impl(const T *dy, const T *x, int64_t n, int32_t c,
     hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 2), st, dy, x, n, c, mean,
                        invstd, gamma, beta, relu, partial, res);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, c,
-                       sums, sums + c);
+                       sums, sums + c, keep);
     return check_launch("u2mkd_bn_backward_local");
 }
 
@@ -615,6 +618,16 @@ int u2mkd_bn_merge_stats(const float *gathered /*[world,2c+1]*/, int32_t world, 
     return check_launch("u2mkd_bn_merge_stats");
 }
 
+/* the same merge, and num_batches_tracked += 1 (may be NULL) in the same launch */
+int u2mkd_bn_merge_stats_counted(const float *gathered, int32_t world, int32_t c, float eps, float momentum,
+                                 float *running_mean, float *running_var, float *mean, float *invstd, float *total,
+                                 int64_t *num_batches_tracked, u2mkd_stream_t s) {
+    U2_REQUIRE(gathered && mean && invstd && total && world > 0 && c > 0, "u2mkd_bn_merge_stats_counted: bad arguments");
+    hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((unsigned)ceil_div(c, 64)), dim3(64), 0, as_stream(s), gathered, world, c,
+                       eps, momentum, running_mean, running_var, mean, invstd, total, num_batches_tracked);
+    return check_launch("u2mkd_bn_merge_stats_counted");
+}
+
 int u2mkd_bn_apply(const float *x, int64_t n, int32_t c, const float *mean, const float *invstd, const float *gamma,
                    const float *beta, int32_t relu, float *y, u2mkd_stream_t s) {
     return bn_apply_impl<float>(x, n, c, mean, invstd, gamma, beta, relu, y, s);
@@ -704,6 +717,19 @@ int u2mkd_bn_backward_local_res_bf16(const void *dy, const void *x, const void *
                                      const float *invstd, const float *gamma, const float *beta, int32_t relu, float *partial,
                                      float *sums, u2mkd_stream_t s) {
     return bn_backward_local_impl<bf16row>(BF(dy), BF(x), n, c, mean, invstd, gamma, beta, relu, partial, sums, s, BF(res));
+}
+
+/* u2mkd_bn_backward_local(_res)(_bf16) with a SECOND copy of the sums: `sums` goes into the all_reduce (in place), `keep` [2c]
+ * stays this rank's (the parameter gradients, which DDP averages) -- the copy kernel in between is gone.  bf16_rows != 0: dy, x,
+ * res are bf16 rows; res may be NULL. */
+int u2mkd_bn_backward_local_keep(const void *dy, const void *x, const void *res, int32_t bf16_rows, int64_t n, int32_t c,
+                                 const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                 float *partial, float *sums, float *keep, u2mkd_stream_t s) {
+    U2_REQUIRE(keep, "u2mkd_bn_backward_local_keep: null pointer");
+    if (bf16_rows)
+        return bn_backward_local_impl<bf16row>(BF(dy), BF(x), n, c, mean, invstd, gamma, beta, relu, partial, sums, s, BF(res), keep);
+    return bn_backward_local_impl<float>(reinterpret_cast<const float *>(dy), reinterpret_cast<const float *>(x), n, c, mean, invstd,
+                                         gamma, beta, relu, partial, sums, s, reinterpret_cast<const float *>(res), keep);
 }
 
 int u2mkd_bn_backward_apply_res_bf16(const void *dy, const void *x, const void *res, int64_t n, int32_t c, const float *total_n,

@@ -181,7 +181,8 @@ bn2d_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ 
 }
 
 __global__ void __launch_bounds__(64)
-bn2d_bwd_finalize_kernel(const float *__restrict__ partial, int np, float *__restrict__ dbeta, float *__restrict__ dgamma) {
+bn2d_bwd_finalize_kernel(const float *__restrict__ partial, int np, float *__restrict__ dbeta, float *__restrict__ dgamma,
+                         float *__restrict__ keep = nullptr) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
     for (int i = lane; i < np; i += 64) {
@@ -193,7 +194,10 @@ bn2d_bwd_finalize_kernel(const float *__restrict__ partial, int np, float *__res
         s1 += __shfl_down(s1, off, 64);
         s2 += __shfl_down(s2, off, 64);
     }
-    if (lane == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    if (lane == 0) {
+        dbeta[c] = s1; dgamma[c] = s2;
+        if (keep) { keep[c] = s1; keep[gridDim.x + c] = s2; }      // (grid = the channels)
+    }
 }
 
 // grid (asplits * B, C); training: dx = gamma * invstd * (dy' - dbeta / n - xhat * dgamma / n); evaluation (dbeta
@@ -338,6 +342,21 @@ int u2mkd_bn2d_backward_local(const float *dy, const float *x, const float *res,
     hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), partial, (int)(splits * b), sums,
                        sums + c);
     return check_launch("u2mkd_bn2d_backward_local");
+}
+
+/* the same with a second copy `keep` [2c] of the sums (u2mkd_bn_backward_local_keep) */
+int u2mkd_bn2d_backward_local_keep(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,
+                                   const float *mean, const float *invstd, const float *gamma, const float *beta, int32_t relu,
+                                   void *workspace, float *sums, float *keep, u2mkd_stream_t s) {
+    U2_REQUIRE(dy && x && mean && invstd && workspace && sums && keep, "u2mkd_bn2d_backward_local_keep: null pointer");
+    U2_REQUIRE(b2_shape_ok(b, c, hw), "u2mkd_bn2d_backward_local_keep: shape [%lld, %d, %lld] out of range", (long long)b, c, (long long)hw);
+    const int splits = b2_splits((int)hw, kB2Chunk);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(bn2d_bwd_partial_kernel, dim3((unsigned)(splits * b), (unsigned)c), dim3(kB2Threads), 0, as_stream(s), dy, x,
+                       res, c, (int)hw, splits, mean, invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), partial, (int)(splits * b), sums,
+                       sums + c, keep);
+    return check_launch("u2mkd_bn2d_backward_local_keep");
 }
 
 int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res, int64_t b, int32_t c, int64_t hw,

@@ -1415,7 +1415,7 @@ class SyncBatchNormFunction(Function):
     stats / gather / elemt / ReLU kernels."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world, res=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group, world, res=None, counter=None):
         import torch.distributed as dist
         L.require_cuda(x)
         b16 = bf16_rows() or (x.dtype == torch.bfloat16 and _BF16_ROWS)
@@ -1432,17 +1432,17 @@ class SyncBatchNormFunction(Function):
         partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
         stats = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
         L.call('u2mkd_bn_local_stats' + sfx, L.ptr(x), n, c, L.ptr(partial), L.ptr(stats), st)
-        gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
         note_collective('all_gather', stats)
         if world > 1:
+            gathered = torch.empty(world, 2 * c + 1, dtype=torch.float32, device=dev)
             _gather_rows(gathered, stats, group)
         else:
-            gathered.copy_(stats.view(1, -1))
-        mean = torch.empty(c, dtype=torch.float32, device=dev)
-        invstd = torch.empty(c, dtype=torch.float32, device=dev)
-        total = torch.empty(1, dtype=torch.float32, device=dev)
-        L.call('u2mkd_bn_merge_stats', L.ptr(gathered), world, c, float(eps), float(momentum), L.ptr(running_mean),
-               L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.ptr(total), L.stream())
+            gathered = stats.view(1, -1)          # (a one-rank group: the row is its own gathering)
+        # mean | invstd | total in one allocation; the step counter is bumped inside the merge launch
+        mit = torch.empty(2 * c + 1, dtype=torch.float32, device=dev)
+        mean, invstd, total = mit[:c], mit[c:2 * c], mit[2 * c:]
+        L.call('u2mkd_bn_merge_stats_counted', L.ptr(gathered), world, c, float(eps), float(momentum), L.ptr(running_mean),
+               L.ptr(running_var), L.ptr(mean), L.ptr(invstd), L.ptr(total), L.ptr(counter), L.stream())
         y = torch.empty_like(x)
         if res is None:
             L.call('u2mkd_bn_apply' + sfx, L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma), L.ptr(beta), int(relu),
@@ -1465,14 +1465,12 @@ class SyncBatchNormFunction(Function):
         dev = x.device
         slabs = L.load().u2mkd_bn_num_slabs(n)
         partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
-        sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        if res is None:
-            L.call('u2mkd_bn_backward_local' + sfx, L.ptr(dy), L.ptr(x), n, c, L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                   L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
-        else:
-            L.call('u2mkd_bn_backward_local_res' + sfx, L.ptr(dy), L.ptr(x), L.ptr(res), n, c, L.ptr(mean), L.ptr(invstd),
-                   L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.stream())
-        local = sums.clone()                      # parameter gradients stay per-rank (DDP averages them)
+        # the local sums twice: `sums` goes into the all_reduce in place, `local` stays this rank's (the parameter gradients:
+        # DDP averages them)
+        both = torch.empty(2, 2 * c, dtype=torch.float32, device=dev)
+        sums, local = both[0], both[1]
+        L.call('u2mkd_bn_backward_local_keep', L.ptr(dy), L.ptr(x), L.ptr(res), int(b16), n, c, L.ptr(mean), L.ptr(invstd),
+               L.ptr(gamma), L.ptr(beta), int(ctx.relu), L.ptr(partial), L.ptr(sums), L.ptr(local), L.stream())
         note_collective('all_reduce', sums)
         if ctx.world > 1:
             _sum_over_ranks(sums, ctx.group)
@@ -1490,7 +1488,7 @@ class SyncBatchNormFunction(Function):
         if dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
         return (dx, local[c:] if gamma is not None else None, local[:c] if beta is not None else None,
-                None, None, None, None, None, None, None, dres)
+                None, None, None, None, None, None, None, dres, None)
 
 
 def _sync_group(bn):
@@ -1519,9 +1517,9 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
     sync = _sync_group(bn) if training else None
     counter = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        # the step counter is bumped inside the statistics kernel (no launch of its own) unless its value is
-        # needed on the host (momentum=None: cumulative average) or the synchronising path runs
-        if bn.momentum is None or sync is not None or x.shape[0] < 2 or not bn.num_batches_tracked.is_cuda:
+        # the step counter is bumped inside the statistics / merge kernel (no launch of its own) unless its value is
+        # needed on the host (momentum=None: cumulative average)
+        if bn.momentum is None or x.shape[0] < 2 or not bn.num_batches_tracked.is_cuda:
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 factor = 1.0 / float(bn.num_batches_tracked)
@@ -1532,7 +1530,7 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
     if residual is not None and not relu:
         raise ValueError('batch_norm: a residual input is fused together with the ReLU only')
     if sync is not None:
-        return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1], residual)
+        return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1], residual, counter)
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
     return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual)
