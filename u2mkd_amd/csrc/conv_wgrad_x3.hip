@@ -23,9 +23,13 @@
 // (Tried and rejected, round 5: this kernel in the f16x2 arithmetic of conv_tp.hip / conv_px3.hip -- two fp16 planes, three
 // products.  The pairs are the reduction dimension, so a scale has to be common to a 32-pair chunk: row a_p scaled by its own
 // power of two, b_p by the inverse, then ONE scale per chunk from the largest |b'|, exchanged between the four waves through
-// LDS in front of the barrier that frees the image.  Half the matrix instructions, a third less LDS -- and 41 us instead of 36
-// at 64 x 64 on the 80k scene: the row maxima make every wave wait for its gathered rows BEFORE the multiply of the chunk in
-// the image instead of after it, which is exactly the latency the pipeline was built to hide.  bf16x3 stays.)
+// LDS in front of the barrier that frees the image.  Half the matrix instructions, a third less LDS -- and SLOWER, with the
+// row maxima before the multiply of the chunk in the image (every wave waits for its gathered rows at the point the pipeline
+// was built to hide: 41 against 36 us at 64 x 64 on the 80k scene) and with them between that multiply and the barrier (same
+// box, standalone: 43.2 against 38.9 us; 128 x 256 on a 12k scene 42.7 against 38.6; only 128 x 128 gains, 110 against 114):
+// the chain per chunk is barrier - transposing reads - products - barrier - split - barrier, and the maxima lengthen the part
+// of it that no other workgroup's products cover.  Accuracy against float64 was no better either (largest error / sum |x||g|
+// on rows of 1e-10..1e10: 2^-18.3 against bf16x3's 2^-20.1 at 128 x 256).  bf16x3 stays.)
 #include <type_traits>
 
 #include "conv_internal.h"
