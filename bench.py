@@ -364,9 +364,12 @@ def roofline_wide_leg(coords_dev, iters=60):
             'ms': dict({k: round(v, 4) for k, v in t.items()}, total=round(total, 4)),
             'TFLOPs': {'fwd': round(tf(flops / 3, t['fwd']), 1), 'dgrad': round(tf(flops / 3, t['dgrad']), 1),
                        'wgrad': round(tf(flops / 3, t['wgrad']), 1)},
-            'peak_note': 'bf16 dense peak 2 500 TFLOP/s / 6 bf16 products per fp32 product (bf16x3).  The products are issued as '
-                         'v_mfma_f32_16x16x16_bf16 (the gfx942 form, 0.72 x the rate of v_mfma_f32_16x16x32_bf16 measured in a '
-                         'dependent chain) because the gfx950 form corrupts other streams\' kernels: DESIGN.md section 4, NOTES N9'}
+            'arithmetic': ('forward / input gradient: f16x2 (3 partial products per fp32 product on v_mfma_f32_16x16x16_f16); '
+                           if f2 else 'forward / input gradient: bf16x3; ') + 'weight gradient: bf16x3 (6 on v_mfma_f32_16x16x16_bf16)',
+            'peak_note': '16-bit dense peak 2 500 TFLOP/s / 6 = the price of an fp32 product in bf16x3 (kept as the yardstick of the row; '
+                         'f16x2 issues 3 per product, so the forward / input-gradient passes could reach twice it).  The products are '
+                         'issued on the gfx942 instruction forms (0.72 x the rate of v_mfma_f32_16x16x32_bf16 measured in a dependent '
+                         'chain) because the gfx950 forms corrupt other streams\' kernels: DESIGN.md section 4, NOTES N9'}
 
 
 # ------------------------------------------------------------------------------ CPU baseline
