@@ -45,9 +45,11 @@ N_VOX = 80000
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = 'LiDAR points/sec/node fwd+bwd (teacher+student+KD), 1/2/4/8 MI355X'
 # the arithmetic type the path computes in: fp32 storage everywhere; the sparse-conv / Linear products are fp32
-# products EMULATED on the bf16 matrix pipe (exact 3-way bf16 split, 6 partial products, fp32 accumulate: fp32 GEMM
-# accuracy, 1e-4 vs the fp32 oracle); --dtype bf16 = autocast (bf16 rows between the sparse operators, bf16 MIOpen)
-DTYPE_LABEL = {'f32': 'f32 (bf16x3 MFMA emulation of the fp32 products, fp32 accumulate)',
+# products EMULATED on the 16-bit matrix pipe -- forward / input gradient f16x2 (two scaled fp16 planes per operand, 3
+# partial products), weight gradient bf16x3 (exact 3-way bf16 split, 6 partial products) -- with fp32 accumulation: fp32
+# GEMM accuracy, <= 2^-20 sum|x||w| vs float64 (tests/test_gpu_conv_f16x2.py), 1e-4 vs the fp32 oracle on the operators;
+# --dtype bf16 = autocast (bf16 rows between the sparse operators, bf16 MIOpen)
+DTYPE_LABEL = {'f32': 'f32 (fp32 products emulated on the 16-bit matrix pipe: f16x2 forward / input gradient, bf16x3 weight gradient; fp32 accumulate)',
                'bf16': 'bf16 autocast (bf16 rows and MFMA products, fp32 accumulate / statistics / master weights)'}
 
 

@@ -187,3 +187,49 @@ def test_a_backward_pass_that_raises_does_not_disarm_the_next_one(hip):
         loss(False).backward()
     torch.cuda.synchronize()
     assert torch.equal(got[0], c1.kernel.grad) and torch.equal(got[1], c2.kernel.grad)
+
+
+def test_linear_bias_gradient_rides_the_side_stream_with_the_weight_gradient(hip):
+    """nn.Linear's bias gradient (a column sum of dY, or the exact zero of a bias that feeds a train-mode BatchNorm) is issued
+    behind the weight gradient on the side stream and joined with it at the end of the backward: same values as torch's, also on
+    a second pass that accumulates into existing .grad (computed in line then) and for a bias used by two layers."""
+    from u2mkd_amd import deferred
+    from u2mkd_amd.torchsparse.nn import functional as F
+    torch.manual_seed(4)
+    n, cin, cout = 20000, 64, 96
+    x = torch.randn(n, cin, device='cuda')
+    w = torch.nn.Parameter(torch.randn(cout, cin, device='cuda') * 0.1)
+    b = torch.nn.Parameter(torch.randn(cout, device='cuda'))
+    g = torch.randn(n, cout, device='cuda')
+    launched = []
+    real_sum = torch.sum
+
+    def spy(*a, **k):
+        launched.append(torch.cuda.current_stream().cuda_stream)
+        return real_sum(*a, **k)
+    main = torch.cuda.current_stream().cuda_stream
+    torch.sum = spy
+    try:
+        with deferred.scope():
+            y = F.linear(x, w, b)
+            y.backward(g)
+    finally:
+        torch.sum = real_sum
+    torch.cuda.synchronize()
+    assert launched and all(s != main for s in launched), 'the column sum ran on the backward\'s own stream'
+    want_b = g.double().sum(0)
+    assert float((b.grad.double() - want_b).abs().max()) <= 1e-4 * float(want_b.abs().max())
+    want_w = g.double().t() @ x.double()
+    assert float((w.grad.double() - want_w).abs().max()) <= 1e-4 * float(want_w.abs().max())
+    # second pass: .grad exists -> autograd accumulates when the function returns -> both gradients in line, sums doubled
+    with deferred.scope():
+        F.linear(x, w, b).backward(g)
+    torch.cuda.synchronize()
+    assert float((b.grad.double() - 2 * want_b).abs().max()) <= 2e-4 * float(want_b.abs().max())
+    # the exact zero of a bias in front of a train-mode BatchNorm
+    b2 = torch.nn.Parameter(torch.randn(cout, device='cuda'))
+    w.grad = None
+    with deferred.scope():
+        F.linear(x, w, b2, bias_feeds_batchnorm=True).backward(g)
+    torch.cuda.synchronize()
+    assert b2.grad is not None and float(b2.grad.abs().max()) == 0.0

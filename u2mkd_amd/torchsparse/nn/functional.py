@@ -1050,6 +1050,8 @@ class LinearFunction(Function):
         weight = weight.contiguous().float()
         # the saved weight IS the parameter (no contiguous / cast copy): its gradient goes to AccumulateGrad untouched
         ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
+        # the bias IS a leaf parameter (not a padded / cast copy): its gradient, too, is read by nobody before the backward ends
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf and bias.requires_grad and bias.dtype == torch.float32) else None
         ctx.overlap_ok = _deferred_overlap_ok()
         want16 = bf16_rows()
         b16 = want16 and _conv_bf16_ok(weight.shape[1], weight.shape[0])
@@ -1102,7 +1104,18 @@ class LinearFunction(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # a bias that feeds a train-mode BatchNorm has the gradient sum(dY) = 0 identically (BatchNorm's input gradient
             # sums to zero over the batch: sum(x_hat) = 0); the reduction over [N, C] would compute rounding noise
-            gb = weight.new_zeros(cout) if ctx.bias_grad_is_zero else g.sum(0, dtype=torch.float32)
+            if _DEFER_BIAS_GRAD and deferred_join and side is not None and ctx.bias_param is not None and ctx.bias_param.grad is None:
+                # behind the weight gradient on its side stream, joined with it when the backward ends: the column sum (or the
+                # fill) leaves the backward's chain (29 reductions + 20 fills per KD step)
+                gb = torch.empty(cout, dtype=torch.float32, device=g.device)
+                gb.record_stream(side)
+                with torch.cuda.stream(side):
+                    if ctx.bias_grad_is_zero:
+                        gb.zero_()
+                    else:
+                        torch.sum(g, 0, dtype=torch.float32, out=gb)
+            else:
+                gb = weight.new_zeros(cout) if ctx.bias_grad_is_zero else g.sum(0, dtype=torch.float32)
         if gx is not None and gx.dtype != ctx.in_dtype:
             gx = gx.to(ctx.in_dtype)
         return gx, gw, gb, None
@@ -1129,6 +1142,7 @@ def linear(x, weight, bias=None, bias_feeds_batchnorm=False):
 
 
 _OVERLAP_WGRAD = os.environ.get('U2MKD_OVERLAP_WGRAD', '1') != '0'
+_DEFER_BIAS_GRAD = os.environ.get('U2MKD_DEFER_BIAS_GRAD', '1') != '0'      # nn.Linear's bias gradient behind its weight gradient on the side stream
 
 
 def _side_stream(device):
