@@ -672,6 +672,13 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
                                           void *workspace, size_t workspace_bytes, float *dq, float *dk, float *dv,
                                           int64_t ld_grad, float *dtq, float *dtk, float *dtv, u2mkd_stream_t s);
 
+/* dtq = dtk = dtv = NULL in the two backward entries: the slab sum (their last launch) is left to the caller --
+ * u2mkd_sptr_table_reduce(workspace, the same n, h, L, split_a, ...) on any stream ordered behind the backward call.  The
+ * relative-position tables are leaf parameters (spherical_transformer.py:126-134): the host side queues the sum on its
+ * weight-gradient side stream and joins it at the end of the backward (u2mkd_amd/sptr/functional.py). */
+int u2mkd_sptr_table_reduce(const void *workspace, int64_t n, int32_t h, int32_t L, float split_a, float *dtq, float *dtk,
+                            float *dtv, u2mkd_stream_t s);
+
 /* ---- the `sptr_cuda` extension, function for function (csrc/sptr_ops.hip) ----------------------------------------
  * The ten functions third_party/SparseTransformer/src/sptr/pointops_api.cpp:9-20 exports, for a caller that keeps
  * sptr's Python layer (sptr/functional.py) and its M = sum_w L_w^2 pair arrays: u2mkd_sptr_<name> replaces

@@ -233,3 +233,52 @@ def test_linear_bias_gradient_rides_the_side_stream_with_the_weight_gradient(hip
         F.linear(x, w, b2, bias_feeds_batchnorm=True).backward(g)
     torch.cuda.synchronize()
     assert b2.grad is not None and float(b2.grad.abs().max()) == 0.0
+
+
+def _spformer_grads(defer_tables, steps=2):
+    from u2mkd_amd import lidar, torchsparse as ts
+    from u2mkd_amd.losses import MixLovaszCrossEntropy
+    from u2mkd_amd.synth import synth_batch
+    import u2mkd_amd.sptr.functional as SF
+    old = SF._DEFER_TABLES
+    SF._DEFER_TABLES = defer_tables
+    launched = []
+    real = SF.L.call
+
+    def spy(name, *a):
+        if name == 'u2mkd_sptr_table_reduce':
+            launched.append(a[-1] != torch.cuda.current_stream().cuda_stream)
+        return real(name, *a)
+    SF.L.call = spy
+    try:
+        torch.manual_seed(3)
+        model = lidar.SPVCNN_SPFORMER(**lidar.spformer_kwargs(cr=0.5, drop_path_rate=0.0)).cuda().train()
+        crit = MixLovaszCrossEntropy(ignore_index=0)
+        b = synth_batch(6000, 1, seed=5)
+        feats, coords, labels = (torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels'))
+        out = []
+        for _ in range(steps):          # the second pass accumulates into existing gradients: the sums run in line again
+            loss = crit(model({'lidar': ts.SparseTensor(feats, coords)})['x_vox'], labels)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        return out, launched
+    finally:
+        SF.L.call = real
+        SF._DEFER_TABLES = old
+
+
+def test_sptr_table_gradients_summed_on_the_side_stream_equal_the_inline_ones(hip):
+    """The relative-position tables are leaf parameters: the slab sum that finishes their gradients is queued on the
+    weight-gradient side stream (u2mkd_sptr_table_reduce) and joined at the end of the backward -- the same bits as the sum
+    inside u2mkd_sptr_attention_backward_strided, in the first pass (deferred) and in the second (in line: .grad exists)."""
+    a, launched = _spformer_grads(True)
+    b, none = _spformer_grads(False)
+    assert launched and all(launched), 'no table sum left the backward\'s stream'
+    assert not none
+    tables = [n for n in a[0] if 'table' in n]
+    assert len(tables) >= 6, sorted(a[0])[:20]
+    for step in range(2):
+        assert a[step].keys() == b[step].keys()
+        for n in a[step]:
+            assert torch.equal(a[step][n], b[step][n]), (step, n)

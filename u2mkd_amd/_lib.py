@@ -126,6 +126,7 @@ SIGNATURES = {
     'u2mkd_sptr_attention_forward_strided': (C.c_int, [_p, _p, _p, _i64, _f32] + [_p] * 8 + [_i32, _i32, _f32, _i64, _i32, _i32, _p, _i64, _p, _p]),
     'u2mkd_sptr_attention_backward_strided': (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _i64] + [_p] * 9 + [_i32, _i32, _f32, _i32, _i64, _i32, _i32]
                                               + [_p, _p, _sz] + [_p, _p, _p, _i64, _p, _p, _p, _p]),
+    'u2mkd_sptr_table_reduce': (C.c_int, [_p, _i64, _i32, _i32, _f32, _p, _p, _p, _p]),
     # the ten sptr_cuda functions, argument for argument (csrc/sptr_ops.hip)
     'u2mkd_sptr_precompute_all': (C.c_int, [_i32, _i32, C.c_uint32] + [_p] * 8),
     'u2mkd_sptr_attention_step1_forward': (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_uint32] + [_p] * 6),

@@ -509,8 +509,8 @@ __device__ __forceinline__ void hist_store_slab(float *slab, const int (&table_o
 // CU, S x shorter chains.
 // query role: dq_i, and the Tq / Tv table gradients
 template <int S>
-__global__ void __launch_bounds__(kSptrThreads)
-sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+__device__ __forceinline__ void
+sptr_bwd_query_body(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                       const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
                       const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
                       const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
@@ -639,8 +639,8 @@ sptr_bwd_query_kernel(const float *__restrict__ q, const float *__restrict__ k, 
 
 // key role: dk_j, dv_j and the Tk table gradient
 template <int S>
-__global__ void __launch_bounds__(kSptrThreads)
-sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+__device__ __forceinline__ void
+sptr_bwd_key_body(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                     const float *__restrict__ dout, const float *__restrict__ lse, const float *__restrict__ delta,
                     const int32_t *__restrict__ sort_idx, const int32_t *__restrict__ wstart,
                     const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,
@@ -761,6 +761,40 @@ sptr_bwd_key_kernel(const float *__restrict__ q, const float *__restrict__ k, co
     float *slab = slabs + (((size_t)blockIdx.x * 2 + wave) * h + hh) * 3 * L * 3 * kHd;
     hist_store_slab<NT>(slab, table_of, L, lane, acc);
 }
+
+#define U2_SPTR_BWD_IN                                                                                                   \
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ dout,  \
+        const float *__restrict__ lse, const float *__restrict__ delta, const int32_t *__restrict__ sort_idx,             \
+        const int32_t *__restrict__ wstart, const int32_t *__restrict__ wlen, const int32_t *__restrict__ qc,             \
+        const float *__restrict__ radial, const float *__restrict__ tq, const float *__restrict__ tk,                     \
+        const float *__restrict__ tv, int L, RelCtx rc, int64_t n, int h
+#define U2_SPTR_BWD_PASS q, k, v, dout, lse, delta, sort_idx, wstart, wlen, qc, radial, tq, tk, tv, L, rc, n, h
+
+template <int S>
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_bwd_query_kernel(U2_SPTR_BWD_IN, float *__restrict__ dq, float *__restrict__ slabs, SptrLayout ly) {
+    sptr_bwd_query_body<S>(U2_SPTR_BWD_PASS, dq, slabs, ly);
+}
+
+template <int S>
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_bwd_key_kernel(U2_SPTR_BWD_IN, float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ slabs, SptrLayout ly) {
+    sptr_bwd_key_body<S>(U2_SPTR_BWD_PASS, dk, dv, slabs, ly);
+}
+
+// Both roles in ONE launch, grid (G, heads, 2): blockIdx.z = 0 the query role, 1 the key role.  The two are independent (they
+// write different rows of the gradients and different tables of the same per-wave slab), and with S > 1 lanes per token
+// (the spherical branch at the coarse strides: 128 workgroups x heads of 2 waves, ~40 KB of LDS each) one role alone leaves
+// most of the chip idle: launched one behind the other they were the longest kernels of the student's backward chain.
+template <int S>
+__global__ void __launch_bounds__(kSptrThreads)
+sptr_bwd_both_kernel(U2_SPTR_BWD_IN, float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv,
+                     float *__restrict__ slabs, SptrLayout ly) {
+    if (blockIdx.z == 0) sptr_bwd_query_body<S>(U2_SPTR_BWD_PASS, dq, slabs, ly);
+    else sptr_bwd_key_body<S>(U2_SPTR_BWD_PASS, dk, dv, slabs, ly);
+}
+#undef U2_SPTR_BWD_IN
+#undef U2_SPTR_BWD_PASS
 
 // dt[tb][row][hh][d] = sum over the G slabs (ascending) -- deterministic
 __global__ void sptr_table_reduce_kernel(const float *__restrict__ slabs, int G, int L, int h, float *__restrict__ dtq,
@@ -918,8 +952,10 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
                                   int64_t ld_grad, float *dtq, float *dtk, float *dtv, u2mkd_stream_t s) {
     if (n == 0 || h == 0) return 0;
     U2_REQUIRE(q && k && v && out && dout && lse && sort_idx && wstart && wlen && qc && tq && tk && tv && delta &&
-                   workspace && dq && dk && dv && dtq && dtk && dtv,
+                   workspace && dq && dk && dv,
                "u2mkd_sptr_attention_backward: null pointer");
+    U2_REQUIRE((dtq && dtk && dtv) || (!dtq && !dtk && !dtv),
+               "u2mkd_sptr_attention_backward: the three table gradients go together (all NULL: the caller sums the slabs itself, u2mkd_sptr_table_reduce)");
     if (int rc = sptr_check("u2mkd_sptr_attention_backward", n, h, hdim, L, qgl, split_a)) return rc;
     U2_REQUIRE(workspace_bytes >= u2mkd_sptr_backward_workspace_bytes(n, h, L),
                "u2mkd_sptr_attention_backward: workspace too small");
@@ -956,15 +992,47 @@ int u2mkd_sptr_attention_backward_strided(const float *q, const float *k, const 
         hipLaunchKernelGGL(sptr_bwd_key_kernel<SS>, dim3(G, h), dim3(kSptrThreads), lds_k, st, q, k, v, dout, lse,       \
                            delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dk, dv, slabs, ly);          \
     } while (0)
-    if (S == 16) U2_SPTR_BWD(16);
+    // S > 1: both roles in one launch (see sptr_bwd_both_kernel); S = 1 (128 tokens' strips per workgroup: 137 + 95 KB of LDS, the
+    // grid already covers the chip) keeps the two launches.  U2MKD_SPTR_BWD_MERGE=0: two launches everywhere (A/B).
+    static const bool merge = [] { const char *e = getenv("U2MKD_SPTR_BWD_MERGE"); return !(e && e[0] == '0'); }();
+    const size_t lds_b = lds_q > lds_k ? lds_q : lds_k;
+#define U2_SPTR_BOTH(SS)                                                                                                 \
+    do {                                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sptr_bwd_both_kernel<SS>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                               \
+        hipLaunchKernelGGL(sptr_bwd_both_kernel<SS>, dim3(G, h, 2), dim3(kSptrThreads), lds_b, st, q, k, v, dout, lse,   \
+                           delta, sort_idx, wstart, wlen, qc, rad, tq, tk, tv, L, rc, n, h, dq, dk, dv, slabs, ly);      \
+    } while (0)
+    if (S > 1 && merge) {
+        if (S == 16) U2_SPTR_BOTH(16);
+        else if (S == 8) U2_SPTR_BOTH(8);
+        else if (S == 4) U2_SPTR_BOTH(4);
+        else U2_SPTR_BOTH(2);
+    } else if (S == 16) U2_SPTR_BWD(16);
     else if (S == 8) U2_SPTR_BWD(8);
     else if (S == 4) U2_SPTR_BWD(4);
     else if (S == 2) U2_SPTR_BWD(2);
     else U2_SPTR_BWD(1);
 #undef U2_SPTR_BWD
-    hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, 2 * G, L, h,
-                       dtq, dtk, dtv);
+#undef U2_SPTR_BOTH
+    if (dtq)
+        hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, st, slabs, 2 * G, L, h,
+                           dtq, dtk, dtv);
     return check_launch("u2mkd_sptr_attention_backward");
+}
+
+/* The last launch of the backward on its own: sums the per-wave slabs u2mkd_sptr_attention_backward(_strided) left in
+ * `workspace` when it was called with dtq = dtk = dtv = NULL (same n, h, L, split_a) -- on any stream ordered behind that call.
+ * The tables are leaf parameters: nobody reads their gradients before the backward ends. */
+int u2mkd_sptr_table_reduce(const void *workspace, int64_t n, int32_t h, int32_t L, float split_a, float *dtq, float *dtk,
+                            float *dtv, u2mkd_stream_t s) {
+    if (n == 0 || h == 0) return 0;
+    U2_REQUIRE(workspace && dtq && dtk && dtv && L > 0 && L <= 50, "u2mkd_sptr_table_reduce: bad arguments");
+    const int G = sptr_bwd_grid(n, sptr_split(n, split_a));
+    const int per = 3 * L * 3 * kHd;
+    hipLaunchKernelGGL(sptr_table_reduce_kernel, dim3((unsigned)ceil_div(per, 256), h), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const float *>(workspace), 2 * G, L, h, dtq, dtk, dtv);
+    return check_launch("u2mkd_sptr_table_reduce");
 }
 
 int u2mkd_sptr_attention_backward(const float *q, const float *k, const float *v, const float *out, const float *dout,

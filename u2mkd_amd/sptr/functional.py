@@ -3,6 +3,8 @@ csrc/sptr.hip (rows a10-a11 of SURVEY.md §8a)."""
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -176,7 +178,13 @@ class PackedAttentionFunction(Function):
         qkv = qkv.contiguous().float()
         n, three, H, d = qkv.shape
         assert three == 3 and d == 16 and len(tables) == 3 * len(branches)
+        given = tables
         tables = tuple(t.contiguous().float() for t in tables)
+        # tables that ARE leaf parameters (no contiguous / cast copy in between): nobody reads their gradients before the
+        # backward ends, so the slab sum that finishes them may leave the backward's chain (deferred.py)
+        ctx.table_leaves = tuple(g if (g is t and g.is_leaf and g.requires_grad) else None for g, t in zip(given, tables))
+        from .. import deferred
+        ctx.overlap_ok = deferred.overlap_ok()
         out = torch.empty(n, H, d, dtype=torch.float32, device=qkv.device)
         lses = []
         st = L.stream()
@@ -223,15 +231,44 @@ class PackedAttentionFunction(Function):
             delta = torch.empty(n, h, dtype=torch.float32, device=qkv.device)
             nbytes = L.load().u2mkd_sptr_backward_workspace_bytes(n, h, tl)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=qkv.device)
+            side = _table_side(ctx, ctx.table_leaves[3 * b:3 * b + 3], qkv.device)
+            late = side is not None
             L.call('u2mkd_sptr_attention_backward_strided', L.ptr(qkv[:, 0, h0:]), L.ptr(qkv[:, 1, h0:]), L.ptr(qkv[:, 2, h0:]),
                    3 * H * d, ctx.scale, L.ptr(out[:, h0:]), L.ptr(dout[:, h0 * d:]), H * d, L.ptr(lses[b]),
                    L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(br['qc']), L.ptr(br['radial']),
                    L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, int(br['qgl']), float(br['split_a']), int(br['span']), n, h, d,
                    L.ptr(delta), L.ptr(ws), nbytes, L.ptr(dqkv[:, 0, h0:]), L.ptr(dqkv[:, 1, h0:]), L.ptr(dqkv[:, 2, h0:]),
-                   3 * H * d, L.ptr(dtq), L.ptr(dtk), L.ptr(dtv), st)
+                   3 * H * d, L.ptr(None if late else dtq), L.ptr(None if late else dtk), L.ptr(None if late else dtv), st)
+            if late:       # the slab sum behind the kernels, on the weight-gradient side stream, joined when the backward ends
+                side.wait_stream(torch.cuda.current_stream(qkv.device))
+                for t in (ws, dtq, dtk, dtv):
+                    t.record_stream(side)
+                L.call('u2mkd_sptr_table_reduce', L.ptr(ws), n, h, tl, float(br['split_a']), L.ptr(dtq), L.ptr(dtk), L.ptr(dtv),
+                       side.cuda_stream)
         if n == 0:
             dqkv.zero_()
         return (dqkv, None, None, *grads)
+
+
+_DEFER_TABLES = os.environ.get('U2MKD_DEFER_SPTR_TABLES', '1') != '0'
+
+
+def _table_side(ctx, leaves, device):
+    """The side stream for a branch's table-gradient sum, or None: all three tables are leaf parameters without a gradient
+    yet, none of them has had a contribution in this backward pass (a shared table: autograd adds the second one as soon as
+    the function returns), a trainer that follows the protocol is active and the step may fork (deferred.py)."""
+    from .. import deferred
+    if not (_DEFER_TABLES and deferred.enabled() and getattr(ctx, 'overlap_ok', False) and deferred.overlap_ok()):
+        return None
+    if any(t is None or t.grad is not None for t in leaves):
+        return None
+    if any(deferred.owned(id(t)) for t in leaves):
+        deferred.join()
+        return None
+    side = deferred.side_for('sparse_wgrad', device, owner=id(leaves[0]))
+    for t in leaves[1:]:
+        deferred.OWNERS.add(id(t))
+    return side
 
 
 def packed_window_attention(qkv, scale, branches):
