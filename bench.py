@@ -631,7 +631,8 @@ def timed_run(step, warmup, steps, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    timed_run.in_order_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    per_step = sorted(timed_run.in_order_ms)
     timed_run.median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
     timed_run.min_max_ms = (per_step[0], per_step[-1])
     cc = D.collective_counts(getattr(getattr(step, 'runner', None), 'net', None))
@@ -660,6 +661,7 @@ def run_rank(args):
         return
     from u2mkd_amd import distributed as D
     D.configure_runtime()                      # (before the first HIP call: the hardware-queue count of a multi-rank process)
+    from u2mkd_amd.train import _staged_geometry as T_staged
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     rank, world, local_rank = D.init_from_env('nccl')
@@ -680,6 +682,7 @@ def run_rank(args):
             # (ms_per_step / value: the contract's wall clock over the K steps; median / min / max: the K intervals between
             # consecutive end-of-step events on the GPU -- SURVEY 8d asks for the median)
             'ms_per_step_median': round(timed_run.median_ms, 3), 'ms_per_step_min_max': [round(v, 3) for v in timed_run.min_max_ms],
+            'ms_per_step_in_order': [round(v, 1) for v in timed_run.in_order_ms],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': DTYPE_LABEL[args.dtype], 'data': 'synthetic',
             'config': {'workload': desc, 'points_per_gpu': n_pts, 'batch_per_gpu': 1, 'parallelism': 'dp%d' % world,
@@ -692,7 +695,11 @@ def run_rank(args):
                        'final_loss': round(loss, 5),
                        # the frozen teacher is a pure function of the batch: steps (warm-up + timed) whose teacher logits differ in
                        # any bit from the first step that ran the same resident batch (train.TeacherWatch; NOTES N9)
-                       'teacher_deviating_steps': teacher_bad, 'teacher_steps_compared': teacher_compared},
+                       'teacher_deviating_steps': teacher_bad, 'teacher_steps_compared': teacher_compared,
+                       # how the process was set up (distributed.configure_runtime / train._staged_geometry): a single-rank process
+                       # keeps the runtime's 4 hardware queues and queues the next batch's geometry in slices between the phases of
+                       # the step; a rank of several runs 8 queues and the geometry in one piece behind the backward
+                       'hardware_queues': D.hardware_queues(), 'next_batch_geometry': 'slices' if T_staged() else 'one piece'},
             # what the N > 1 path actually ran on: the process group the gradient buckets and the BatchNorm statistics were
             # reduced over, and the spread of the ranks' own clocks over the same timed region
             'distributed': {'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),

@@ -23,14 +23,23 @@ def test_deferred_joins_are_off_until_a_trainer_enables_them():
 
 def test_hardware_queue_setting_is_the_launchers_not_the_imports():
     """importing the package leaves the environment alone; distributed.configure_runtime() (called by bench.py /
-    run_training.py before their first GPU call) sets GPU_MAX_HW_QUEUES=8 unless the user exported a value."""
-    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
-    r = subprocess.run([sys.executable, '-c', 'import sys, os; sys.path.insert(0, %r); import u2mkd_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"));'
-                        'from u2mkd_amd import distributed as D; D.configure_runtime(); print(os.environ.get("GPU_MAX_HW_QUEUES"))' % ROOT],
-                       capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0 and r.stdout.split() == ['None', '8'], (r.stdout, r.stderr[-1000:])
-    r = _py('import os, u2mkd_amd\nfrom u2mkd_amd import distributed as D\nD.configure_runtime()\nprint(os.environ["GPU_MAX_HW_QUEUES"])', {'GPU_MAX_HW_QUEUES': '4'})
-    assert r.returncode == 0 and r.stdout.strip() == '4'
+    run_training.py before their first GPU call) sets GPU_MAX_HW_QUEUES=8 for a rank of a multi-rank job (WORLD_SIZE > 1 or
+    U2MKD_FORCE_DDP=1) unless the user exported a value, and leaves the runtime's default (4) to a single-rank process, whose
+    trainer then queues the next batch's geometry in slices (train._staged_geometry follows the same setting)."""
+    base = {k: v for k, v in os.environ.items() if k not in ('GPU_MAX_HW_QUEUES', 'WORLD_SIZE', 'U2MKD_FORCE_DDP', 'U2MKD_STAGED_GEOMETRY')}
+    code = ('import sys, os; sys.path.insert(0, %r); import u2mkd_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"));'
+            'from u2mkd_amd import distributed as D, train as T; D.configure_runtime(); print(os.environ.get("GPU_MAX_HW_QUEUES"), T._staged_geometry())' % ROOT)
+
+    def run(extra):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=dict(base, **extra))
+        assert r.returncode == 0, r.stderr[-1000:]
+        return r.stdout.split()
+    assert run({}) == ['None', 'None', 'True']
+    assert run({'WORLD_SIZE': '8'}) == ['None', '8', 'False']
+    assert run({'U2MKD_FORCE_DDP': '1'}) == ['None', '8', 'False']
+    assert run({'WORLD_SIZE': '8', 'GPU_MAX_HW_QUEUES': '4'}) == ['4', '4', 'True']
+    assert run({'GPU_MAX_HW_QUEUES': '8'}) == ['8', '8', 'False']
+    assert run({'U2MKD_STAGED_GEOMETRY': '0'}) == ['None', 'None', 'False']
 
 
 def test_schedule_choice_at_the_boundary():

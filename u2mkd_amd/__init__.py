@@ -8,7 +8,8 @@ There is no CPU / PyTorch fallback: operators raise on CPU tensors.
 __version__ = '0.1.0'
 
 # (Importing the package changes nothing in the process environment.  The launchers -- bench.py, run_training.py -- call
-# ``distributed.configure_runtime()`` before their first GPU call: 8 HIP hardware queues for the step's five streams.)
+# ``distributed.configure_runtime()`` before their first GPU call: 8 HIP hardware queues for a rank of a multi-rank job, the
+# runtime's 4 for a single-rank process.)
 
 
 def install_as_torchsparse():

@@ -16,7 +16,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'configure_runtime', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'collective_counts', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
+__all__ = ['init_from_env', 'configure_runtime', 'multi_rank_process', 'hardware_queues', 'world', 'rank', 'wrap_model', 'BucketedGradientAverage', 'collective_counts', 'max_over_ranks', 'min_over_ranks', 'scene_seed', 'shutdown']
 
 
 def init_from_env(backend: str | None = None):
@@ -43,27 +43,51 @@ def init_from_env(backend: str | None = None):
     return rnk, world_size, local
 
 
+def multi_rank_process() -> bool:
+    """True for a process that is (or is made to behave as) one rank of several: WORLD_SIZE > 1 in the launcher's environment,
+    an initialised group of more than one rank, or U2MKD_FORCE_DDP=1 (the N > 1 code path on one GPU)."""
+    if os.environ.get('U2MKD_FORCE_DDP') == '1':
+        return True
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size() > 1
+    try:
+        return int(os.environ.get('WORLD_SIZE', '1')) > 1
+    except ValueError:
+        return False
+
+
+def hardware_queues() -> int:
+    """HIP hardware queues of this process as far as the environment tells (the runtime's default is 4)."""
+    try:
+        return int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        return 4
+
+
 def configure_runtime(warn=True):
     """Process-level HIP settings; must run before the process's first HIP call (the launchers -- bench.py,
     run_training.py -- call it on their first line; nothing is changed at ``import u2mkd_amd``): the runtime reads the
     variable at its initialisation only, so a late call warns and changes nothing.
 
-    ``GPU_MAX_HW_QUEUES=8`` (the runtime's default is 4).  A training step keeps FIVE streams busy -- student LiDAR (main),
-    frozen teacher, camera branch, weight gradients, the next batch's geometry -- and with 4 hardware queues the fifth
-    shares a queue with another stream, in order: the geometry pre-pass, issued behind the backward, then started only when
-    the backward had drained, the host sat in its size reads until then and began every step with no lead over the GPU
-    (the student's first kernel reached an idle main stream 8 ms into the step).  With 5 / 6 / 8 queues the pre-pass runs
-    underneath the backward and the host stays a whole step ahead: 72.2 -> 71.6 / 69.9 / 70.4 ms (tools/host_lead.py).
-    A multi-rank process needs the room for a second reason: RCCL's communicator brings streams of its own (with 4 queues
-    +10.5 ms per KD step at ONE rank, tools/ddp_cost.py)."""
+    The number of HIP hardware queues, by the kind of process (round 5; same-box sweeps in NOTES N9.11):
+    * ONE rank (the default bench line): the runtime's default, 4, is left alone.  The step keeps five streams busy -- student
+      LiDAR (main), frozen teacher, camera branch, weight gradients, the next batch's geometry -- so one of them shares a
+      queue; since the geometry is queued in slices between the phases of the step (train.KDStep: its host reads find their
+      counts ready) that sharing costs nothing, while the slices on a queue of their own (5 / 6 / 8 queues) push the
+      hardware scheduler over a cliff: 64.2 ms at 4 queues against 105-106 ms at 5, 6 and 8.
+    * one rank OF SEVERAL (WORLD_SIZE > 1, or U2MKD_FORCE_DDP=1): ``GPU_MAX_HW_QUEUES=8`` and the geometry in one piece behind
+      the backward (train._staged_geometry reads the same setting): the gradient reducer's and RCCL's streams need the room
+      (N > 1 path at one rank: 70-73 ms at 8 queues, 76-77 ms at 4, with or without the slices)."""
     if 'GPU_MAX_HW_QUEUES' in os.environ:       # the user's choice wins
+        return
+    if not multi_rank_process():
         return
     if torch.cuda.is_initialized():
         if not warn:
             return
         import warnings
         warnings.warn('u2mkd_amd.distributed.configure_runtime() was called after the HIP runtime had been initialised: '
-                      'GPU_MAX_HW_QUEUES keeps the runtime\'s default (4) and the step\'s fifth stream shares a hardware queue '
+                      'GPU_MAX_HW_QUEUES keeps the runtime\'s default (4) and the streams of a multi-rank step share hardware queues '
                       '(a few percent of step time); call it before the first GPU call, or export GPU_MAX_HW_QUEUES=8',
                       RuntimeWarning, stacklevel=2)
         return

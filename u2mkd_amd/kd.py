@@ -21,7 +21,8 @@ from .fusion import Atten_Fusion_Conv, L2CFusion, c2l_gather, feature_fetch, l2c
 from .pixel_head import sampled_head_applies, sampled_pixel_logits
 from .lidar.blocks import (BasicConvolutionBlock, BasicDeconvolutionBlock, FusedSequential, PointBatchNorm1d, PointLinear,
                            ResidualBlock)
-from .lidar.point_voxel import initial_voxelize, point_to_voxel, prepare_geometry, prepare_geometry_many, voxel_to_point
+from .lidar.point_voxel import (initial_voxelize, point_to_voxel, prepare_geometry, prepare_geometry_many, prepare_geometry_staged,
+                                voxel_to_point)
 from .torchsparse.nn import functional as spf
 from .lidar.sphereformer import SphereFormer
 from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
@@ -337,6 +338,16 @@ class TSDFull(nn.Module):
         with torch.no_grad():
             g_s, g_t = prepare_geometry_many([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres),
                                               (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)])
+        in_mod['student']['_geometry'] = g_s
+        in_mod['teacher']['_geometry'] = g_t
+        return in_mod
+
+    def prepare_staged(self, in_mod: dict):
+        """``prepare`` as a generator that yields in front of each of its two host reads (point_voxel.prepare_geometry_staged):
+        train.KDStep resumes it between the phases of the CURRENT step, so the reads find their counts ready.  The caller sets
+        ``torch.no_grad()`` (and its stream / autocast contexts) around every ``next()``; returns ``in_mod``."""
+        g_s, g_t = yield from prepare_geometry_staged([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres),
+                                                       (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)])
         in_mod['student']['_geometry'] = g_s
         in_mod['teacher']['_geometry'] = g_t
         return in_mod

@@ -93,19 +93,23 @@ def _prepare_geometry_level_by_level(x: SparseTensor, pres, vres):
     return z, x0
 
 
-def prepare_geometry_many(items):
-    """prepare_geometry for several networks' inputs (``items`` = [(SparseTensor, pres, vres)]: the KD step's student and
-    teacher) with TWO host round trips in total: the sizes of all stride-1 voxel sets are read together, then the sizes
-    of every down-sampled level of every network (spf.DownsamplePyramid) together with the out-of-range flags -- where
-    the one-network-at-a-time, one-level-at-a-time form stopped the host 6 times per network.  The work queued to the
-    GPU and every result (voxel order, coordinates, kernel maps) are the same."""
+def prepare_geometry_staged(items):
+    """prepare_geometry_many as a GENERATOR that yields in front of each of its two host reads: a caller with other host work
+    (train.KDStep: a step's forward and backward to queue) resumes it later and finds the counts already computed -- the same
+    launches in the same order on whatever stream is current at each resumption, no waiting.  No context manager is held
+    across a yield (a ``torch.no_grad()`` or stream context would leak into the caller's code): the CALLER sets them
+    around every ``next()``.  Returns (StopIteration.value) what prepare_geometry_many returns."""
     if not _BATCHED:
+        yield
+        yield
         return [_prepare_geometry_level_by_level(x, pres, vres) for x, pres, vres in items]
     states = [_voxelize_issue(PointTensor(x.F, x.C.float()), pres, vres) for x, pres, vres in items]
+    yield
     sizes = spf.read_counts([st['cnt'] for st in states])                      # round trip 1
     x0s = [_voxelize_finish(st, n) for st, n in zip(states, sizes)]
     totals = _level_strides(KMAP_SPECS)
     pyramids = [spf.DownsamplePyramid(x0.C, totals) if x0.C.shape[0] else None for x0 in x0s]
+    yield
     values = spf.read_counts([c for p in pyramids if p is not None for c in p.counts()])   # round trip 2
     out, at = [], 0
     for st, x0, pyr in zip(states, x0s, pyramids):
@@ -117,6 +121,20 @@ def prepare_geometry_many(items):
             at += k
         out.append((st['z'], x0))
     return out
+
+
+def prepare_geometry_many(items):
+    """prepare_geometry for several networks' inputs (``items`` = [(SparseTensor, pres, vres)]: the KD step's student and
+    teacher) with TWO host round trips in total: the sizes of all stride-1 voxel sets are read together, then the sizes
+    of every down-sampled level of every network (spf.DownsamplePyramid) together with the out-of-range flags -- where
+    the one-network-at-a-time, one-level-at-a-time form stopped the host 6 times per network.  The work queued to the
+    GPU and every result (voxel order, coordinates, kernel maps) are the same."""
+    stages = prepare_geometry_staged(items)
+    try:
+        while True:
+            next(stages)
+    except StopIteration as done:
+        return done.value
 
 
 def prepare_geometry(x: SparseTensor, pres, vres):

@@ -59,6 +59,16 @@ def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4, name='sgd
     raise NotImplementedError(name)
 
 
+def _staged_geometry() -> bool:
+    """The next batch's geometry in slices between the phases of the current step (KDStep.__call__) -- or in one piece behind
+    the backward.  U2MKD_STAGED_GEOMETRY=0 / 1 decides; otherwise slices exactly when the process runs on the runtime's 4
+    hardware queues (a single-rank process, distributed.configure_runtime): with more queues the slices' stream gets a queue
+    of its own and the step falls off a scheduling cliff (64 -> 105 ms, NOTES N9.11)."""
+    env = os.environ.get('U2MKD_STAGED_GEOMETRY')
+    if env in ('0', '1'):
+        return env == '1'
+    return D.hardware_queues() <= 4
+
 class _Amp:
     """``amp.autocast(enabled)`` + ``amp.GradScaler(enabled)`` of the reference trainers
     (core/nusc_trainers.py:157-158,285,362-364; core/spformer_trainer.py likewise).  amp = False / None: fp32
@@ -297,6 +307,16 @@ class KDStep:
         self.model.train()
         self.model.model_t.eval()          # core/nusc_trainers.py:203-208
 
+    def _advance_geometry(self, geo, staged):
+        """One slice of the next batch's geometry (kd.TSDFull.prepare_staged) on the geometry stream, under the contexts the
+        one-piece ``prepare`` runs in; returns the prepared ``in_mod`` when the generator is done, else None."""
+        with torch.cuda.stream(geo), self.amp.autocast(), torch.no_grad():
+            try:
+                next(staged)
+            except StopIteration as done:
+                return done.value
+        return None
+
     @staticmethod
     def _in_mod(d):
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
@@ -318,10 +338,35 @@ class KDStep:
         if getattr(self, '_geo_done', None) is not None:
             torch.cuda.current_stream().wait_event(self._geo_done)
             self._geo_done = None
+        staged = None
+        if prefetch is not None and d['s_feats'].is_cuda and deferred.overlap_ok() and _staged_geometry():
+            # The next batch's geometry in THREE slices on the side stream, one in front of each phase of this step: its two
+            # host reads then fall behind the forward's and the backward's launch work (25 + 30 ms of host time) and find
+            # their counts ready -- the step is bound by the host (tools/host_phases.py: host time = wall time), and the reads
+            # were 5-6 ms of it sitting in hipStreamSynchronize.  Same launches, same order, same stream as the one-piece form
+            # below; `entry`, `_geo_done`, `_geo_keep` and the record_stream registration as there.
+            geo = KD._side_stream(d['s_feats'], 'geo')
+            geo.wait_event(entry)
+            staged = self.model.prepare_staged(self._in_mod(prefetch))
+            self._advance_geometry(geo, staged)            # slice 1: point hashes, voxel sets (launches only)
         with self.amp.autocast():
             out = self.net(in_mod)
             ld = KD.kd_losses(out, d['targets'], d['fov_mask'], d['inverse_map'], d['inds'], d['num_pts'], d['num_vox_t'],
                               self.crit, d['keyframe_mask_full'])
+        if staged is not None:
+            self._advance_geometry(geo, staged)            # read 1 (ready), slice 2: the down-sampled levels
+            self.amp.backward_and_step(ld['total'], self.opt)
+            self.sched.step()
+            done = self._advance_geometry(geo, staged)     # read 2 (ready), slice 3: kernel maps, schedules
+            self._queued = (prefetch, done)
+            self._geo_done = geo.record_event()
+            self._geo_keep = in_mod
+            users = [torch.cuda.current_stream(), KD._side_stream(d['s_feats'], 'teacher'), KD._side_stream(d['s_feats'], 'camera')]
+            for key in ('student', 'teacher'):
+                for t in _tensors_of(self._queued[1][key].get('_geometry')):
+                    for st in users:
+                        t.record_stream(st)
+            return ld['total'].detach()
         if prefetch is not None and d['s_feats'].is_cuda and deferred.overlap_ok():
             # The next batch's geometry AFTER this step's backward has been issued, on a side stream: its ~1 000 small
             # kernels (hash tables, kernel maps, voxel sets) and the two host round trips run underneath the backward's
