@@ -1,10 +1,24 @@
 import numpy as np
 
+_SEEN = {}      # (value, ndim) -> tuple: the same few strides / kernel sizes are asked for ~600 times per training step
+
 
 def make_ntuple(x, ndim=3):
     """torchsparse.utils.make_ntuple."""
+    try:
+        hit = _SEEN.get((x, ndim))      # (ints and tuples of ints; lists / arrays are unhashable and take the long way)
+    except TypeError:
+        hit = None
+    if hit is not None:
+        return hit
     if isinstance(x, (int, np.integer)):
-        return tuple(int(x) for _ in range(ndim))
-    x = tuple(int(v) for v in x)
-    assert len(x) == ndim, x
-    return x
+        out = tuple(int(x) for _ in range(ndim))
+    else:
+        out = tuple(int(v) for v in x)
+        assert len(out) == ndim, x
+    try:
+        if len(_SEEN) < 4096:
+            _SEEN[(x, ndim)] = out
+    except TypeError:
+        pass
+    return out
