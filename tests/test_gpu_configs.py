@@ -115,3 +115,38 @@ def test_prefetched_geometry_makes_the_forward_sync_free_and_changes_nothing(hip
     finally:
         torch.cuda.set_sync_debug_mode('default')
     assert bool(torch.isfinite(out['stu']['x_vox']).all())
+
+
+def test_geometry_in_slices_gives_the_step_the_same_geometry(hip, monkeypatch):
+    """train.KDStep with ``prefetch=``: the next batch's geometry queued in slices between the phases of the current step
+    (U2MKD_STAGED_GEOMETRY=1, the single-rank default) against the one-piece form behind the backward (=0): the same voxel
+    sets and coordinates for every batch, the frozen teacher's logits bit for bit, the first loss within rounding (the student's
+    float atomics)."""
+    from u2mkd_amd import train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    from u2mkd_amd.torchsparse.nn import functional as F
+    batches = [T.kd_batch_to_device(synth_kd_batch(3000 + 500 * i, 1, seed=31 + i, image_hw=(64, 112))) for i in range(3)]
+
+    def run(staged):
+        monkeypatch.setenv('U2MKD_STAGED_GEOMETRY', '1' if staged else '0')
+        runner = _runner(1.0, 2.0)
+        watch = T.TeacherWatch(runner.model.model_t)
+        losses, geo = [], []
+        cur = T.fresh_batch(batches[0])
+        for i in range(4):
+            nxt = T.fresh_batch(batches[(i + 1) % 3])
+            watch.key = i
+            losses.append(float(runner(cur, prefetch=nxt)))
+            g = runner._queued[1]                         # the prepared in_mod of the next batch
+            z, x0 = g['student']['_geometry']
+            tz, tx0 = g['teacher']['_geometry']
+            geo.append((x0.C.clone(), tx0.C.clone(), z.C.clone()))
+            cur = nxt
+        torch.cuda.synchronize()
+        return losses, geo, [t for _, t in watch.log]
+    a, b = run(False), run(True)
+    assert abs(a[0][0] - b[0][0]) <= 1e-5 * abs(a[0][0]), (a[0], b[0])
+    for ga, gb in zip(a[1], b[1]):
+        for ta, tb in zip(ga, gb):
+            assert torch.equal(ta, tb)
+    assert torch.equal(a[2][0], b[2][0])               # the first step's teacher logits (later steps follow different students)
