@@ -59,6 +59,18 @@ def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4, name='sgd
     raise NotImplementedError(name)
 
 
+def _advance_geometry(amp, geo, staged):
+    """One slice of the next batch's geometry (a generator: kd.TSDFull.prepare_staged / point_voxel.prepare_geometry_staged) on
+    the geometry stream, under the contexts the one-piece preparation runs in; returns the generator's result when it is
+    done, else None."""
+    with torch.cuda.stream(geo), amp.autocast(), torch.no_grad():
+        try:
+            next(staged)
+        except StopIteration as done:
+            return done.value
+    return None
+
+
 def _staged_geometry() -> bool:
     """The next batch's geometry in slices between the phases of the current step (KDStep.__call__) -- or in one piece behind
     the backward.  U2MKD_STAGED_GEOMETRY=0 / 1 decides; otherwise slices exactly when the process runs on the runtime's 4
@@ -132,11 +144,38 @@ class LidarStep:
         in_mod = {'lidar': ts.SparseTensor(feats, coords)}
         if queued is not None and queued[0] is feats and queued[1] is coords:
             in_mod = queued[2]
+        staged = None
+        if prefetch is not None and feats.is_cuda and deferred.overlap_ok() and _staged_geometry():
+            # the next batch's geometry in slices on a side stream, one in front of each phase of this step (as KDStep does,
+            # see there): its two size reads find their counts ready instead of waiting behind the forward's kernels
+            from .lidar.point_voxel import prepare_geometry_staged
+            main = torch.cuda.current_stream()
+            entry = main.record_event()
+            if getattr(self, '_geo_done', None) is not None:
+                main.wait_event(self._geo_done)
+                self._geo_done = None
+            geo = KD._side_stream(feats, 'geo')
+            geo.wait_event(entry)
+            nf, nc = prefetch
+            nxt = {'lidar': ts.SparseTensor(nf, nc)}
+            staged = prepare_geometry_staged([(nxt['lidar'], self.model.pres, self.model.vres)])
+            _advance_geometry(self.amp, geo, staged)
         with self.amp.autocast():
             out = self.net(in_mod)['x_vox']
             if keyframe_mask is not None:
                 out, targets = out[keyframe_mask], targets[keyframe_mask]
             loss = self.criterion(out, targets)
+        if staged is not None:
+            _advance_geometry(self.amp, geo, staged)
+            self.amp.backward_and_step(loss, self.opt)
+            self.sched.step()
+            nxt['_geometry'] = _advance_geometry(self.amp, geo, staged)[0]
+            self._queued = (nf, nc, nxt)
+            self._geo_done = geo.record_event()
+            self._geo_keep = in_mod              # (this batch's geometry lives until the next call has queued its forward)
+            for t in _tensors_of(nxt['_geometry']):
+                t.record_stream(main)            # allocated on the side stream, read (and freed) on the caller's
+            return loss.detach()
         if prefetch is not None:
             from .lidar.point_voxel import prepare_geometry
             nf, nc = prefetch
@@ -308,14 +347,7 @@ class KDStep:
         self.model.model_t.eval()          # core/nusc_trainers.py:203-208
 
     def _advance_geometry(self, geo, staged):
-        """One slice of the next batch's geometry (kd.TSDFull.prepare_staged) on the geometry stream, under the contexts the
-        one-piece ``prepare`` runs in; returns the prepared ``in_mod`` when the generator is done, else None."""
-        with torch.cuda.stream(geo), self.amp.autocast(), torch.no_grad():
-            try:
-                next(staged)
-            except StopIteration as done:
-                return done.value
-        return None
+        return _advance_geometry(self.amp, geo, staged)
 
     @staticmethod
     def _in_mod(d):
