@@ -34,6 +34,11 @@ typedef void *u2mkd_stream_t; /* hipStream_t */
 /* ---- library ---------------------------------------------------------- */
 int u2mkd_version(void);
 const char *u2mkd_last_error(void);
+/* Stream ordering for the host side (no reference counterpart: the reference is single-stream): `waiter` continues only behind
+ * what is queued on `signaler` at the time of the call -- one event record + one stream wait on an event object kept per waiter
+ * stream (the one exception to "nothing is allocated inside": a hipEvent per stream, once).  torch.cuda.Stream.wait_stream's
+ * job in one call; not for use under hipGraph capture of the signaler. */
+int u2mkd_stream_wait_stream(u2mkd_stream_t waiter, u2mkd_stream_t signaler);
 
 /* ---- coordinate hashing ------------------------------------------------
  * replaces torchsparse.backend.hash_cuda / kernel_hash_cuda

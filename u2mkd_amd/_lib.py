@@ -39,6 +39,7 @@ SIGNATURES = {
     'u2mkd_conv_forward': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_debug_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'u2mkd_stream_wait_stream': (C.c_int, [_p, _p]),
     'u2mkd_conv_tiles_supported': (_i32, [_i32, _i32, _i32]),
     'u2mkd_conv_tiles_arith': (_i32, [_i32, _i32, _i32]),
     'u2mkd_weight_fragments_bytes': (_sz, [_i32, _i32, _i32, _i32]),

@@ -1,6 +1,8 @@
 // Coordinate hashing, device hash table, kernel-map (rulebook) construction.
 // Replaces torchsparse v1.4.0 hash_cuda / kernel_hash_cuda / hash_query_cuda
 // and the python kmap build of F.conv3d.
+#include <mutex>
+#include <unordered_map>
 #include <stdarg.h>
 
 #include <stdlib.h>
@@ -284,6 +286,37 @@ extern "C" {
 
 int u2mkd_version(void) { return 100; }
 const char *u2mkd_last_error(void) { return g_err; }
+
+/* `waiter` continues only behind everything queued on `signaler` so far: one event record + one stream wait (what
+ * torch.cuda.Stream.wait_stream does through three Python calls and a new event object each time -- the trainers order a side
+ * stream behind the caller's ~130 times per backward pass).  The event objects are made once per waiter stream and kept; a later
+ * record on the same event does not disturb a wait already queued (hipStreamWaitEvent takes the record that precedes it). */
+int u2mkd_stream_wait_stream(u2mkd_stream_t waiter, u2mkd_stream_t signaler) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, hipEvent_t> events;
+    hipStream_t w = as_stream(waiter), sg = as_stream(signaler);
+    if (w == sg) return 0;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = events.find(w);
+        if (it == events.end()) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                set_error("u2mkd_stream_wait_stream: hipEventCreateWithFlags failed");
+                return 1;
+            }
+            events.emplace(w, ev);
+        } else {
+            ev = it->second;
+        }
+        // (record + wait under the lock: two threads ordering the same waiter must not interleave their record / wait pairs)
+        if (hipEventRecord(ev, sg) != hipSuccess || hipStreamWaitEvent(w, ev, 0) != hipSuccess) {
+            set_error("u2mkd_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
+            return 1;
+        }
+    }
+    return 0;
+}
 
 int u2mkd_hash(const int32_t *coords, int64_t n, int64_t *out, u2mkd_stream_t s) {
     if (n == 0) return 0;

@@ -208,6 +208,7 @@ class PackedAttentionFunction(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        from .. import deferred
         branches = ctx.branches
         nb = len(branches)
         saved = ctx.saved_tensors
@@ -240,7 +241,7 @@ class PackedAttentionFunction(Function):
                    L.ptr(delta), L.ptr(ws), nbytes, L.ptr(dqkv[:, 0, h0:]), L.ptr(dqkv[:, 1, h0:]), L.ptr(dqkv[:, 2, h0:]),
                    3 * H * d, L.ptr(None if late else dtq), L.ptr(None if late else dtk), L.ptr(None if late else dtv), st)
             if late:       # the slab sum behind the kernels, on the weight-gradient side stream, joined when the backward ends
-                side.wait_stream(torch.cuda.current_stream(qkv.device))
+                deferred.order_behind_current(side, qkv.device.index if qkv.device.index is not None else torch.cuda.current_device())
                 for t in (ws, dtq, dtk, dtv):
                     t.record_stream(side)
                 L.call('u2mkd_sptr_table_reduce', L.ptr(ws), n, h, tl, float(br['split_a']), L.ptr(dtq), L.ptr(dtk), L.ptr(dtv),
