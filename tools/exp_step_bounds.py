@@ -1,6 +1,6 @@
 """Upper bounds for step-level changes, measured instead of estimated: the pipelined KD step (fresh batches, geometry
 prefetch) with parts of the work switched off.  One variant per process (env / argv), wall ms per step printed.
-  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [half_res_tail] [cached_plans]"""
+  python tools/exp_step_bounds.py [no_cam_wgrad] [no_pix_decoder] [half_res_tail] [cached_plans] [no_cam_backward]"""
 import sys, time, os; sys.path.insert(0, '.')
 import torch
 from u2mkd_amd import lidar, train as T, kd as KD
@@ -15,6 +15,23 @@ if 'no_cam_wgrad' in flags:        # camera convolutions without weight gradient
     for n, p in model.model_s.pix_branch.named_parameters():
         if p.dim() == 4:
             p.requires_grad_(False)
+if 'no_cam_backward' in flags:       # the camera ENCODER's features enter the fusion detached: no gradient flows back into the ResNet layers
+    pb = model.model_s.pix_branch     # (its backward chain -- MIOpen input gradients interlocked with the LiDAR branch at every fusion stage -- disappears)
+    for name in ('layer1', 'layer2', 'layer3', 'layer4'):
+        layer = getattr(pb, name, None)
+        if layer is not None:
+            real = layer.forward
+            layer.forward = (lambda f: (lambda *a, **k: _detach(f(*a, **k))))(real)
+
+
+def _detach(o):
+    if isinstance(o, torch.Tensor):
+        return o.detach()
+    if isinstance(o, (tuple, list)):
+        return type(o)(_detach(v) for v in o)
+    return o
+
+
 if 'half_res_tail' in flags:      # the pixel head evaluated on the H/2 map (no final x2 up-sampling): what the full-resolution tail costs
     pb = model.model_s.pix_branch
     fu = pb.forward_up
