@@ -22,4 +22,9 @@ Pinning status (see DESIGN.md "Oracle"):
 * model wiring / losses are pinned on golden vectors generated in the build
   container by importing the reference's own Python modules over
   ``oracle.torchsparse_cpu`` (``tests/golden/make_golden.py``).
+* ``f16x2_ref`` is not a restatement of reference code: a numpy model of the
+  PRODUCT's own f16x2 multiply (two scaled fp16 planes per fp32 operand, three
+  partial products), so that its accuracy bound against float64 can be checked
+  on the CPU (``tests/test_f16x2_arithmetic.py``); the GPU kernels are held to
+  the same bound in ``tests/test_gpu_conv_f16x2.py``.
 """
