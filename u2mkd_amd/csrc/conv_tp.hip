@@ -43,6 +43,9 @@
 
 namespace u2mkd {
 
+#ifndef U2MKD_TP_EXTRA_LDS
+#define U2MKD_TP_EXTRA_LDS 0      // (occupancy probes only: tools/build_variant.sh _lds "-DU2MKD_TP_EXTRA_LDS=8192" conv_tp.hip)
+#endif
 constexpr int kTpPad = 8;             // row pad of the LDS row image (dwords), see AS below
 constexpr int kTpRowShift = 25;       // s_idx word of a pair = input row | tile row << 25 (input rows < 2^25, launch_conv_tp checks)
 
@@ -752,7 +755,7 @@ static void launch_tp(dim3 grid, int K, hipStream_t st, const float *in, const f
                       float *out, unsigned long long *stamps = nullptr) {
     constexpr int TN = 16 * NW * NBW;
     const size_t lds = (size_t)64 * (TN + 4) * 4 + (size_t)2 * 16 * ((AR == 2 ? 6 * CIN : AR == 3 ? 2 * CIN : 4 * CIN) + 4 * kTpPad) + (size_t)(K + 1) * 64 * 4 + 32 * 4 + 64 * 4 +
-                       (size_t)(4 * K + 8) * 4 + (AR == 4 ? 2 * 16 * 4 : 0);
+                       (size_t)(4 * K + 8) * 4 + (AR == 4 ? 2 * 16 * 4 : 0) + U2MKD_TP_EXTRA_LDS;
     const int n_tiles = (int)ceil_div(rr.end - rr.begin, 64);
     // one resident wave of workgroups at most (they deal the items among themselves, lightest first)
     static int occ_by_k[33];                         // resident workgroups per CU of THIS instantiation at kernel volume K
