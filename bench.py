@@ -56,8 +56,8 @@ DTYPE_LABEL = {'f32': 'f32 (fp32 products emulated on the 16-bit matrix pipe: f1
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--voxels', type=int, default=N_VOX)
     ap.add_argument('--cr', type=float, default=1.0)
     ap.add_argument('--cr-t', type=float, default=2.0)
