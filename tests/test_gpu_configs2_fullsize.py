@@ -6,7 +6,7 @@ configs/nuscenes/train/spformer_tsd_full_ours_star.yaml:32-43, one 80 000-point 
 against the reference's own classes: test_kd_path.py; per operator: test_gpu_torchsparse_ops.py; the pixel head at this
 camera size: test_gpu_pixel_head.py):
   * the LiDAR side is run-to-run reproducible: the student's voxel set / kernel-map geometry bit for bit (order-deterministic
-    kernels, no atomics), the frozen teacher's logits bit for bit in about nine runs of ten and inside a stated band otherwise; the student's outputs, which depend on MIOpen's
+    kernels, no atomics), the frozen teacher's logits bit for bit (torch.equal over every repetition, round 5); the student's outputs, which depend on MIOpen's
     convolutions (not reproducible run to run, DESIGN.md section 7b), to rounding noise;
   * every student parameter receives a finite gradient, the frozen teacher none; every loss term is finite;
   * the teacher -> student re-index (core/nusc_trainers.py:295-324) selects exactly the rows the reference's chained

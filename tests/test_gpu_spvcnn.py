@@ -261,6 +261,37 @@ def test_teacher_only_step_masks_the_loss_to_key_frame_voxels(hip):
     assert abs(float(full) - float(want)) > 1e-4
 
 
+def test_lidar_step_prefetch_loop_ending_without_prefetch_matches_the_plain_loop(hip, monkeypatch):
+    """train.LidarStep(prefetch=next) queues the next batch's geometry on a side stream; the LAST call of an epoch has
+    prefetch=None and must still order its forward behind that stream (the wait sat inside the staged branch).
+    Losses of the prefetching loop == the plain loop's, step for step (SPVCNN on the library's kernels is bit-reproducible),
+    in the staged and in the one-piece mode."""
+    import torch
+    from u2mkd_amd import lidar, torchsparse as ts, train as T
+    from u2mkd_amd.synth import synth_batch
+    kw = dict(cr=0.5, in_channel=4, num_classes=17, pres=0.05, vres=0.05)
+    bs = [synth_batch(9000 + 1000 * i, 1, seed=60 + i) for i in range(3)]
+    bs = [tuple(torch.from_numpy(b[k]).cuda() for k in ('feats', 'coords', 'labels')) for b in bs]
+
+    def loop(prefetch, staged='1'):
+        monkeypatch.setenv('U2MKD_STAGED_GEOMETRY', staged)
+        torch.manual_seed(0)
+        model = lidar.SPVCNN(**kw).cuda().train()
+        model.dropout.p = 0.0
+        run = T.LidarStep(model, num_epochs=1, batch_size=1)
+        cur = [t.clone() for t in bs[0]]
+        out = []
+        for i in range(3):
+            nxt = [t.clone() for t in bs[i + 1]] if i + 1 < 3 else None
+            out.append(float(run(*cur, prefetch=(nxt[0], nxt[1]) if (prefetch and nxt) else None)))
+            cur = nxt
+        return out
+    want = loop(False)
+    for staged in ('1', '0'):
+        got = loop(True, staged)
+        assert got == want, (staged, got, want)
+
+
 def test_eval_batchnorm_folded_into_the_convolution_equals_the_two_pass_form(hip):
     """Inference (frozen teacher / evaluation): spnn.Conv3d -> eval-mode BatchNorm (-> ReLU | + residual -> ReLU) runs as one
     convolution whose store applies scale / shift / residual / ReLU (functional.conv_eval_affine, build_blocks.py:25-31,59-71);

@@ -141,6 +141,11 @@ class LidarStep:
         deferred.begin_step()      # (nothing of a backward pass that raised stays booked)
         deferred.set_reduced_precision(self.amp.enabled)      # (library kernels in bf16 / fp16: no side streams, deferred.overlap_ok)
         queued = self.__dict__.pop('_queued', None)
+        if getattr(self, '_geo_done', None) is not None:
+            # whichever branch this call takes (prefetch=None on an epoch's last batch, staging switched off), the forward
+            # reads kernel maps the previous call built on the geometry stream: order the main stream behind them first
+            torch.cuda.current_stream().wait_event(self._geo_done)
+            self._geo_done = None
         in_mod = {'lidar': ts.SparseTensor(feats, coords)}
         if queued is not None and queued[0] is feats and queued[1] is coords:
             in_mod = queued[2]
@@ -151,9 +156,6 @@ class LidarStep:
             from .lidar.point_voxel import prepare_geometry_staged
             main = torch.cuda.current_stream()
             entry = main.record_event()
-            if getattr(self, '_geo_done', None) is not None:
-                main.wait_event(self._geo_done)
-                self._geo_done = None
             geo = KD._side_stream(feats, 'geo')
             geo.wait_event(entry)
             nf, nc = prefetch
