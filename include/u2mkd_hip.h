@@ -386,14 +386,9 @@ int u2mkd_devoxelize_plan(const int32_t *idx8 /*[n,8]*/, const float *w8 /*[n,8]
                           int32_t *entry_row /*[8n]*/, float *entry_w /*[8n]*/, int32_t *seg /*[nv+1]*/, u2mkd_stream_t s);
 int u2mkd_ti_weights(const float *coords /*[n,4] float (x,y,z,b)*/, const int64_t *idx_kn /*[8,n]*/, int64_t n,
                      float scale, float *w_n8 /*[n,8]*/, int32_t *idx_n8 /*[n,8]*/, u2mkd_stream_t s);
-/* Debugging only (tools/dbg_stale_probe.py), NOT part of the boundary: with U2MKD_DEBUG_TI_PROBE=1 in the environment
- * u2mkd_ti_weights runs a variant that reads every input word with an ordinary load AND with agent- / system-scope loads
- * and logs the threads whose reads disagree (a kernel behind its producer on one stream must never see that);
- * u2mkd_debug_probe_read copies the log to the host (device synchronisation), entries of u2mkd_debug_probe_entry_bytes(). */
-int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int32_t reset);
-int32_t u2mkd_debug_probe_entry_bytes(void);
-int u2mkd_debug_probe_rows_read(void *dst /*[2][81920] x uint32[4]*/, int32_t slot /*launch mod 16*/);
-int u2mkd_debug_probe_wg_read(void *dst /*[64][2048] x {uint32 launch + 1, uint32 low bits of w_n8}*/, int32_t *launches, int32_t reset);
+/* (The coherence probe of round 5 -- tools/dbg_stale_probe.py, U2MKD_DEBUG_TI_PROBE=1 -- lives behind -DU2MKD_DEBUG_PROBE in
+ * csrc/voxel.hip and is built by tools/build_variant.sh into a library of its own; the shipped library carries neither its
+ * device-side logs nor its four read-out entries.) */
 
 /* ---- the pixel head's full-resolution tail at the pixels that are read (csrc/pixhead.hip) -----------------------------
  * Replaces the dense evaluation of  Feature_Fetch(classifier_pix(upsample(x, image size)))  (the final F.interpolate of

@@ -203,6 +203,40 @@ def test_reducer_recovers_from_a_backward_pass_that_raised_and_arms_without_para
     assert torch.equal(xin.grad, torch.full_like(xin, 2.0))
 
 
+def test_reducer_sink_reaches_outputs_in_namedtuples_and_tensor_objects():
+    """the sink that books the end-of-backward flush must reach outputs carried in a namedtuple, a defaultdict and
+    a SparseTensor-like object (``.F``); a pass without parameter gradients through such outputs still issues every bucket."""
+    import collections
+    from u2mkd_amd import distributed as D
+    from oracle import torchsparse_cpu as ots
+    Out = collections.namedtuple('Out', 'a b')
+
+    class Carrier(torch.nn.Module):
+        def __init__(self, kind):
+            super().__init__()
+            self.w = torch.nn.Linear(4, 4)
+            self.kind = kind
+
+        def forward(self, x):
+            y = x * 3
+            if self.kind == 'namedtuple':
+                return Out(y, 7)
+            if self.kind == 'defaultdict':
+                d = collections.defaultdict(list)
+                d['y'] = y
+                return d
+            return ots.SparseTensor(y, torch.zeros(x.shape[0], 4, dtype=torch.int32))
+    for kind, pick in (('namedtuple', lambda o: o.a), ('defaultdict', lambda o: o['y']), ('sparse', lambda o: o.F)):
+        red = D.BucketedGradientAverage(Carrier(kind), bucket_cap_mb=0.0001)
+        xin = torch.randn(3, 4, requires_grad=True)
+        out = red(xin)
+        if kind == 'namedtuple':
+            assert type(out) is Out and out.b == 7
+        pick(out).sum().backward()
+        assert red.collectives['count'] == len(red._buckets), kind
+        assert torch.equal(xin.grad, torch.full_like(xin, 3.0)), kind
+
+
 def test_reducer_no_sync_accumulates_locally():
     from u2mkd_amd import distributed as D
     torch.manual_seed(0)

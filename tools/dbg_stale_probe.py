@@ -27,6 +27,13 @@ from test_gpu_configs4_fullsize import _step
 
 ENTRY = np.dtype([('i', '<i8'), ('k', '<i4'), ('xcc', '<u4'), ('hwid', '<u4'), ('launch', '<u4'), ('v_plain', '<i8'),
                   ('v_agent', '<i8'), ('v_sys', '<i8'), ('v_after_inv', '<i8'), ('t', '<u8')])
+# the probe is not in the shipped library: tools/build_variant.sh _probe "-DU2MKD_DEBUG_PROBE" voxel.hip, then
+# U2MKD_LIB_SUFFIX=_probe python tools/dbg_stale_probe.py
+_i32, _i64, _p = C.c_int32, C.c_int64, C.c_void_p
+L.SIGNATURES.update({'u2mkd_debug_probe_read': (C.c_int, [_p, _i64, _p, _i32]),
+                     'u2mkd_debug_probe_entry_bytes': (_i32, []),
+                     'u2mkd_debug_probe_rows_read': (C.c_int, [_p, _i32]),
+                     'u2mkd_debug_probe_wg_read': (C.c_int, [_p, _p, _i32])})
 lib = L.load()
 assert lib.u2mkd_debug_probe_entry_bytes() == ENTRY.itemsize, (lib.u2mkd_debug_probe_entry_bytes(), ENTRY.itemsize)
 CAP = 4096

@@ -169,10 +169,6 @@ SIGNATURES = {
     'u2mkd_devoxelize_plan_workspace_bytes': (C.c_size_t, [_i64, _i64]),
     'u2mkd_devoxelize_plan': (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     'u2mkd_ti_weights': (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p]),
-    'u2mkd_debug_probe_read': (C.c_int, [_p, _i64, _p, _i32]),
-    'u2mkd_debug_probe_entry_bytes': (_i32, []),
-    'u2mkd_debug_probe_rows_read': (C.c_int, [_p, _i32]),
-    'u2mkd_debug_probe_wg_read': (C.c_int, [_p, _p, _i32]),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 // Replaces torchsparse v1.4.0 hash_cuda / kernel_hash_cuda / hash_query_cuda
 // and the python kmap build of F.conv3d.
 #include <mutex>
+#include <map>
 #include <unordered_map>
 #include <stdarg.h>
 
@@ -293,25 +294,42 @@ const char *u2mkd_last_error(void) { return g_err; }
  * record on the same event does not disturb a wait already queued (hipStreamWaitEvent takes the record that precedes it). */
 int u2mkd_stream_wait_stream(u2mkd_stream_t waiter, u2mkd_stream_t signaler) {
     static std::mutex mu;
-    static std::unordered_map<hipStream_t, hipEvent_t> events;
+    // one event per (waiter stream, device of the signaler): an event records only on streams of the device it was made on
+    static std::map<std::pair<hipStream_t, int>, hipEvent_t> events;
     hipStream_t w = as_stream(waiter), sg = as_stream(signaler);
     if (w == sg) return 0;
+    int dev = 0, cur = 0;
+    if (hipStreamGetDevice(sg, &dev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+        set_error("u2mkd_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
+        return 1;
+    }
+    hipStreamCaptureStatus cap_w = hipStreamCaptureStatusNone, cap_s = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(w, &cap_w);
+    (void)hipStreamIsCapturing(sg, &cap_s);
+    const bool capturing = cap_w != hipStreamCaptureStatusNone || cap_s != hipStreamCaptureStatusNone;
     hipEvent_t ev = nullptr;
     {
         std::lock_guard<std::mutex> lock(mu);
-        auto it = events.find(w);
+        auto it = capturing ? events.end() : events.find({w, dev});
         if (it == events.end()) {
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                set_error("u2mkd_stream_wait_stream: hipEventCreateWithFlags failed");
+            // (a cached event must not be re-recorded inside a stream capture: a capture gets an event of its own)
+            if (cur != dev) (void)hipSetDevice(dev);
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (cur != dev) (void)hipSetDevice(cur);
+            if (e != hipSuccess) {
+                set_error("u2mkd_stream_wait_stream: hipEventCreateWithFlags failed: %s", hipGetErrorString(e));
                 return 1;
             }
-            events.emplace(w, ev);
+            if (!capturing) events.emplace(std::make_pair(w, dev), ev);
         } else {
             ev = it->second;
         }
         // (record + wait under the lock: two threads ordering the same waiter must not interleave their record / wait pairs)
-        if (hipEventRecord(ev, sg) != hipSuccess || hipStreamWaitEvent(w, ev, 0) != hipSuccess) {
-            set_error("u2mkd_stream_wait_stream: %s", hipGetErrorString(hipGetLastError()));
+        hipError_t e = hipEventRecord(ev, sg);
+        if (e == hipSuccess) e = hipStreamWaitEvent(w, ev, 0);
+        if (capturing) (void)hipEventDestroy(ev);      // (released once the recorded work has completed)
+        if (e != hipSuccess) {
+            set_error("u2mkd_stream_wait_stream: %s", hipGetErrorString(e));
             return 1;
         }
     }

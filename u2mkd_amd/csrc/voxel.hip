@@ -314,6 +314,7 @@ __global__ void ti_weights_kernel(const float4 *__restrict__ coords, const int64
     }
 }
 
+#ifdef U2MKD_DEBUG_PROBE     // (tools/build_variant.sh _probe "-DU2MKD_DEBUG_PROBE" voxel.hip; not in the shipped library)
 // ---- debug: coherence probe (tools/dbg_stale_probe.py; U2MKD_DEBUG_TI_PROBE=1) -------------------------------------
 // The same arithmetic as ti_weights_kernel on the values an ORDINARY load returns, but every input word is read a second
 // and third time past the caches (agent-scope and system-scope atomic loads) and a fourth time with an ordinary load
@@ -429,12 +430,16 @@ __global__ void ti_weights_probe_kernel(const float4 *__restrict__ coords, const
     }
 }
 
+#endif  // U2MKD_DEBUG_PROBE
+
 }  // namespace u2mkd
 
 
 using namespace u2mkd;
 
+#ifdef U2MKD_DEBUG_PROBE
 static unsigned g_probe_launches_host = 0;      // (debug probe: launches so far; the host thread that launches is the only writer)
+#endif
 
 #define LAUNCH_ROWS(kernel, n, c, ...)                                                                  \
     do {                                                                                                \
@@ -542,17 +547,20 @@ int u2mkd_ti_weights(const float *coords, const int64_t *idx_kn, int64_t n, floa
                      int32_t *idx_n8, u2mkd_stream_t s) {
     if (n == 0) return 0;
     U2_REQUIRE(coords && idx_kn && w_n8 && idx_n8, "u2mkd_ti_weights: null pointer");
+#ifdef U2MKD_DEBUG_PROBE
     static const bool probe = [] { const char *e = getenv("U2MKD_DEBUG_TI_PROBE"); return e && e[0] == '1'; }();
     if (probe) {
         hipLaunchKernelGGL(ti_weights_probe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
                            reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8, g_probe_launches_host++);
         return check_launch("u2mkd_ti_weights(probe)");
     }
+#endif
     hipLaunchKernelGGL(ti_weights_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s),
                        reinterpret_cast<const float4 *>(coords), idx_kn, n, scale, w_n8, idx_n8);
     return check_launch("u2mkd_ti_weights");
 }
 
+#ifdef U2MKD_DEBUG_PROBE
 // debug: copies the coherence probe's log to the host (synchronises the device); layout = ProbeEntry of csrc/voxel.hip
 int u2mkd_debug_probe_read(void *dst, int64_t max_entries, int32_t *n_total, int32_t reset) {
     U2_REQUIRE(dst && n_total, "u2mkd_debug_probe_read: null pointer");
@@ -593,5 +601,7 @@ int u2mkd_debug_probe_wg_read(void *dst, int32_t *launches, int32_t reset) {
     *launches = (int32_t)g_probe_launches_host;
     return 0;
 }
+
+#endif  // U2MKD_DEBUG_PROBE
 
 }  // extern "C"

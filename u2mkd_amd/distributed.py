@@ -132,12 +132,27 @@ class _ArmSink(torch.autograd.Function):
 
 
 def _map_tensors(o, fn):
+    """Apply ``fn`` to every tensor reachable through dicts, lists, tuples (named ones too) and the feature matrix of a
+    SparseTensor / PointTensor (``.F``, replaced in place); containers of other kinds are returned unchanged.  (The sunk
+    tensors are views made by one autograd.Function: in-place operations on a wrapped module's outputs raise, as with
+    torch DDP's own sink.)"""
     if torch.is_tensor(o):
         return fn(o)
-    if isinstance(o, dict):
-        return type(o)((k, _map_tensors(v, fn)) for k, v in o.items())
-    if isinstance(o, (list, tuple)):
+    if type(o) is dict:
+        return {k: _map_tensors(v, fn) for k, v in o.items()}
+    if isinstance(o, tuple) and hasattr(o, '_fields'):          # namedtuple: positional constructor
+        return type(o)(*(_map_tensors(v, fn) for v in o))
+    if type(o) in (list, tuple):
         return type(o)(_map_tensors(v, fn) for v in o)
+    if isinstance(o, dict):                                     # (defaultdict, OrderedDict ...: keep the object, map its values)
+        for k in list(o.keys()):
+            o[k] = _map_tensors(o[k], fn)
+        return o
+    f = getattr(o, 'F', None)
+    if torch.is_tensor(f):
+        g = fn(f)
+        if g is not None and g is not f:
+            o.F = g
     return o
 
 
@@ -238,7 +253,7 @@ class BucketedGradientAverage(torch.nn.Module):
         if torch.is_grad_enabled() and self._sync:
             self._reset()
             tensors = []
-            _map_tensors(out, lambda t: tensors.append(t) if t.requires_grad else None)
+            _map_tensors(out, lambda t: (tensors.append(t) if t.requires_grad else None, t)[1])
             if tensors:
                 sunk = iter(_ArmSink.apply(self._self_ref, *tensors))
                 out = _map_tensors(out, lambda t: next(sunk) if t.requires_grad else t)
