@@ -39,6 +39,17 @@ const char *u2mkd_last_error(void);
  * stream (the one exception to "nothing is allocated inside": a hipEvent per stream, once).  torch.cuda.Stream.wait_stream's
  * job in one call; not for use under hipGraph capture of the signaler. */
 int u2mkd_stream_wait_stream(u2mkd_stream_t waiter, u2mkd_stream_t signaler);
+/* Host mailbox (csrc/mailbox.hip) for the sizes a geometry pre-pass has to know on the host -- the values the reference reads
+ * with blocking copies inside `torch.unique` (core/models/utils.py:20) and torchsparse v1.4.0's spdownsample.
+ * u2mkd_mailbox_alloc: `bytes` of mapped, coherent host memory, zeroed (the second exception to "nothing is allocated
+ * inside": once per process).  u2mkd_mailbox_post queues ONE small kernel on `s` that stores the n <= 32 device integers
+ * srcs[i] (int64 where bit i of is64 is set, else int32; `srcs` is a HOST array of device pointers) as
+ * slot[i] = (seq mod 2^32) << 32 | value, one indivisible 8-byte system-scope store each (values outside [0, 2^32 - 2] arrive
+ * as 0xffffffff): a host that polls until the upper half of every word equals `seq` has the values without any stream-ordered
+ * copy or stream synchronisation, and without relying on the order in which two device stores reach host memory. */
+void *u2mkd_mailbox_alloc(size_t bytes);
+int u2mkd_mailbox_free(void *p);
+int u2mkd_mailbox_post(const void *const *srcs, uint32_t is64, int32_t n, int64_t *slot, int64_t seq, u2mkd_stream_t s);
 
 /* ---- coordinate hashing ------------------------------------------------
  * replaces torchsparse.backend.hash_cuda / kernel_hash_cuda
@@ -786,6 +797,16 @@ int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res,
                               const float *total_n /*[1] device*/, const float *mean, const float *invstd, const float *gamma,
                               const float *beta, int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx,
                               float *dres /*or NULL*/, u2mkd_stream_t s);
+
+/* ---- optimizer (csrc/optim.hip) --------------------------------------------------------------------------------------
+ * torch.optim.SGD(momentum, nesterov, weight_decay) -- core/builder.py:663-669 -- over all parameters of a group in one launch,
+ * element for element the operations and roundings of torch's multi-tensor path (torch/optim/sgd.py:_multi_tensor_sgd).
+ * jobs: device int64 [n_jobs, 6] = (parameter, gradient or 0 = skip, momentum buffer, elements, index of the tensor's first
+ * chunk, 1 = the buffer does not exist yet: b = g + wd p); a chunk = u2mkd_sgd_chunk_elements() elements, one workgroup each;
+ * contract = 1: every `a + alpha * b` is one fused multiply-add (what ATen's kernels compile to), 0: two roundings. */
+int32_t u2mkd_sgd_chunk_elements(void);
+int u2mkd_sgd_batch(const int64_t *jobs, int32_t n_jobs, int64_t total_chunks, float lr, float momentum, float weight_decay,
+                    int32_t nesterov, int32_t contract, u2mkd_stream_t s);
 
 #ifdef __cplusplus
 }

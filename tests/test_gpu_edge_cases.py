@@ -209,8 +209,8 @@ def test_batched_geometry_pass_equals_the_level_by_level_one_in_two_round_trips(
     mk = lambda b: ts.SparseTensor(torch.from_numpy(b['feats']).cuda(), torch.from_numpy(b['coords']).cuda())
     want = [PV._prepare_geometry_level_by_level(mk(b), 0.05, 0.05) for b in scenes]
     trips = []
-    real = spf.read_counts
-    monkeypatch.setattr(spf, 'read_counts', lambda t: (trips.append(len(t)), real(t))[1])
+    real = spf.wait_counts
+    monkeypatch.setattr(spf, 'wait_counts', lambda h, *a: (trips.append(h.n), real(h, *a))[1])
     monkeypatch.setattr(torch, 'unique', lambda *a, **k: (_ for _ in ()).throw(AssertionError('torch.unique in the batched pass')))
     got = PV.prepare_geometry_many([(mk(b), 0.05, 0.05) for b in scenes])
     assert trips == [2, 2 * 5]                       # sizes of the two voxel sets; 4 levels + the range flag per network
@@ -232,3 +232,28 @@ def test_batched_geometry_pass_equals_the_level_by_level_one_in_two_round_trips(
         spf.DownsamplePyramid(bad, [2, 4]).finish(spf.read_counts(spf.DownsamplePyramid(bad, [2, 4]).counts()))
     ok = spf.DownsamplePyramid(torch.from_numpy(scenes[0]['coords']).cuda(), [2])
     assert ok.finish(spf.read_counts(ok.counts()))[(2, 2, 2)].shape[1] == 4          # the flag was cleared
+
+
+def test_counts_mailbox_delivers_posted_device_integers(hip):
+    """functional.post_counts / wait_counts (csrc/mailbox.hip): device integers (int64 and int32, views with storage offsets)
+    posted by one kernel into mapped host memory and polled by the host -- the values of the stream-ordered copy they replace
+    (torch.unique's size read in the reference, core/models/utils.py:20), for more posts than the ring has slots, for several
+    posts outstanding at once, from a side stream, and next to the A/B path (`U2MKD_COUNTS_MAILBOX=0`'s stack + tolist)."""
+    from u2mkd_amd.torchsparse.nn import functional as spf
+    base = torch.arange(1000, dtype=torch.int64, device='cuda') * 3
+    for r in range(150):                                   # (64 slots: the ring wraps twice)
+        ts_ = [base[r + i] if i % 2 else torch.tensor([r * 7 + i], dtype=torch.int32, device='cuda') for i in range(1 + r % 11)]
+        want = [int(t) for t in ts_]
+        assert spf.read_counts(ts_) == want
+    hs = [spf.post_counts([base[i], base[i + 1]]) for i in range(20)]
+    assert [spf.wait_counts(h) for h in reversed(hs)] == [[3 * i, 3 * i + 3] for i in reversed(range(20))]
+    assert spf.wait_counts(hs[0]) == [0, 3]                # (a second wait returns the kept values)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(20_000_000)                      # the producer is still running when the host starts to poll
+        x = torch.full((1,), 41, dtype=torch.int64, device='cuda') + 1
+        h = spf.post_counts([x])
+    assert spf.wait_counts(h) == [42]
+    assert spf.read_counts([]) == []
+    big = [base[i] for i in range(33)]                     # more than a slot holds: the copy path
+    assert spf.read_counts(big) == [3 * i for i in range(33)]

@@ -40,6 +40,11 @@ SIGNATURES = {
     'u2mkd_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_debug_conv_forward_sorted': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_stream_wait_stream': (C.c_int, [_p, _p]),
+    'u2mkd_sgd_chunk_elements': (_i32, []),
+    'u2mkd_sgd_batch': (C.c_int, [_p, _i32, _i64, _f32, _f32, _f32, _i32, _i32, _p]),
+    'u2mkd_mailbox_alloc': (_p, [_sz]),
+    'u2mkd_mailbox_free': (C.c_int, [_p]),
+    'u2mkd_mailbox_post': (C.c_int, [_p, C.c_uint32, _i32, _p, _i64, _p]),
     'u2mkd_conv_tiles_supported': (_i32, [_i32, _i32, _i32]),
     'u2mkd_conv_tiles_arith': (_i32, [_i32, _i32, _i32]),
     'u2mkd_weight_fragments_bytes': (_sz, [_i32, _i32, _i32, _i32]),

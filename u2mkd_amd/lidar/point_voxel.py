@@ -104,13 +104,17 @@ def prepare_geometry_staged(items):
         yield
         return [_prepare_geometry_level_by_level(x, pres, vres) for x, pres, vres in items]
     states = [_voxelize_issue(PointTensor(x.F, x.C.float()), pres, vres) for x, pres, vres in items]
+    # (the sizes are POSTED to the host mailbox by the slice that produces them and picked up by the next one: the host never
+    # waits on a copy queued behind other streams' work, spf.post_counts)
+    mail = spf.post_counts([st['cnt'] for st in states])
     yield
-    sizes = spf.read_counts([st['cnt'] for st in states])                      # round trip 1
+    sizes = spf.wait_counts(mail)                                              # round trip 1
     x0s = [_voxelize_finish(st, n) for st, n in zip(states, sizes)]
     totals = _level_strides(KMAP_SPECS)
     pyramids = [spf.DownsamplePyramid(x0.C, totals) if x0.C.shape[0] else None for x0 in x0s]
+    mail = spf.post_counts([c for p in pyramids if p is not None for c in p.counts()])
     yield
-    values = spf.read_counts([c for p in pyramids if p is not None for c in p.counts()])   # round trip 2
+    values = spf.wait_counts(mail)                                             # round trip 2
     out, at = [], 0
     for st, x0, pyr in zip(states, x0s, pyramids):
         if pyr is None:

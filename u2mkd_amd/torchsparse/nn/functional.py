@@ -317,11 +317,97 @@ def unique_sorted_deferred(keys):
     return buf, (pos[-1] if n else torch.zeros((), dtype=torch.int64, device=keys.device))
 
 
+# ---- host mailbox for the sizes the host has to know (csrc/mailbox.hip) -----------------------------------------------------
+# U2MKD_COUNTS_MAILBOX=0: every read is a stream-ordered device-to-host copy + stream synchronisation (rounds 1-5; A/B runs)
+_MAILBOX_ON = os.environ.get('U2MKD_COUNTS_MAILBOX', '1') != '0'
+_MAIL_SLOTS, _MAIL_WORDS = 64, 32          # a ring of slots of 32 words, one per value: (sequence number << 32) | value
+_MAIL = {}                                 # 'mem': numpy view of the ring, 'base': its address, 'seq': last sequence number
+
+
+def _mailbox():
+    if not _MAIL:
+        import ctypes
+        import numpy as np
+        nbytes = _MAIL_SLOTS * _MAIL_WORDS * 8
+        base = L.load().u2mkd_mailbox_alloc(nbytes)
+        if not base:
+            raise RuntimeError('u2mkd_mailbox_alloc failed: ' + L.load().u2mkd_last_error().decode('utf-8', 'replace'))
+        _MAIL['base'] = base
+        _MAIL['mem'] = np.ctypeslib.as_array((ctypes.c_uint64 * (_MAIL_SLOTS * _MAIL_WORDS)).from_address(base))
+        _MAIL['seq'] = 0
+        _MAIL['ptrs'] = (ctypes.c_void_p * 32)()
+    return _MAIL
+
+
+class _PostedCounts:
+    """Handle of :func:`post_counts`: the values are on their way to the host."""
+    __slots__ = ('n', 'at', 'seq', 'tensors', 'stream', 'values')
+
+
+def post_counts(tensors):
+    """ISSUE side of a host read of several 0-d / 1-element device integers: one small kernel on the current stream stores them
+    into mapped host memory (u2mkd_mailbox_post) -- queue it right behind their producers; :func:`wait_counts` later polls for
+    them.  Unlike a stream-ordered copy issued at the time of the read, nothing here waits for what OTHER streams that share
+    the hardware queue have queued in between (NOTES N10)."""
+    h = _PostedCounts()
+    h.tensors = list(tensors)
+    h.n = len(h.tensors)
+    h.values = None
+    if h.n == 0:
+        h.values = []
+        return h
+    if not (_MAILBOX_ON and h.n <= 32 and all(t.is_cuda and t.numel() == 1 and t.dtype in (torch.int64, torch.int32) for t in h.tensors)):
+        h.seq = None                  # (CPU tensors, the A/B switch: the stream-ordered copy at wait time)
+        return h
+    m = _mailbox()
+    m['seq'] += 1
+    h.seq = m['seq']
+    h.at = (h.seq % _MAIL_SLOTS) * _MAIL_WORDS
+    is64 = 0
+    for i, t in enumerate(h.tensors):
+        m['ptrs'][i] = t.data_ptr()
+        if t.dtype == torch.int64:
+            is64 |= 1 << i
+    h.stream = torch.cuda.current_stream()
+    import ctypes
+    L.call('u2mkd_mailbox_post', ctypes.addressof(m['ptrs']), is64, h.n, m['base'] + h.at * 8, h.seq, L.stream())
+    return h
+
+
+def wait_counts(h, timeout_s=60.0):
+    """HOST side: the values of :func:`post_counts` as Python ints (polls the mailbox's sequence word)."""
+    if h.values is not None:
+        return h.values
+    if h.seq is None:
+        h.values = torch.stack([t.reshape(()).to(torch.int64) for t in h.tensors]).tolist()
+        return h.values
+    # word i = (seq << 32) | value: ready when its upper half is this post's sequence number (csrc/mailbox.hip)
+    words = _MAIL['mem'][h.at:h.at + h.n]
+    tag = h.seq & 0xffffffff
+    if not bool(((words >> 32) == tag).all()):
+        import time
+        t0, spins = time.perf_counter(), 0
+        while not bool(((words >> 32) == tag).all()):
+            spins += 1
+            if spins & 255 == 0:
+                if time.perf_counter() - t0 > timeout_s:
+                    h.stream.synchronize()          # (raises if the producing stream faulted)
+                    if not bool(((words >> 32) == tag).all()):
+                        raise RuntimeError('wait_counts: the mailbox was not written (sequence %d)' % h.seq)
+                time.sleep(0)
+    h.values = [int(w) & 0xffffffff for w in words]
+    if 0xffffffff in h.values:
+        raise OverflowError('wait_counts: a posted value is outside [0, 2^32 - 2]')
+    h.tensors = None
+    return h.values
+
+
 def read_counts(tensors):
-    """One host round trip for a list of 0-d / 1-element device integers."""
+    """One host round trip for a list of 0-d / 1-element device integers (issue + wait; a caller with other host work in
+    between calls :func:`post_counts` / :func:`wait_counts` itself)."""
     if not tensors:
         return []
-    return torch.stack([t.reshape(()).to(torch.int64) for t in tensors]).tolist()
+    return wait_counts(post_counts(tensors))
 
 
 class DownsamplePyramid:

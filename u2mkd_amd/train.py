@@ -13,6 +13,7 @@ from . import distributed as D
 from . import kd as KD
 from . import torchsparse as ts
 from .losses import MixLovaszCrossEntropy
+from .optim import FusedSGD
 
 __all__ = ['cosine_schedule_with_warmup', 'make_optimizer', 'LidarStep', 'KDStep', 'TeacherWatch', 'kd_batch_to_device', 'pin_kd_batch', 'fresh_batch', 'state_dict',
            'load_state_dict', 'load_weights']
@@ -43,15 +44,15 @@ def make_optimizer(params, lr=0.24, momentum=0.9, weight_decay=1.0e-4, name='sgd
         blocks = [p for n, p in named if 'transformer_block' in n]
         if name == 'sgd_spformer':
             common = dict(momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
-            return torch.optim.SGD([dict(params=rest, lr=lr, **common), dict(params=blocks, lr=lr * 0.1, **common)],
-                                   lr=lr, **common)
+            return FusedSGD([dict(params=rest, lr=lr, **common), dict(params=blocks, lr=lr * 0.1, **common)],
+                            lr=lr, **common)
         return torch.optim.AdamW([dict(params=rest, lr=lr, weight_decay=weight_decay),
                                   dict(params=blocks, lr=lr * transformer_lr_scale, weight_decay=weight_decay)],
                                  lr=lr, weight_decay=weight_decay)
     if isinstance(params, torch.nn.Module):
         params = params.parameters()
     if name == 'sgd':
-        return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+        return FusedSGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
     if name == 'adam':
         return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay)
     if name == 'adamw':
