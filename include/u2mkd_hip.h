@@ -798,6 +798,20 @@ int u2mkd_bn2d_backward_apply(const float *dy, const float *x, const float *res,
                               const float *beta, int32_t relu, const float *sums /*[2c] over all ranks*/, float *dx,
                               float *dres /*or NULL*/, u2mkd_stream_t s);
 
+/* ---- sptr window attention, tile form (csrc/sptr_tiles.hip) ---------------------------------------------------------------
+ * u2mkd_sptr_attention_forward_strided's function and arguments (same reference kernels replaced: rpe/
+ * relative_pos_encoding_cuda_kernel.cu:42-274, attention/attention_cuda_kernel.cu:4-112, sptr/utils.py:80-95) evaluated on
+ * 16 x 16 (query, key) tiles: q . k and P V on v_mfma_f32_16x16x4_f32, the relative-position terms from per-token strips
+ * q_i . Tq[r][ax], k_j . Tk[r][ax] (a pre-pass into `workspace`, u2mkd_sptr_tiles_workspace_bytes(n, h) bytes) by look-up,
+ * the value tables through a per-query histogram.  Same out / lse; results differ from the per-pair kernels by rounding
+ * (the table terms are summed in a different order). */
+size_t u2mkd_sptr_tiles_workspace_bytes(int64_t n, int32_t h);
+int u2mkd_sptr_attention_forward_tiles(const float *q, const float *k, const float *v, int64_t ld_qkv, float q_scale,
+                                       const int32_t *sort_idx, const int32_t *wstart, const int32_t *wlen, const int32_t *qc,
+                                       const float *radial, const float *tq, const float *tk, const float *tv, int32_t L,
+                                       int32_t qgl, float split_a, int64_t n, int32_t h, int32_t hdim, float *out, int64_t ld_out,
+                                       float *lse, void *workspace, size_t workspace_bytes, u2mkd_stream_t s);
+
 /* ---- optimizer (csrc/optim.hip) --------------------------------------------------------------------------------------
  * torch.optim.SGD(momentum, nesterov, weight_decay) -- core/builder.py:663-669 -- over all parameters of a group in one launch,
  * element for element the operations and roundings of torch's multi-tensor path (torch/optim/sgd.py:_multi_tensor_sgd).

@@ -76,6 +76,44 @@ def test_window_attention_fwd_bwd(hip, sphere, window, quant, h):
         assert _rel(x.grad, y.grad) < 1e-4, name
 
 
+@pytest.mark.parametrize('sphere,window,quant,h,n', [
+    (True, [16.0, 16.0, 120.0], [16 / 24, 16 / 24, 5.0], 3, 3000),       # large spherical windows: many full 16 x 16 tiles
+    (True, [4.0, 4.0, 120.0], [16 / 12, 16 / 12, 5.0], 2, 3000),
+    (True, [16.0, 16.0, 120.0], [16 / 12, 16 / 12, 5.0], 16, 1500),
+    (False, [0.6, 0.6, 0.6], [0.025, 0.025, 0.025], 3, 3000),            # cubic windows of a few tokens: tiles mostly masked
+    (False, [2.4, 2.4, 2.4], [0.1, 0.1, 0.1], 8, 1501),                  # (a token count that is not a multiple of 16)
+    (True, [16.0, 16.0, 120.0], [16 / 24, 16 / 24, 5.0], 1, 7),          # fewer tokens than one tile
+])
+def test_tile_form_of_the_forward_equals_the_oracle_and_the_per_pair_kernels(hip, monkeypatch, sphere, window, quant, h, n):
+    """csrc/sptr_tiles.hip (U2MKD_SPTR_TILES: 16 x 16 score tiles on v_mfma_f32_16x16x4_f32, relative-position terms from
+    per-token strips by look-up, value tables through a per-query histogram) against the CPU oracle (sptr's dataflow,
+    <= 1e-5) and against the per-pair kernels of csrc/sptr.hip on the same plan (outputs and log-sum-exp <= 1e-5; the
+    backward, which reads the saved log-sum-exp, gives the same gradients <= 1e-5)."""
+    from u2mkd_amd import sptr
+    from u2mkd_amd.sptr import functional as SF
+    d, qgl = 16, 24
+    L = 2 * qgl if sphere else 2 * qgl - 1
+    a = 0.0125 if sphere else None
+    xyz, b = _tokens(n, 5, sphere=sphere)
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
+    tq, tk, tv = (0.3 * torch.randn(L, 3, h, d, generator=g) for _ in range(3))
+    go = torch.randn(n, h, d, generator=g)
+    i0, i0o, n_max, i1, i1o, sort_idx = S.get_indices_params(xyz, b, np.array(window))
+    ref = S.sparse_self_attention(q, k, v, xyz, i0, i0o, n_max, i1, i1o, sort_idx, np.array(window), np.array(quant), qgl, tq, tk, tv, a)
+    res = {}
+    for mode in ('0', 'all'):
+        monkeypatch.setattr(SF, '_TILES', mode)
+        leaves = [t.clone().cuda().requires_grad_(True) for t in (q, k, v, tq, tk, tv)]
+        plan = sptr.WindowPlan(xyz.cuda(), b.cuda(), np.array(window))
+        out = sptr.window_attention(*leaves[:3], xyz.cuda(), plan, np.array(quant), qgl, *leaves[3:], a)
+        out.backward(go.cuda())
+        res[mode] = [out.detach()] + [t.grad for t in leaves]
+    assert _rel(res['all'][0].cpu(), ref) < 1e-5
+    for x, y in zip(res['all'], res['0']):
+        assert _rel(x, y.cpu()) < 1e-5
+
+
 def test_reference_api_signature(hip):
     """The four names spherical_transformer.py:7 imports, called the way it calls them."""
     from functools import partial

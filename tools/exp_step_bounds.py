@@ -36,6 +36,29 @@ if 'half_res_tail' in flags:      # the pixel head evaluated on the H/2 map (no 
     pb = model.model_s.pix_branch
     fu = pb.forward_up
     pb.forward_up = lambda feats, im_size=None: fu(feats, im_size=None)
+if 'no_sptr' in flags or 'no_sptr_student' in flags:      # window attention replaced by its value rows (differentiable, ~free): the upper bound of a faster attention kernel
+    from u2mkd_amd import sptr as _sp
+    from u2mkd_amd.lidar import sphereformer as _sf
+    _real_pwa = _sp.packed_window_attention
+
+    def _cheap(qkv, scale, branches):
+        if 'no_sptr_student' in flags and not torch.is_grad_enabled():
+            return _real_pwa(qkv, scale, branches)                 # (the frozen teacher keeps the real kernels)
+        return qkv[:, 2].reshape(qkv.shape[0], -1) * 1.0
+    _sp.packed_window_attention = _cheap
+    _sf.sptr.packed_window_attention = _cheap
+if 'no_lidar_bn' in flags:      # BatchNorm over voxel / point rows as identity (+ ReLU): the upper bound of folding it into its neighbours
+    from u2mkd_amd.torchsparse.nn import functional as _spf
+    _real_bn = _spf.batch_norm
+
+    def _bn(x, bn, relu=False, residual=None):
+        if not bn.training:
+            return _real_bn(x, bn, relu, residual)
+        y = x if residual is None else x + residual
+        return torch.relu(y) if relu else y * 1.0
+    _spf.batch_norm = _bn
+    from u2mkd_amd.lidar import blocks as _bl
+    _bl.spf.batch_norm = _bn
 run = T.KDStep(model, num_epochs=50, batch_size=1)
 run.train_mode()
 res = [T.kd_batch_to_device(synth_kd_batch(80000, 1, seed=1234 + i, image_hw=(360, 640))) for i in range(4)]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
-args = bench.parse()
+args = bench.parse()      # (host_phases.py --voxels 3000 --image-hw 64 112: the host floor, a scene too small to load the GPU)
 args.steps, args.warmup = 16, 6
 step, n_pts, desc = bench.build_step(args, 0, 'kd', args.image_hw)
 run = step.runner
@@ -26,6 +26,24 @@ def timed(obj, name, label):
 
 
 timed(run.model, 'prepare', 'geometry of the next batch (incl. blocking reads)')
+from u2mkd_amd.torchsparse.nn import functional as spf
+import u2mkd_amd.train as T0
+timed(spf, 'wait_counts', '  of which: waiting for posted sizes (wait_counts)')
+_slice = [0]
+_real_adv = T0._advance_geometry
+
+
+def _adv(*a, **k):
+    t0 = time.perf_counter()
+    try:
+        return _real_adv(*a, **k)
+    finally:
+        lab = 'geometry slice %d (launches + its read)' % (_slice[0] % 3 + 1)
+        _slice[0] += 1
+        acc[lab] = acc.get(lab, 0.0) + time.perf_counter() - t0
+
+
+T0._advance_geometry = _adv
 timed(run.model.model_t, 'forward', 'teacher forward issue')
 timed(run.model.model_s, 'forward', 'student forward issue (incl. camera)')
 timed(run.amp, 'backward_and_step', 'backward + optimizer issue')

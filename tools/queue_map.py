@@ -15,7 +15,7 @@ from u2mkd_amd import deferred
 print('GPU_MAX_HW_QUEUES =', os.environ.get('GPU_MAX_HW_QUEUES'))
 torch.cuda.init()
 main = torch.cuda.current_stream()
-roles = ['teacher', 'camera', 'sparse_wgrad', 'geo']
+roles = sys.argv[1:] or ['geo', 'camera', 'teacher', 'sparse_wgrad']      # (creation order = the order a KD step first uses them)
 streams = {'main': main}
 for r in roles:
     streams[r] = deferred.stream(0, r)

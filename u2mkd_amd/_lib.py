@@ -129,6 +129,8 @@ SIGNATURES = {
     'u2mkd_sptr_attention_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_sptr_backward_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'u2mkd_sptr_attention_backward': (C.c_int, [_p] * 14 + [_i32, _i32, _f32, _i32, _i64, _i32, _i32] + [_p, _p, _sz] + [_p] * 7),
+    'u2mkd_sptr_tiles_workspace_bytes': (_sz, [_i64, _i32]),
+    'u2mkd_sptr_attention_forward_tiles': (C.c_int, [_p, _p, _p, _i64, _f32] + [_p] * 8 + [_i32, _i32, _f32, _i64, _i32, _i32, _p, _i64, _p, _p, _sz, _p]),
     'u2mkd_sptr_attention_forward_strided': (C.c_int, [_p, _p, _p, _i64, _f32] + [_p] * 8 + [_i32, _i32, _f32, _i64, _i32, _i32, _p, _i64, _p, _p]),
     'u2mkd_sptr_attention_backward_strided': (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _i64] + [_p] * 9 + [_i32, _i32, _f32, _i32, _i64, _i32, _i32]
                                               + [_p, _p, _sz] + [_p, _p, _p, _i64, _p, _p, _p, _p]),

@@ -63,7 +63,37 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f'[u2mkd_amd.build] linked {LIB}')
     elif verbose:
         print(f'[u2mkd_amd.build] up to date: {LIB}')
+    build_host(force=force or rebuilt, verbose=verbose)
     return LIB
+
+
+HOST_SRC = os.path.join(HERE, 'csrc_host', 'host_ops.cpp')
+HOST_LIB = os.path.join(LIBDIR, '_u2mkd_host.so')
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """lib/_u2mkd_host.so: the C++ host side of the hottest operators (csrc_host/host_ops.cpp), a CPython extension over
+    libtorch and libu2mkd_hip.so.  Host code only: g++ (no device code in it)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    newest = max(os.path.getmtime(HOST_SRC), os.path.getmtime(os.path.join(os.path.dirname(HERE), 'include', 'u2mkd_hip.h')))
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= newest:
+        if verbose:
+            print(f'[u2mkd_amd.build] up to date: {HOST_LIB}')
+        return HOST_LIB
+    abi = int(bool(getattr(torch._C, '_GLIBCXX_USE_CXX11_ABI', True)))
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+           '-DHIPBLAS_V2', '-DTORCH_EXTENSION_NAME=_u2mkd_host', f'-D_GLIBCXX_USE_CXX11_ABI={abi}', '-DTORCH_API_INCLUDE_EXTENSION_H',
+           *[f'-I{p}' for p in ce.include_paths()], '-I/opt/rocm/include', '-I' + sysconfig.get_paths()['include'],
+           HOST_SRC, '-o', HOST_LIB, *[f'-L{p}' for p in ce.library_paths()], '-lc10', '-lc10_hip', '-ltorch', '-ltorch_cpu',
+           '-ltorch_hip', '-ltorch_python', f'-L{LIBDIR}', '-lu2mkd_hip', '-Wl,-rpath,$ORIGIN']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'host extension build failed:\n{r.stdout}\n{r.stderr}')
+    if verbose:
+        print(f'[u2mkd_amd.build] built {HOST_LIB}')
+    return HOST_LIB
 
 
 if __name__ == '__main__':

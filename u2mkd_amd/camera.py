@@ -60,13 +60,14 @@ class MaxPool3x3s2(nn.MaxPool2d):
 
 
 _UP_TAPS = {}
-# U2MKD_UP_BILINEAR: 1 = the decoder's up-samplings on csrc/pixhead.hip (gathering, run-to-run reproducible backward),
-# 0 = torch's kernels (backward scatters with float atomics), auto (default) = 1 exactly when
-# torch.use_deterministic_algorithms(True) is set -- torch's backward refuses to run then.  Measured on one box, three
-# pairs: the HIP kernels take 1.1 ms less kernel time per KD step (forward 135-450 us -> 14-180 us per call, backward
-# 215 -> 131 us) and the step is 0.3-0.4 ms SLOWER (74.4-74.7 vs 74.1-74.4 ms): the camera stream is not the critical
-# one and its earlier finish only moves the overlap, so the default keeps torch's kernels.
-_UP_MODE = os.environ.get('U2MKD_UP_BILINEAR', 'auto')
+# U2MKD_UP_BILINEAR: 1 (default since round 6) = the decoder's up-samplings on csrc/pixhead.hip (gathering, run-to-run
+# reproducible backward), 0 = torch's kernels (backward scatters with float atomics), auto = 1 exactly when
+# torch.use_deterministic_algorithms(True) is set -- torch's backward refuses to run then.  The HIP kernels take 1.1 ms less
+# kernel time per KD step (forward 135-450 us -> 14-180 us per call, backward 215 -> 131 us).  Round 4 measured the step 0.3-0.4 ms
+# SLOWER with them (74.4-74.7 vs 74.1-74.4 ms) and kept torch's; in round 6 the step is bound by the GPU in both phases and the
+# same switch reads 62.76 / 62.91 / 63.04 against 63.15 / 63.08 / 63.02 ms (three same-box pairs): small, in the right direction,
+# and the backward is reproducible -- so they are the default now.
+_UP_MODE = os.environ.get('U2MKD_UP_BILINEAR', '1')
 _UP_HIP = None if _UP_MODE == 'auto' else _UP_MODE != '0'
 
 

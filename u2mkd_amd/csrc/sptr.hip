@@ -15,10 +15,10 @@
 // backward recomputes the scores from the saved log-sum-exp.  Table gradients are
 // accumulated in LDS and flushed once per workgroup.
 #include "common.h"
+#include "sptr_internal.h"
 
 namespace u2mkd {
 
-constexpr int kHd = 16;        // head dim (asserted by the reference, sptr/functional.py:355)
 constexpr int kTabRow = 20;    // LDS floats per table row (16 + 4 pad against bank conflicts)
 constexpr int kSptrThreads = 128;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -184,45 +184,6 @@ __global__ void quant_coords_kernel(const float *__restrict__ xyz, const int32_t
         qc[p * 3 + d] = (int32_t)div_floor(m, qs[d]);
     }
     if (radial) radial[p] = xyz[t * 3 + 2];
-}
-
-// spherical_transformer.py:39-64 exponential_split on d = r_query - r_key
-__device__ __forceinline__ int exp_split(float d, float a) {
-    float da = fabsf(d);
-    float flag = d >= 0.f ? 1.f : 0.f;
-    float idx = 2.f * floorf(logf((da + 2.f * a) / a) / 0.6931471805599453f) - 2.f;
-    float half = floorf(idx / 2.f);
-    idx = idx + (((3.f * exp2f(half) - 2.f) * a <= da) ? 1.f : 0.f);
-    idx = idx * (2.f * flag - 1.f) + (flag - 1.f);
-    return (int)idx + 24;
-}
-
-// row strides (floats) of the token-major operands and the scale applied to q on load: lets the kernels read q, k, v
-// straight out of the packed [N, 3, H, 16] output of the qkv projection (one branch = a range of heads), write the
-// heads of a branch into their columns of the [N, H * 16] attention output, and the gradients into a packed
-// [N, 3, H, 16] buffer -- without the slice / scale / concatenate copies around them
-struct SptrLayout {
-    int64_t ld_qkv, ld_out, ld_grad;
-    float q_scale;
-};
-
-struct RelCtx {
-    int qgl;        // quant_grid_length
-    float a;        // > 0: spherical branch (exponential radial split + clamp)
-};
-
-__device__ __forceinline__ void rel_rows(const RelCtx &c, const int qi[3], float ri, const int qj[3], float rj,
-                                         int r[3]) {
-    r[0] = qi[0] - qj[0] + c.qgl - 1;
-    r[1] = qi[1] - qj[1] + c.qgl - 1;
-    r[2] = qi[2] - qj[2] + c.qgl - 1;
-    if (c.a > 0.f) {
-        r[2] = exp_split(ri - rj, c.a);
-        const int hi = 2 * c.qgl - 1;
-        r[0] = min(max(r[0], 0), hi);
-        r[1] = min(max(r[1], 0), hi);
-        r[2] = min(max(r[2], 0), hi);
-    }
 }
 
 // s_tab: [3 tables][L][3][kTabRow]
@@ -762,6 +723,15 @@ sptr_bwd_key_body(const float *__restrict__ q, const float *__restrict__ k, cons
     hist_store_slab<NT>(slab, table_of, L, lane, acc);
 }
 
+// Waves per SIMD the backward kernels are compiled for.  Everything in registers (256 + 88 accumulator registers) is one
+// wave per SIMD; S = 16 -- the spherical branch at the coarsest stride: windows of hundreds of tokens, the longest launch of the
+// student's backward -- gains 25 % from two waves (<= 256 registers, ~200 bytes of scratch per lane: 1.37-1.58 -> 1.04-1.07 ms
+// in the step), the other splits do not (round 6, NOTES N10.7).  -DU2MKD_SPTR_BWD_WPE=n forces n everywhere (A/B builds).
+#if defined(U2MKD_SPTR_BWD_WPE)
+#define U2_SPTR_BWD_BOUNDS __launch_bounds__(kSptrThreads, U2MKD_SPTR_BWD_WPE)
+#else
+#define U2_SPTR_BWD_BOUNDS __launch_bounds__(kSptrThreads, (S == 16 ? 2 : 1))
+#endif
 #define U2_SPTR_BWD_IN                                                                                                   \
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ dout,  \
         const float *__restrict__ lse, const float *__restrict__ delta, const int32_t *__restrict__ sort_idx,             \
@@ -771,13 +741,13 @@ sptr_bwd_key_body(const float *__restrict__ q, const float *__restrict__ k, cons
 #define U2_SPTR_BWD_PASS q, k, v, dout, lse, delta, sort_idx, wstart, wlen, qc, radial, tq, tk, tv, L, rc, n, h
 
 template <int S>
-__global__ void __launch_bounds__(kSptrThreads)
+__global__ void U2_SPTR_BWD_BOUNDS
 sptr_bwd_query_kernel(U2_SPTR_BWD_IN, float *__restrict__ dq, float *__restrict__ slabs, SptrLayout ly) {
     sptr_bwd_query_body<S>(U2_SPTR_BWD_PASS, dq, slabs, ly);
 }
 
 template <int S>
-__global__ void __launch_bounds__(kSptrThreads)
+__global__ void U2_SPTR_BWD_BOUNDS
 sptr_bwd_key_kernel(U2_SPTR_BWD_IN, float *__restrict__ dk, float *__restrict__ dv, float *__restrict__ slabs, SptrLayout ly) {
     sptr_bwd_key_body<S>(U2_SPTR_BWD_PASS, dk, dv, slabs, ly);
 }
@@ -787,7 +757,7 @@ sptr_bwd_key_kernel(U2_SPTR_BWD_IN, float *__restrict__ dk, float *__restrict__ 
 // (the spherical branch at the coarse strides: 128 workgroups x heads of 2 waves, ~40 KB of LDS each) one role alone leaves
 // most of the chip idle: launched one behind the other they were the longest kernels of the student's backward chain.
 template <int S>
-__global__ void __launch_bounds__(kSptrThreads)
+__global__ void U2_SPTR_BWD_BOUNDS
 sptr_bwd_both_kernel(U2_SPTR_BWD_IN, float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv,
                      float *__restrict__ slabs, SptrLayout ly) {
     if (blockIdx.z == 0) sptr_bwd_query_body<S>(U2_SPTR_BWD_PASS, dq, slabs, ly);

@@ -99,6 +99,16 @@ OWNERS = set()        # ids of the leaves whose gradient was issued on a side st
 # the same ~120 ms cliff with a priority stream).  Deferred gradient work therefore borrows a stream that is idle during the
 # backward: the frozen teacher's (kd._side_stream), which only works during the forward.
 _ALIAS = {'camera_wgrad': 'teacher'}
+# U2MKD_GEO_STREAM: which stream carries the next batch's geometry slices.  'own' (rounds 3-5): a fifth stream -- on the
+# runtime's four hardware queues it SHARES a queue with the main stream, whose barrier packets (the joins with the camera
+# stream at every fusion point) then hold the slices' kernels back: the host's first size read waited ~14 ms per step for a
+# slice queued 30 ms earlier (NOTES N10).  'sparse_wgrad' / 'teacher' / 'camera' put the slices on that role's stream instead
+# (four streams, four queues, nobody shares): the wait disappears from the read and the same time reappears spread over
+# every launch call of the step -- the step is bound by the GPU, the host is merely held wherever it runs ahead (measured: 64.4
+# vs 64.2-64.5 ms in same-box pairs) -- so the default stays 'own'.
+_GEO = _os.environ.get('U2MKD_GEO_STREAM', 'own')
+if _GEO != 'own':
+    _ALIAS['geo'] = _GEO
 
 
 def stream(device_index: int, role: str) -> torch.cuda.Stream:

@@ -113,6 +113,29 @@ class WindowPlan:
         return int(self.wlen.max().item()) if self.n else 0
 
 
+# U2MKD_SPTR_TILES: which branches run the TILE form of the forward (csrc/sptr_tiles.hip: 16 x 16 score tiles on the matrix pipe,
+# relative-position terms by look-up) instead of the one-thread-per-(token, head) kernels of csrc/sptr.hip.  'sphere': the
+# spherical branch, whose windows hold tens to hundreds of tokens; 'all': the cubic branch too (windows of 4-9 tokens: the tiles
+# are mostly masked); '0' (default): none.  The tile form is verified (tests/test_gpu_sptr.py runs it) and was MEASURED SLOWER in
+# round 6 (one wave per 16 queries, strips re-read per tile: 3.5 -> 6.5 ms of forward launches per KD step, NOTES N10.6): it stays
+# as the tested starting point of that formulation, off by default.
+_TILES = os.environ.get('U2MKD_SPTR_TILES', '0')
+
+
+def _attention_forward(q, k, v, ld_qkv, q_scale, plan, qc, radial, tq, tk, tv, tl, qgl, split_a, n, h, d, out, ld_out, lse, st):
+    """One branch's forward on row-strided operands (q, k, v: views whose first element is the branch's first head)."""
+    if _TILES == 'all' or (_TILES == 'sphere' and split_a > 0):
+        nbytes = L.load().u2mkd_sptr_tiles_workspace_bytes(n, h)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=out.device)
+        L.call('u2mkd_sptr_attention_forward_tiles', L.ptr(q), L.ptr(k), L.ptr(v), ld_qkv, q_scale, L.ptr(plan.sort_idx),
+               L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(qc), L.ptr(radial), L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, qgl, split_a,
+               n, h, d, L.ptr(out), ld_out, L.ptr(lse), L.ptr(ws), nbytes, st)
+        return
+    L.call('u2mkd_sptr_attention_forward_strided', L.ptr(q), L.ptr(k), L.ptr(v), ld_qkv, q_scale, L.ptr(plan.sort_idx),
+           L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(qc), L.ptr(radial), L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, qgl, split_a,
+           n, h, d, L.ptr(out), ld_out, L.ptr(lse), st)
+
+
 class WindowAttentionFunction(Function):
     @staticmethod
     def forward(ctx, q, k, v, tq, tk, tv, plan, qc, radial, qgl, split_a, qc_span=0):
@@ -130,9 +153,8 @@ class WindowAttentionFunction(Function):
             raise RuntimeError(f'relative position tables must be [L,3,{h},{d}], got {tuple(tq.shape)}')
         out = torch.empty_like(q)
         lse = torch.empty(n, h, dtype=torch.float32, device=q.device)
-        L.call('u2mkd_sptr_attention_forward', L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(plan.sort_idx), L.ptr(plan.wstart),
-               L.ptr(plan.wlen), L.ptr(qc), L.ptr(radial), L.ptr(tq), L.ptr(tk), L.ptr(tv), tl, int(qgl),
-               float(split_a), n, h, d, L.ptr(out), L.ptr(lse), L.stream())
+        _attention_forward(q, k, v, h * d, 1.0, plan, qc, radial, tq, tk, tv, tl, int(qgl), float(split_a), n, h, d, out, h * d, lse,
+                           L.stream())
         ctx.save_for_backward(q, k, v, out, lse, tq, tk, tv, qc, radial if radial is not None else q.new_empty(0))
         ctx.plan, ctx.qgl, ctx.split_a, ctx.has_radial = plan, int(qgl), float(split_a), radial is not None
         ctx.qc_span = int(qc_span)
@@ -198,10 +220,8 @@ class PackedAttentionFunction(Function):
             if n == 0 or h == 0:
                 continue
             plan = br['plan']
-            L.call('u2mkd_sptr_attention_forward_strided', L.ptr(qkv[:, 0, h0:]), L.ptr(qkv[:, 1, h0:]), L.ptr(qkv[:, 2, h0:]),
-                   3 * H * d, float(scale), L.ptr(plan.sort_idx), L.ptr(plan.wstart), L.ptr(plan.wlen), L.ptr(br['qc']),
-                   L.ptr(br['radial']), L.ptr(tq), L.ptr(tk), L.ptr(tv), tq.shape[0], int(br['qgl']), float(br['split_a']),
-                   n, h, d, L.ptr(out[:, h0:]), H * d, L.ptr(lse), st)
+            _attention_forward(qkv[:, 0, h0:], qkv[:, 1, h0:], qkv[:, 2, h0:], 3 * H * d, float(scale), plan, br['qc'], br['radial'],
+                               tq, tk, tv, tq.shape[0], int(br['qgl']), float(br['split_a']), n, h, d, out[:, h0:], H * d, lse, st)
         ctx.save_for_backward(qkv, out, *lses, *tables)
         ctx.branches, ctx.scale = branches, float(scale)
         return out.view(n, H * d)

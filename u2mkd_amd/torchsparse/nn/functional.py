@@ -21,10 +21,21 @@ import weakref
 import torch
 from torch.autograd import Function
 
+from ... import _host
 from ... import _lib as L
 from ..tensor import SparseTensor
 from ..utils import make_ntuple
 from .utils import get_kernel_offsets
+
+_HOST = False          # lib/_u2mkd_host.so (C++ host side of the hottest operators) once loaded; None: U2MKD_HOST_OPS=0
+
+
+def host_ops():
+    global _HOST
+    if _HOST is False:
+        _HOST = _host.ops()
+    return _HOST
+
 
 __all__ = ['sphash', 'sphashquery', 'spcount', 'spvoxelize', 'spdevoxelize', 'calc_ti_weights',
            'spdownsample', 'conv3d', 'KernelMap', 'HashTable', 'ti_weights_n8', 'batch_norm']
@@ -1633,4 +1644,9 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
         return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1], residual, counter)
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
+    h = _HOST if _HOST is not False else host_ops()
+    if h is not None and x.dtype == torch.float32 and x.is_cuda and x.shape[0] > 0 and not bf16_rows() \
+            and (residual is None or residual.dtype == torch.float32):
+        # the same pass with its host side in C++ (csrc_host/host_ops.cpp: BatchNormRows)
+        return h.batch_norm_rows(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual)
     return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual)
