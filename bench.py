@@ -450,8 +450,8 @@ else:
         y = cam(img)
         y = y[0] if isinstance(y, (tuple, list)) else y
         y.float().mean().backward()
-    parts = {'teacher_fwd_s': med(t_fwd, 1, warm=0), 'student_lidar_fwd_bwd_s': med(s_step, 1, warm=0),
-             'swiftnet_one_camera_fwd_bwd_s': med(c_step, 1, warm=0)}
+    parts = {'teacher_fwd_s': med(t_fwd, 3), 'student_lidar_fwd_bwd_s': med(s_step, 3),
+             'swiftnet_one_camera_fwd_bwd_s': med(c_step, 3)}
     t0 = time.perf_counter(); opt.step(); parts['sgd_s'] = time.perf_counter() - t0
     out['parts'] = parts
     out['step_s'] = parts['teacher_fwd_s'] + parts['student_lidar_fwd_bwd_s'] + 6 * parts['swiftnet_one_camera_fwd_bwd_s'] + parts['sgd_s']
@@ -480,8 +480,8 @@ def cpu_baseline_leg(args, timeout_s=480):
         sample = ('training step (fwd + Lovasz/CE + bwd + SGD) of SPVCNN cr=%g on one %d-voxel synthetic scene, CPU oracle, '
                   '%d threads, median of 3 after 1 warm-up' % (args.cr, n_vox, threads))
     base = {'value': None, 'unit': 'points/s', 'cores': threads, 'kind': 'port',
-            'kind_note': 'composite of separately timed parts, one un-warmed repetition each; a lower bound on the CPU time '
-                         '(= an upper bound on CPU points/s): fusion MLPs and KD loss terms are not in it'}
+            'kind_note': 'composite of separately timed parts, each the median of 3 repetitions after 1 warm-up; a lower bound on '
+                         'the CPU time (= an upper bound on CPU points/s): fusion MLPs and KD loss terms are not in it'}
     try:
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
         o = json.loads(r.stdout.strip().splitlines()[-1])
@@ -600,9 +600,9 @@ def build_step(args, rank, workload, image_hw, sweeps=None, dtype=None, voxels=N
         # Software pipelining: the copy of batch i+1 is made inside step i and its geometry (voxel sets, kernel
         # maps: the host synchronisations) is prepared between step i's forward and backward (KDStep prefetch=);
         # every batch's geometry is built exactly once, inside the timed loop.
-        d = nxt[0] if nxt[0] is not None else fresh(resident[counter[0] % n_batches])
+        d = nxt[0] if nxt[0] is not None else dict(fresh(resident[counter[0] % n_batches]), _key=counter[0] % n_batches)
         counter[0] += 1
-        nxt[0] = fresh(resident[counter[0] % n_batches]) if prefetch else None
+        nxt[0] = dict(fresh(resident[counter[0] % n_batches]), _key=counter[0] % n_batches) if prefetch else None
         return runner(d, prefetch=nxt[0])
     step.runner = runner
     return step, n_pts, desc

@@ -33,10 +33,10 @@ t0 = time.time()
 torch.cuda.reset_peak_memory_stats()
 sizes = [int(rng.choice([2000, 9000, 30000, 80000])) for _ in range((int(sys.argv[2]) if len(sys.argv) > 2 else 30) + 1)]
 batches = [T.kd_batch_to_device(synth_kd_batch(n, 1, seed=100 + i, image_hw=(360, 640))) for i, n in enumerate(sizes[:6])]
-cur = T.fresh_batch(batches[0])
+cur = dict(T.fresh_batch(batches[0]), _key=0)
 watch = T.TeacherWatch(kd_model.model_t)     # the frozen teacher must give bit-identical logits whenever a batch comes round again
 for it in range(len(sizes) - 1):
-    nxt = T.fresh_batch(batches[(it + 1) % len(batches)])
+    nxt = dict(T.fresh_batch(batches[(it + 1) % len(batches)]), _key=(it + 1) % len(batches))      # (the batch carries its key: its teacher may run a step ahead)
     watch.key = it % len(batches)
     loss = float(kd_run(cur, prefetch=nxt))
     assert np.isfinite(loss), (it, loss)

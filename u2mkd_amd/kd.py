@@ -368,6 +368,17 @@ class TSDFull(nn.Module):
             return ret
         main = torch.cuda.current_stream()
         stu_in = in_mod['student']
+        ahead = in_mod['teacher'].pop('_teacher_out', None)
+        if ahead is not None:
+            # the trainer queued this batch's teacher forward one step ahead (``teacher_ahead``, train.KDStep): nothing of the
+            # teacher is issued here, the host goes straight to the student
+            t = ahead
+            ret = {'stu': self.model_s(stu_in)}
+            main.wait_stream(side)
+            for v in _tensors(t):
+                v.record_stream(main)
+            ret['t'] = t
+            return ret
         if _CAMERA_STREAM and self.training and _overlap_ok():
             # the camera head first: its large kernels run while the host queues the teacher's ~1500 small ones
             stu_in = dict(stu_in, _camera_head=self.model_s.camera_head(stu_in))
@@ -387,6 +398,33 @@ class TSDFull(nn.Module):
 
 
 _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
+# U2MKD_TEACHER_AHEAD: the frozen teacher's forward of batch k + 1 is ISSUED by the trainer at the end of step k, behind the
+# backward's launches (train.KDStep with ``prefetch=``), instead of at the start of step k + 1: its ~1 000 launches (6-7 ms of
+# host time) leave the forward phase.  1 = the teacher's kernels may start as soon as its geometry is there (next to the tail of
+# the backward), 2 = they additionally wait for the end of the backward's main-stream chain, 0 = off (default).  The teacher is
+# frozen (no gradient, eval-mode BatchNorm): its outputs do not depend on which side of the optimizer step they are computed.
+# MEASURED (round 6, same-box pairs): 63.3-63.6 ms with it against 62.7-63.1 ms without -- single steps drop to 57-58 ms, the mean
+# does not move: the step is bound by the GPU's total kernel time (86 ms over five streams), not by where or when the host
+# issues it (NOTES N10).  Kept as a switch: it is the measurement that settles the question.
+_TEACHER_AHEAD = int(os.environ.get('U2MKD_TEACHER_AHEAD', '0'))
+
+
+def teacher_ahead(model, in_mod_next, after=()):
+    """Queue ``model.model_t``'s forward for a PREPARED next batch (``TSDFull.prepare``: its geometry is there) on the teacher's
+    side stream, behind the events ``after``; the outputs ride in ``in_mod_next['teacher']['_teacher_out']`` until
+    ``TSDFull.forward`` of that batch picks them up.  Returns False (nothing queued) where the step does not fork."""
+    if not (_TEACHER_AHEAD and _TEACHER_STREAM and model.training and _overlap_ok()):
+        return False
+    tea = in_mod_next['teacher']
+    if tea.get('_geometry') is None or not tea['lidar'].F.is_cuda:
+        return False
+    side = _side_stream(tea['lidar'].F, 'teacher')
+    for ev in after:          # (the batch's tensors, its geometry; not the backward that was queued in between)
+        if ev is not None:
+            side.wait_event(ev)
+    with torch.cuda.stream(side), torch.no_grad():
+        tea['_teacher_out'] = model.model_t(tea)
+    return True
 
 
 def _overlap_ok():

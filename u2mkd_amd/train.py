@@ -303,8 +303,10 @@ class TeacherWatch:
         self._handle = model_t.register_forward_hook(self._hook)
 
     def _hook(self, module, inputs, output):
-        if self.key is not None:
-            self.log.append((self.key, output['x_vox'].detach().clone()))
+        # the batch's own key where it carries one (`d['_key']`: the teacher of batch k + 1 may run inside step k, kd.teacher_ahead)
+        key = inputs[0].get('_key', self.key) if inputs and isinstance(inputs[0], dict) else self.key
+        if key is not None:
+            self.log.append((key, output['x_vox'].detach().clone()))
 
     def deviating_steps(self):
         """(steps that differ from the first visit of their batch, steps compared)"""
@@ -357,6 +359,8 @@ class KDStep:
         stu = {'lidar': ts.SparseTensor(d['s_feats'], d['s_coords']), 'images': d['images'],
                'pixel_coordinates': d['pixel_coordinates'], 'masks': d['masks'], 'fov_mask': d['fov_mask']}
         tea = {'lidar': ts.SparseTensor(d['t_feats'], d['t_coords'])}
+        if '_key' in d:
+            tea['_key'] = d['_key']          # (TeacherWatch: which resident batch this is)
         return {'student': stu, 'teacher': tea}
 
     def __call__(self, d, prefetch=None):
@@ -392,10 +396,15 @@ class KDStep:
             self._advance_geometry(geo, staged)            # read 1 (ready), slice 2: the down-sampled levels
             self.amp.backward_and_step(ld['total'], self.opt)
             self.sched.step()
+            after_bwd = torch.cuda.current_stream().record_event() if KD._TEACHER_AHEAD == 2 else None
             done = self._advance_geometry(geo, staged)     # read 2 (ready), slice 3: kernel maps, schedules
             self._queued = (prefetch, done)
             self._geo_done = geo.record_event()
             self._geo_keep = in_mod
+            # the next batch's frozen-teacher forward, queued NOW: the GPU is still running this step's backward, the host
+            # would otherwise arrive at the next step's start with the teacher's ~1 000 launches ahead of the student's
+            with self.amp.autocast():
+                KD.teacher_ahead(self.model, done, after=(entry, self._geo_done, after_bwd))
             users = [torch.cuda.current_stream(), KD._side_stream(d['s_feats'], 'teacher'), KD._side_stream(d['s_feats'], 'camera')]
             for key in ('student', 'teacher'):
                 for t in _tensors_of(self._queued[1][key].get('_geometry')):
