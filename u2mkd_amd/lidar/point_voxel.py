@@ -156,7 +156,7 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     cache = z.additional_features
     if cache is None or cache.get('idx_query') is None or cache['idx_query'].get(x.s) is None:
         pc_hash = spf.sphash(_floor_coords(z.C, x.s[0]))
-        idx_query = spf.HashTable(spf.sphash(x.C)).query_with_i32(pc_hash)
+        idx_query = spf.coords_table(x.C).query_with_i32(pc_hash)
         counts = spf.spcount(spf._plan(idx_query, 'i32', lambda: idx_query.int().contiguous()), x.C.shape[0])
         z.additional_features['idx_query'][x.s] = idx_query
         z.additional_features['counts'][x.s] = counts
@@ -177,7 +177,7 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTenso
             or z.weights.get(x.s) is None:
         off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
         old_hash = spf.sphash(_floor_coords(z.C, x.s[0]), off)          # [8, N]
-        idx_kn = spf.HashTable(spf.sphash(x.C.to(z.F.device))).query(old_hash)
+        idx_kn = spf.coords_table(x.C.to(z.F.device)).query(old_hash)
         weights, idx_query = spf.ti_weights_n8(z.C, idx_kn, scale=x.s[0])   # [N,8], [N,8]
         if nearest:
             weights[:, 1:] = 0.

@@ -98,6 +98,14 @@ class HashTable:
         return out
 
 
+def coords_table(coords: torch.Tensor) -> HashTable:
+    """The hash table over a coordinate set's hashes, built ONCE per coordinate tensor (cached on it with its version counter,
+    ``_plan``): a level's coordinates are hashed and inserted by build_kmap (twice per level: the 3 x 3 x 3 and the 2 x 2 x 2
+    map), point_to_voxel and voxel_to_point alike -- 44 builds (4 launches each) per KD step, 10 distinct tables."""
+    c = _i32(coords).contiguous()
+    return _plan(c, 'hashtable', lambda: HashTable(sphash(c)))
+
+
 def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
     """Index of every query hash in ``references`` (-1 on miss), query shape kept."""
     return HashTable(references).query(queries)
@@ -786,7 +794,7 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride, out_coo
     n_in = coords.shape[0]
     offsets = get_kernel_offsets(kernel_size, stride=tensor_stride, device=dev)
     k = offsets.shape[0]
-    table = HashTable(sphash(coords))
+    table = coords_table(coords)
     strided = any(s > 1 for s in stride)
     if not strided:
         out_coords = coords
