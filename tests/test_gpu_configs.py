@@ -150,3 +150,35 @@ def test_geometry_in_slices_gives_the_step_the_same_geometry(hip, monkeypatch):
         for ta, tb in zip(ga, gb):
             assert torch.equal(ta, tb)
     assert torch.equal(a[2][0], b[2][0])               # the first step's teacher logits (later steps follow different students)
+
+
+def test_teacher_issued_one_step_ahead_gives_the_same_teacher_and_the_same_first_loss(hip, monkeypatch):
+    """kd.teacher_ahead (U2MKD_TEACHER_AHEAD: the frozen teacher's forward of batch k + 1 queued behind step k's backward, on
+    the teacher's stream, picked up by TSDFull.forward of that batch): every batch's teacher logits bit for bit those of the
+    in-line order (the teacher is frozen: eval-mode BatchNorm, no gradient), each computed exactly once, the first loss equal."""
+    from u2mkd_amd import kd as KD, train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    batches = [T.kd_batch_to_device(synth_kd_batch(3000 + 400 * i, 1, seed=71 + i, image_hw=(64, 112))) for i in range(3)]
+
+    def run(ahead):
+        monkeypatch.setattr(KD, '_TEACHER_AHEAD', ahead)
+        monkeypatch.setenv('U2MKD_STAGED_GEOMETRY', '1')
+        runner = _runner(1.0, 2.0)
+        watch = T.TeacherWatch(runner.model.model_t)
+        losses = []
+        cur = dict(T.fresh_batch(batches[0]), _key=0)
+        for i in range(4):
+            nxt = dict(T.fresh_batch(batches[(i + 1) % 3]), _key=(i + 1) % 3)
+            losses.append(float(runner(cur, prefetch=nxt)))
+            cur = nxt
+        torch.cuda.synchronize()
+        return losses, list(watch.log)
+    (la, ta), (lb, tb) = run(0), run(1)
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(la[0]), (la, lb)
+    # in-line: batches 0, 1, 2, 0; ahead: 0 (in line), then 1, 2, 0 and the queued-but-unused 1 of the last call
+    assert [k for k, _ in ta] == [0, 1, 2, 0] and [k for k, _ in tb] == [0, 1, 2, 0, 1]
+    for (ka, a), (kb, b) in zip(ta, tb):
+        assert ka == kb and torch.equal(a, b), ka
+    monkeypatch.setattr(KD, '_TEACHER_AHEAD', 2)
+    lc = run(2)[0]
+    assert abs(la[0] - lc[0]) <= 1e-5 * abs(la[0])
