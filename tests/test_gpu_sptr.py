@@ -112,7 +112,7 @@ def test_tile_form_of_the_forward_equals_the_oracle_and_the_per_pair_kernels(hip
     assert _rel(res['all'][0].cpu(), ref) < 1e-5
     for x, y in zip(res['all'], res['0']):
         # (a gradient that is analytically zero -- single-token windows -- is exactly 0 on one path and rounding noise on the other)
-        assert _rel(x, y.cpu()) < 1e-5 or float((x - y).abs().max()) < 1e-6
+        assert _rel(x, y.cpu()) < 1e-5 or float((x - y).abs().max()) < 1e-5
 
 
 def test_reference_api_signature(hip):

@@ -114,29 +114,94 @@ constexpr int kShortSeg = 24;
 // One launch: the first `short_blocks` workgroups sort the short segments (a thread per segment), the rest walk the long ones
 // (a workgroup per candidate, grid-stride).
 constexpr int kLongChunk = 2048;
+constexpr int kWaveSeg = 1024;          // entries a single wave sorts in its quarter of the LDS array
 __global__ void __launch_bounds__(kCsrThreads)
 csr_sort_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict__ order, int32_t *__restrict__ scratch,
                 int short_blocks) {
-    __shared__ int s_in[kLongChunk];
+    constexpr int kShared = kShortSeg * kCsrThreads;      // 6 144 ints: the short path's columns; 4 wave strips of kWaveSeg; one chunk of kLongChunk
+    static_assert(kShared >= 4 * kWaveSeg && kShared >= kLongChunk, "LDS array too small");
+    __shared__ int s_in[kShared];
     if ((int)blockIdx.x < short_blocks) {
         int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (v >= nv) return;
         const int b = seg[v], n = seg[v + 1] - b;
         if (n < 2 || n > kShortSeg) return;
         int32_t *o = order + b;
+        // the segment in a private LDS column (entry i of thread t at s_in[i * 256 + t]: conflict-free), insertion sort there:
+        // in place in global memory every shift was a dependent load + store through L2 (48 us per launch, 1.6 ms per KD step)
+        int *col = s_in + threadIdx.x;
+        for (int i = 0; i < n; ++i) col[i * kCsrThreads] = o[i];
         for (int i = 1; i < n; ++i) {
-            const int x = o[i];
+            const int x = col[i * kCsrThreads];
             int j = i - 1;
-            while (j >= 0 && o[j] > x) { o[j + 1] = o[j]; --j; }
-            o[j + 1] = x;
+            while (j >= 0 && col[j * kCsrThreads] > x) { col[(j + 1) * kCsrThreads] = col[j * kCsrThreads]; --j; }
+            col[(j + 1) * kCsrThreads] = x;
         }
+        for (int i = 0; i < n; ++i) o[i] = col[i * kCsrThreads];
         return;
     }
-    const int lane = threadIdx.x, nl = kCsrThreads;
     const int first = (int)blockIdx.x - short_blocks, stride = (int)gridDim.x - short_blocks;
-    for (int64_t v = first; v < nv; v += stride) {
+    // medium segments (25 .. kWaveSeg entries: the voxels of a coarse level in the devoxelisation's backward grouping hold
+    // 20-100 corners each): ONE WAVE per segment, bitonic in the wave's own LDS strip -- no workgroup barrier between the
+    // stages (a wave's LDS operations are served in issue order), four segments per workgroup at a time.  A workgroup per
+    // segment spent its time in 21-28 __syncthreads per 64-128 entries: 1.6 ms per KD step.
+    {
+        const int wid = threadIdx.x >> 6, wl = threadIdx.x & 63;
+        volatile int *ws = s_in + wid * kWaveSeg;
+        // (64 segments are LOOKED AT per step, one per lane; walking them one by one -- two dependent loads per segment from a
+        // workgroup that mostly finds nothing to do -- took 120 us on the 345 600 pixel segments of the full-resolution grid)
+        // wave g of tw looks at segments g, g + tw, g + 2 tw, ...: 64 of them per step (one per lane), so that a run of
+        // consecutive medium segments -- a whole coarse level -- spreads over all waves of the launch
+        const int64_t gw = (int64_t)first * 4 + wid, tw = (int64_t)stride * 4;
+        for (int64_t base = gw; base < nv; base += tw * 64) {
+            const int64_t vl = base + (int64_t)wl * tw;
+            const int bl = vl < nv ? seg[vl] : 0;
+            const int nl = vl < nv ? seg[vl + 1] - bl : 0;
+            unsigned long long todo = __ballot(nl > kShortSeg && nl <= kWaveSeg);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int b = __shfl(bl, src), n = __shfl(nl, src);
+                int32_t *o = order + b;
+                int m = 64;
+                while (m < n) m <<= 1;
+                for (int i = wl; i < m; i += 64) ws[i] = i < n ? o[i] : 0x7fffffff;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int k = 2; k <= m; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = wl; t < (m >> 1); t += 64) {
+                            const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                            const int a = ws[lo], b2 = ws[hi];
+                            const bool up = (lo & k) == 0;
+                            if ((a > b2) == up) { ws[lo] = b2; ws[hi] = a; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                for (int i = wl; i < n; i += 64) o[i] = ws[i];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x, nl = kCsrThreads;
+    __shared__ int s_list[kCsrThreads], s_cnt;
+    // the long segments (> kWaveSeg entries), a workgroup each: found 256 at a time, then sorted one after the other
+    for (int64_t base = (int64_t)first * kCsrThreads; base < nv; base += (int64_t)stride * kCsrThreads) {
+        if (lane == 0) s_cnt = 0;
+        __syncthreads();
+        {
+            const int64_t vl = base + lane;
+            if (vl < nv && seg[vl + 1] - seg[vl] > kWaveSeg) s_list[atomicAdd(&s_cnt, 1)] = (int)(vl - base);
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int qi = 0; qi < cnt; ++qi) {
+        const int64_t v = base + s_list[qi];
         const int b = seg[v], n = seg[v + 1] - b;
-        if (n <= kShortSeg) continue;
         int32_t *o = order + b;
         if (n <= kLongChunk) {
             // bitonic sort of the (distinct) entry ids in LDS, padded to a power of two with INT_MAX: n log^2 n / 2
@@ -171,6 +236,8 @@ csr_sort_kernel(const int32_t *__restrict__ seg, int64_t nv, int32_t *__restrict
             }
             __syncthreads();
         }
+        }
+        __syncthreads();
     }
 }
 

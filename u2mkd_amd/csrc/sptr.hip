@@ -774,8 +774,17 @@ __global__ void sptr_table_reduce_kernel(const float *__restrict__ slabs, int G,
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     int hh = blockIdx.y;
     if (e >= per) return;
+    // (ascending slab order, eight loads in flight: one dependent round trip per slab made this sum 100 us for 256 slabs)
     float acc = 0.f;
-    for (int g = 0; g < G; ++g) acc += slabs[((size_t)g * h + hh) * per + e];
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slabs[((size_t)(g + u) * h + hh) * per + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; g < G; ++g) acc += slabs[((size_t)g * h + hh) * per + e];
     int tb = e / (rows * kHd);
     int rem = e - tb * rows * kHd;
     int row = rem / kHd, d = rem - row * kHd;
