@@ -1120,15 +1120,20 @@ def _dense_x3_ok(cin, cout):
     return _PAIRS_X3 and _LINEAR_X3 and bool(L.load().u2mkd_conv_pairs_x3_supported(cin, cout))
 
 
-def _dense_x3(x, weight, forward, bias=None):
+def _dense_x3(x, weight, forward, bias=None, kernel_layout=False):
     """x @ weight.T (+ bias) (forward) or x @ weight (the input gradient) for nn.Linear's weight [out, in] on the
     bf16x3 pair kernel's dense mode; the fragment-order weights of both orientations come from one cached launch.
-    bf16 rows (bf16 storage): the same kernel's one-plane form, bf16 in and out, fp32 bias and accumulation."""
+    bf16 rows (bf16 storage): the same kernel's one-plane form, bf16 in and out, fp32 bias and accumulation.
+    ``kernel_layout``: ``weight`` is [in, out] (the one offset of a 1 x 1 x 1 spnn.Conv3d ``kernel``): x @ weight forward,
+    x @ weight.T for the input gradient -- the other orientation of the same cached fragments, no transposed copy."""
     n = x.shape[0]
-    cout = weight.shape[0] if forward else weight.shape[1]
+    if kernel_layout:          # [in, out] or the conv kernel itself, [1, in, out]
+        cout = weight.shape[-1] if forward else weight.shape[-2]
+    else:
+        cout = weight.shape[0] if forward else weight.shape[1]
     b16 = x.dtype == torch.bfloat16
     f2 = not b16 and _pairs_f16x2(x.shape[1], cout)
-    wf = _weight_layout(weight, not forward, True, arith=3 if b16 else (4 if f2 else 0))
+    wf = _weight_layout(weight, forward if kernel_layout else not forward, True, arith=3 if b16 else (4 if f2 else 0))
     y = torch.empty(n, cout, dtype=x.dtype, device=x.device)
     L.call('u2mkd_linear_forward_bf16' if b16 else ('u2mkd_linear_forward_f16x2' if f2 else 'u2mkd_linear_forward_x3'), L.ptr(x), n,
            x.shape[1], L.ptr(wf), cout, L.ptr(bias), L.ptr(y), L.stream())
@@ -1224,6 +1229,67 @@ class LinearFunction(Function):
         if gx is not None and gx.dtype != ctx.in_dtype:
             gx = gx.to(ctx.in_dtype)
         return gx, gw, gb, None
+
+
+class PointwiseConvFunction(Function):
+    """spnn.Conv3d with a 1 x 1 x 1 kernel (the ``downsample`` branch of a ResidualBlock, core/models/build_blocks.py:66-70):
+    y = x @ kernel (+ bias) with ``kernel`` [cin, cout] (v1.4.0 stores a one-offset kernel 2-D; [1, cin, cout] is taken too) AS
+    THE PARAMETER STORES IT.  Rounds 2-5 handed nn.Linear's
+    Function ``kernel[0].t()``: a transposed view that had to be copied, re-laid into MFMA fragments and scaled on every call (a
+    temporary never sees the per-step batched fragment refresh) and whose gradient went back through a transposing node -- 16
+    such layers per KD step.  Here the forward and the input gradient read the two orientations of the PARAMETER's cached
+    fragments and the weight gradient is produced in the kernel's own layout (dW[0] = X^T dY: the pair-list kernel over the
+    identity pairs, as LinearFunction uses it with the roles swapped)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias):
+        L.require_cuda(x, kernel)
+        ctx.weight_is_param = kernel.is_leaf
+        ctx.overlap_ok = _deferred_overlap_ok()
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        want16 = bf16_rows()
+        b16 = want16 and _conv_bf16_ok(cin, cout)
+        ctx.in_dtype = x.dtype
+        x = _rows(x, b16)
+        if x.dim() != 2 or x.shape[1] != cin:
+            raise RuntimeError(f'conv3d (1x1x1): input {tuple(x.shape)} does not match kernel {tuple(kernel.shape)}')
+        ctx.save_for_backward(x, kernel)
+        ctx.has_bias = bias is not None
+        if x.shape[0] == 0:
+            return x.new_zeros(0, cout)
+        b = bias.contiguous().float() if bias is not None else None
+        y = _dense_x3(x, kernel, True, b, kernel_layout=True)
+        return y.to(torch.bfloat16) if (want16 and not b16) else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel = ctx.saved_tensors
+        b16 = x.dtype == torch.bfloat16
+        g = _rows(g, b16)
+        n = x.shape[0]
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        gx = gw = gb = None
+        if n == 0:
+            return x.new_zeros(x.shape), torch.zeros_like(kernel), (kernel.new_zeros(cout) if ctx.has_bias else None)
+        side, deferred_join = None, False
+        if ctx.needs_input_grad[1]:
+            pairs, plan = _identity_pairs(n, g.device)
+            nbytes = L.load().u2mkd_conv_wgrad_pairs_workspace_bytes(n, cin, cout, 1)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+            gw = torch.empty_like(kernel)
+            side, deferred_join = _wgrad_side(kernel, ctx.weight_is_param, g.device, ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan,
+                                               allow=getattr(ctx, 'overlap_ok', True))
+            L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(x), cin, L.ptr(g), cout,
+                   L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), side.cuda_stream if side is not None else L.stream())
+        if ctx.needs_input_grad[0]:
+            gx = _dense_x3(g, kernel, False, kernel_layout=True)
+        if side is not None and not deferred_join:
+            torch.cuda.current_stream(g.device).wait_stream(side)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0, dtype=torch.float32)
+        if gx is not None and gx.dtype != ctx.in_dtype:
+            gx = gx.to(ctx.in_dtype)
+        return gx, gw, gb
 
 
 def linear(x, weight, bias=None, bias_feeds_batchnorm=False):
@@ -1396,7 +1462,11 @@ def conv3d(input: SparseTensor, weight: torch.Tensor, kernel_size, bias=None, st
 
     if kernel_size == (1, 1, 1) and stride == (1, 1, 1) and dilation == (1, 1, 1):
         w = weight[0] if weight.dim() == 3 else weight          # kernel [1, cin, cout] or [cin, cout]
-        if w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
+        if (weight.dim() == 2 or weight.shape[0] == 1) and weight.is_contiguous() and weight.dtype == torch.float32 \
+                and _dense_x3_ok(w.shape[0], w.shape[1]) and feats.is_cuda and feats.dim() == 2 and feats.shape[1] == w.shape[0]:
+            # the kernel in its own [1, cin, cout] layout: cached fragments, no transposed copy (PointwiseConvFunction)
+            feats = PointwiseConvFunction.apply(feats, weight, bias)
+        elif w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0:
             feats = linear(feats, w.t(), bias)
         else:
             feats = feats.matmul(w)
