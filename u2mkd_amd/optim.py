@@ -143,29 +143,33 @@ class FusedSGD(torch.optim.SGD):
                 self._adopt_state(fg)
             self._adopt = False
         for group, fg, grads in plans:
-            slot = fg.turn % _RING
-            fg.turn += 1
-            ev = fg.events[slot]
-            if ev is not None and not ev.query():
-                ev.synchronize()              # (the host is a whole ring ahead of the copy that reads this staging buffer)
-            tab = fg.tabs[slot]
-            tab[:, 1] = [0 if g is None else g.data_ptr() for g in grads]
-            tab[:, 5] = fg.first_col
-            fg.table.copy_(fg.stage[slot], non_blocking=True)
-            if ev is None:
-                ev = fg.events[slot] = torch.cuda.Event()
-            ev.record()
-            L.call('u2mkd_sgd_batch', L.ptr(fg.table), len(fg.params), fg.total_chunks, float(group['lr']), float(group['momentum']),
-                   float(group['weight_decay']), int(bool(group['nesterov'])), self._contract, L.stream())
-            if fg.missing and group['momentum'] != 0:
-                # torch: a parameter's momentum buffer comes into being with its first gradient (buf = clone(grad))
-                for i, g in enumerate(grads):
-                    if g is not None and not fg.has_buf[i]:
-                        fg.has_buf[i] = True
-                        fg.first_col[i] = 0
-                        fg.missing -= 1
-                        self.state[fg.params[i]]['momentum_buffer'] = fg.bufs[i]
+            with torch.cuda.device(fg.device):          # (the launch goes to the current stream of the GROUP's device)
+                self._launch(group, fg, grads)
         return loss
+
+    def _launch(self, group, fg, grads):
+        slot = fg.turn % _RING
+        fg.turn += 1
+        ev = fg.events[slot]
+        if ev is not None and not ev.query():
+            ev.synchronize()              # (the host is a whole ring ahead of the copy that reads this staging buffer)
+        tab = fg.tabs[slot]
+        tab[:, 1] = [0 if g is None else g.data_ptr() for g in grads]
+        tab[:, 5] = fg.first_col
+        fg.table.copy_(fg.stage[slot], non_blocking=True)
+        if ev is None:
+            ev = fg.events[slot] = torch.cuda.Event()
+        ev.record()
+        L.call('u2mkd_sgd_batch', L.ptr(fg.table), len(fg.params), fg.total_chunks, float(group['lr']), float(group['momentum']),
+               float(group['weight_decay']), int(bool(group['nesterov'])), self._contract, L.stream())
+        if fg.missing and group['momentum'] != 0:
+            # torch: a parameter's momentum buffer comes into being with its first gradient (buf = clone(grad))
+            for i, g in enumerate(grads):
+                if g is not None and not fg.has_buf[i]:
+                    fg.has_buf[i] = True
+                    fg.first_col[i] = 0
+                    fg.missing -= 1
+                    self.state[fg.params[i]]['momentum_buffer'] = fg.bufs[i]
 
     def _torch_step(self, loss):
         """torch's own update (whatever the fused path does not cover); its buffers are adopted by the next fused step."""
