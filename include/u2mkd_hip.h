@@ -477,6 +477,15 @@ int u2mkd_lovasz_terms(const int64_t *perm, const float *errors, const int64_t *
                        int32_t c, float *jgrad, float *partial, float *stats, u2mkd_stream_t s);
 int u2mkd_lovasz_backward(const float *g_out, const float *stats, const int64_t *perm, const float *jgrad, const float *probas,
                           const int64_t *labels, int32_t ignore_index, int64_t n, int32_t c, float *d_probas, u2mkd_stream_t s);
+/* nn.CrossEntropyLoss(ignore_index, mean over the valid rows) on [n, c] logits (core/criterions.py:167-174: the `ce` half of
+ * MixLovaszCrossEntropy; torch: log_softmax + nll_loss, two single-workgroup reductions of 57 + 76 us at 80 000 x 17).
+ * u2mkd_ce_forward: lse [n] (kept for the backward), stats = {mean loss over the valid rows, 1 / #valid}; partial:
+ * u2mkd_ce_partials(n) floats.  u2mkd_ce_backward: dx [n, c] = g_out[0] / #valid * (softmax(x) - onehot), 0 on ignored rows. */
+int64_t u2mkd_ce_partials(int64_t n);
+int u2mkd_ce_forward(const float *x, const int64_t *labels, int32_t ignore_index, int64_t n, int32_t c, float *lse, float *partial,
+                     float *stats, u2mkd_stream_t s);
+int u2mkd_ce_backward(const float *g_out, const float *stats, const float *x, const float *lse, const int64_t *labels,
+                      int32_t ignore_index, int64_t n, int32_t c, float *dx, u2mkd_stream_t s);
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
  * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and

@@ -81,3 +81,37 @@ def test_devoxelize_plan_equals_the_torch_ops(hip, n, nv, seed):
     assert torch.equal(seg, seg_ref)
     assert torch.equal(erow[:live], (order >> 3)[:live])
     assert torch.equal(ew[:live], w.view(-1)[order.long()][:live])
+
+
+@pytest.mark.parametrize('n,c,frac_ignored', [(80000, 17, 0.2), (1000, 17, 0.0), (257, 5, 0.5), (3, 17, 0.0), (5000, 33, 0.9)])
+def test_fused_cross_entropy_equals_torchs(hip, n, c, frac_ignored):
+    """losses._CrossEntropyFunction (csrc/lovasz.hip ce_forward / ce_backward: lse per row, fixed-order sums, one backward pass)
+    against nn.CrossEntropyLoss(ignore_index=0) -- core/criterions.py:167-174 -- in float64: value and gradient, ignored rows
+    with zero gradient; the MixLovaszCrossEntropy module with and without the fused pass."""
+    from u2mkd_amd import losses
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 3).cuda()
+    y = torch.randint(1, c, (n,), generator=g)
+    y[torch.rand(n, generator=g) < frac_ignored] = 0
+    y = y.cuda()
+    xa = x.clone().requires_grad_(True)
+    got = losses._CrossEntropyFunction.apply(xa, y, 0)
+    (got * 1.7).backward()
+    xd = x.double().clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(xd, y, ignore_index=0)
+    (want * 1.7).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    assert float((xa.grad.double() - xd.grad).abs().max()) <= 1e-6 * float(xd.grad.abs().max()) + 1e-12
+    assert float(xa.grad[y == 0].abs().max() if bool((y == 0).any()) else 0.0) == 0.0
+    crit = losses.MixLovaszCrossEntropy(ignore_index=0)
+    xb, xc = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = crit(xb, y)
+    a.backward()
+    old, losses._FUSED_CE = losses._FUSED_CE, False
+    try:
+        b = crit(xc, y)
+        b.backward()
+    finally:
+        losses._FUSED_CE = old
+    assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
+    assert float((xb.grad - xc.grad).abs().max()) <= 1e-6 * float(xc.grad.abs().max()) + 1e-9

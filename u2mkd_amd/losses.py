@@ -7,6 +7,8 @@ sort of the [P, C] error matrix instead of C separate sorts of length P, and no
 host synchronisation (absent classes are masked, not skipped by a Python
 ``if fg.sum() == 0``).  Same value and gradient as the reference formulation.
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -120,6 +122,40 @@ class Lovasz_softmax(nn.Module):
         return lovasz_softmax_flat(probas, labels, labels != self.ignore_index)
 
 
+class _CrossEntropyFunction(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index, reduction='mean') on [P, C] fp32 logits as one pass per direction
+    (csrc/lovasz.hip: ce_forward / ce_backward; torch: log_softmax + nll_loss, whose two reductions are single-workgroup
+    kernels -- 57 + 76 us at 80 000 x 17, twice per KD step on the critical stream)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, ignore_index):
+        from . import _lib as L
+        x = x.contiguous()
+        labels = labels.contiguous()
+        P, C = x.shape
+        lse = torch.empty(P, dtype=torch.float32, device=x.device)
+        partial = torch.empty(int(L.load().u2mkd_ce_partials(P)), dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        L.call('u2mkd_ce_forward', L.ptr(x), L.ptr(labels), int(ignore_index), P, C, L.ptr(lse), L.ptr(partial), L.ptr(stats), L.stream())
+        ctx.save_for_backward(x, labels, lse, stats)
+        ctx.ignore_index = int(ignore_index)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        x, labels, lse, stats = ctx.saved_tensors
+        P, C = x.shape
+        g = g.contiguous().float().reshape(1)
+        dx = torch.empty_like(x)
+        L.call('u2mkd_ce_backward', L.ptr(g), L.ptr(stats), L.ptr(x), L.ptr(lse), L.ptr(labels), ctx.ignore_index, P, C, L.ptr(dx),
+               L.stream())
+        return dx, None, None
+
+
+_FUSED_CE = os.environ.get('U2MKD_FUSED_CE', '1') != '0'      # 0: torch's log_softmax + nll_loss (the formulation the fused pass is tested against)
+
+
 class MixLovaszCrossEntropy(nn.Module):
     def __init__(self, weight=None, classes='present', ignore_index=255):
         super().__init__()
@@ -127,5 +163,11 @@ class MixLovaszCrossEntropy(nn.Module):
         self.lovasz = Lovasz_softmax(classes, ignore_index=ignore_index)
         self.ce = nn.CrossEntropyLoss(weight=weight, ignore_index=ignore_index)
 
+    def _ce(self, x, y):
+        if (_FUSED_CE and self.ce.weight is None and self.ce.label_smoothing == 0.0 and x.is_cuda and x.dim() == 2
+                and x.dtype == torch.float32 and y.dtype == torch.int64 and x.shape[0] > 0 and -2 ** 31 <= self.ignore_index < 2 ** 31):
+            return _CrossEntropyFunction.apply(x, y, self.ignore_index)
+        return self.ce(x, y)
+
     def forward(self, x, y):
-        return self.lovasz(F.softmax(x, 1), y) + self.ce(x, y)
+        return self.lovasz(F.softmax(x, 1), y) + self._ce(x, y)
