@@ -28,6 +28,7 @@ from . import _lib as L
 __all__ = ['sampled_pixel_logits', 'sampled_head_applies']
 
 _ENABLED = os.environ.get('U2MKD_SAMPLED_PIXEL_HEAD', '1') != '0'
+_ROW_BN = os.environ.get('U2MKD_PIXEL_HEAD_ROW_BN', '1') != '0'      # 0: the samples' normalise + ReLU as torch element-wise kernels (A/B, tests)
 _COEF = {}
 _ROWS_PER_CHUNK = 16
 
@@ -115,24 +116,45 @@ class _UpsampledBatchNormReLU(torch.autograd.Function):
                     bn.running_var.mul_(1.0 - m).add_((var * unbias).to(bn.running_var.dtype), alpha=m)
         else:
             mean, var = bn.running_mean.double(), bn.running_var.double()
-        invstd = (var + bn.eps).rsqrt().float()
-        mean = mean.float()
-        xhat = (u - mean) * invstd
-        y = torch.relu(xhat * weight + bias)
-        ctx.save_for_backward(x, xhat, y, weight, invstd, mean)
+        invstd = (var + bn.eps).rsqrt().float().contiguous()
+        mean = mean.float().contiguous()
+        weight, bias, u = weight.contiguous(), bias.contiguous(), u.contiguous()
+        # relu((u - mean) invstd weight + bias) over the [S, C] samples: the row BatchNorm's apply pass with THESE statistics
+        # (one pass; as five element-wise kernels it moved 1.5 GB per step at 6 x 360x640)
+        if _ROW_BN:
+            y = torch.empty_like(u)
+            L.call('u2mkd_bn_apply', L.ptr(u), u.shape[0], c, L.ptr(mean), L.ptr(invstd), L.ptr(weight), L.ptr(bias), 1, L.ptr(y),
+                   L.stream())
+        else:
+            y = torch.relu((u - mean) * invstd * weight + bias)
+        ctx.save_for_backward(x, u, weight, bias, invstd, mean)
         ctx.meta = (training, count, coef, sync)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        x, xhat, y, weight, invstd, mean = ctx.saved_tensors
+        x, u, weight, bias, invstd, mean = ctx.saved_tensors
         training, count, coef, sync = ctx.meta
-        g = gy * (y > 0)
-        dbeta = g.sum(0)
-        dgamma = (g * xhat).sum(0)
+        # g = gy (y > 0); dbeta = sum g; dgamma = sum g xhat; du = g scale: the row BatchNorm's backward in its eval form (the
+        # statistics' own gradient reaches every pixel of the map, below), mask and xhat re-derived from u
+        gy = gy.contiguous()
+        s_rows = u.shape[0]
+        cc = u.shape[1]
+        partial = torch.empty(max(int(L.load().u2mkd_bn_num_slabs(s_rows)), 1) * 2 * cc, dtype=torch.float32, device=u.device)
+        dgamma = torch.empty(cc, dtype=torch.float32, device=u.device)
+        dbeta = torch.empty(cc, dtype=torch.float32, device=u.device)
+        du = torch.empty_like(u)
+        if not _ROW_BN:
+            xhat = (u - mean) * invstd
+            g = gy * (xhat * weight + bias > 0)
+            dbeta, dgamma, du = g.sum(0), (g * xhat).sum(0), g * (weight * invstd)
+        elif s_rows:
+            L.call('u2mkd_bn_backward', L.ptr(gy), L.ptr(u), s_rows, cc, L.ptr(mean), L.ptr(invstd), L.ptr(weight), L.ptr(bias), 1, 0,
+                   L.ptr(partial), L.ptr(dgamma), L.ptr(dbeta), L.ptr(du), L.stream())
+        else:
+            dgamma.zero_(); dbeta.zero_()
         scale = weight * invstd
-        du = g * scale
         dx = None
         if training:
             # dU = scale * (g - mean(g) - xhat * mean(g * xhat)) over ALL count pixels; g = 0 off the samples.  The two
@@ -163,6 +185,7 @@ def sampled_head_applies(x, head):
     (nn.BatchNorm is an fp32 operator under autocast anyway)."""
     from .camera import BatchNorm2d, SyncBatchNorm2d
     return (_ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 1024      # (the row BatchNorm kernels' channel counts)
             and type(head.norm) in (BatchNorm2d, SyncBatchNorm2d) and head.norm.momentum is not None
             and head.conv.bias is None and head.conv.kernel_size == (1, 1))
 
