@@ -117,6 +117,41 @@ def test_prefetched_geometry_makes_the_forward_sync_free_and_changes_nothing(hip
     assert bool(torch.isfinite(out['stu']['x_vox']).all())
 
 
+def test_plans_built_a_step_ahead_change_nothing(hip, monkeypatch):
+    """U2MKD_PREFETCH_PLANS=1: the student's batch-only index structures (point <-> voxel maps with their scatter / gather
+    plans, kernel-map schedules, window plans, point <-> pixel plans) built with the next batch's geometry instead of at first
+    use.  (1) the forward of a batch prepared that way finds them all: no plan-building entry is called inside it from the
+    second batch on; (2) the student's logits of the same batch with the same weights are what the lazy path computes."""
+    from u2mkd_amd import _lib as L, kd as KD, train as T
+    from u2mkd_amd.synth import synth_kd_batch
+    from u2mkd_amd.torchsparse.nn import functional as F
+    batches = [T.kd_batch_to_device(synth_kd_batch(2500 + 300 * i, 1, seed=60 + i, image_hw=(64, 112))) for i in range(2)]
+    run = _runner(1.0, 1.0)
+    run.model.eval()                                   # (no dropout / DropPath: the two forwards below are comparable)
+    outs = {}
+    # (u2mkd_c2l_plan is not in the list: the sampled pixel head builds its full-resolution plan on the camera stream)
+    builders = ('u2mkd_csr_build', 'u2mkd_devoxelize_plan', 'u2mkd_sptr_plan_prepare', 'u2mkd_l2c_finish', 'u2mkd_l2c_keys',
+                'u2mkd_tile_schedule', 'u2mkd_pairs_build', 'u2mkd_hash', 'u2mkd_kernel_hash', 'u2mkd_sptr_quant_coords')
+    for ahead in (False, True):
+        monkeypatch.setattr(F, '_PREFETCH_PLANS', ahead)
+        with torch.no_grad():
+            for i, b in enumerate(batches):        # (the first batch teaches the network's uses of its kernel maps and map sizes)
+                in_mod = run.model.prepare(run._in_mod(T.fresh_batch(b)))
+                seen = []
+                real = L.call
+                monkeypatch.setattr(L, 'call', lambda name, *a: (seen.append(name), real(name, *a))[1])
+                out = run.model.model_s(in_mod['student'])
+                monkeypatch.setattr(L, 'call', real)
+                outs[(ahead, i)] = out['x_vox'].clone()
+                if ahead and i == 1:
+                    assert not [n for n in seen if n in builders], sorted(set(n for n in seen if n in builders))
+                if not ahead:
+                    assert any(n in builders for n in seen)
+    for i in range(2):
+        assert outs[(True, i)].shape == outs[(False, i)].shape
+        assert float((outs[(True, i)] - outs[(False, i)]).abs().max()) <= 1e-4 * float(outs[(False, i)].abs().max()), i
+
+
 def test_geometry_in_slices_gives_the_step_the_same_geometry(hip, monkeypatch):
     """train.KDStep with ``prefetch=``: the next batch's geometry queued in slices between the phases of the current step
     (U2MKD_STAGED_GEOMETRY=1, the single-rank default) against the one-piece form behind the backward (=0): the same voxel

@@ -210,6 +210,42 @@ def _c2l_plan(pixel_coordinates, masks, h, w):
     return idx8, w8
 
 
+def c2l_plan(pixel_coordinates, masks, h, w):
+    """(corner rows int32 [sum N_b, 8], corner weights f32 [sum N_b, 8]) of the camera -> LiDAR gather on h x w maps, cached on
+    ``masks[0]`` (rebuilt when a mask or a coordinate tensor changed)."""
+    from .torchsparse.nn import functional as spf
+    return spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w),
+                     *masks[1:], *pixel_coordinates)
+
+
+def l2c_plan(pixel_coordinates, masks, ch, cw):
+    """(forward CSR, backward CSR, pixels) of the LiDAR -> camera pixel-mean map on a ch x cw grid, cached on ``masks[0]``."""
+    from .torchsparse.nn import functional as spf
+    return spf._plan(masks[0], 'l2c_%d_%d' % (ch, cw), lambda: _l2c_plan(pixel_coordinates, masks, ch, cw),
+                     *masks[1:], *pixel_coordinates)
+
+
+def _l2c_grids(ifh, ifw, n_scales):
+    cnt = 1
+    for _ in range(n_scales):
+        yield int(round(float(ifh) / cnt + 0.01)), int(round(float(ifw) / cnt + 0.01))
+        cnt *= 2
+
+
+def prefetch_plans(pixel_coordinates, masks, shapes):
+    """The point <-> pixel plans of a batch for the fusion points ``shapes`` = [(map height, map width, l2c scales), ..], built
+    now on the current stream (a trainer preparing the next batch: kd.StudentMSP2IFM.prefetch_plans): the gather plan of
+    c2l_gather with the plan of its backward, and the pixel-mean maps of l2c_scatter, all of which depend on the batch's
+    pixel coordinates and masks only."""
+    from .torchsparse.nn import functional as spf
+    n_img = len(masks) * masks[0].shape[0]
+    for ifh, ifw, n_scales in shapes:
+        idx8, w8 = c2l_plan(pixel_coordinates, masks, ifh, ifw)
+        spf.devoxelize_plan(idx8, w8, n_img * ifh * ifw)
+        for ch, cw in _l2c_grids(ifh, ifw, n_scales):
+            l2c_plan(pixel_coordinates, masks, ch, cw)
+
+
 def c2l_gather(feature_maps, pixel_coordinates, masks):
     """Camera -> LiDAR gather.  feature_maps [B, ncam, C, h, w]; per sample coordinates
     [ncam, N_b, 2] and masks [ncam, N_b].  Returns [sum N_b, C], zeros outside every camera."""
@@ -217,8 +253,7 @@ def c2l_gather(feature_maps, pixel_coordinates, masks):
     _lib.require_cuda(feature_maps)                      # HIP device only; there is no CPU fallback
     from .torchsparse.nn import functional as spf
     B, ncam, C, h, w = feature_maps.shape
-    idx8, w8 = spf._plan(masks[0], 'c2l_%d_%d' % (h, w), lambda: _c2l_plan(pixel_coordinates, masks, h, w),
-                         *masks[1:], *pixel_coordinates)
+    idx8, w8 = c2l_plan(pixel_coordinates, masks, h, w)
     rows = _NchwToRows.apply(feature_maps)
     if C % 4:                                   # e.g. the 17-class logit map: pad rows to whole 16-byte segments
         rows = F.pad(rows, (0, 4 - C % 4))
@@ -354,16 +389,11 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
     from .torchsparse.nn import functional as spf
     B, ncam, C = len(masks), masks[0].shape[0], point_feats.shape[1]
     total = None
-    cnt = 1
-    for _ in range(n_scales):
-        ch = int(round(float(ifh) / cnt + 0.01))
-        cw = int(round(float(ifw) / cnt + 0.01))
-        fwd, bwd, n_dst = spf._plan(masks[0], 'l2c_%d_%d' % (ch, cw),
-                                    lambda: _l2c_plan(pixel_coordinates, masks, ch, cw), *masks[1:], *pixel_coordinates)
+    for ch, cw in _l2c_grids(ifh, ifw, n_scales):
+        fwd, bwd, n_dst = l2c_plan(pixel_coordinates, masks, ch, cw)
         grid = _SegmentMap.apply(point_feats, fwd, bwd, n_dst).view(B * ncam, ch, cw, C).permute(0, 3, 1, 2)
         up = grid if (ch, cw) == (ifh, ifw) else F.interpolate(grid, (ifh, ifw), mode='bilinear', align_corners=True)
         total = up if total is None else total + up
-        cnt *= 2
     # the grids are channel-last views; hand the camera branch (NCHW convs) a plain NCHW tensor so
     # its skip additions do not mix memory formats (strided adds were 5 ms of the KD step)
     return (total / n_scales).contiguous()

@@ -48,6 +48,7 @@ class StudentMSP2IFM(nn.Module):
         img_cs = self.pix_branch.img_cs
         self.in_channel, self.num_classes, self.out_channel = in_channel, num_classes, cs[-1]
         self.pres, self.vres = pres, vres
+        self._fusion_shapes = {}      # {(image height, width): {fusion point: (map height, map width, l2c scales)}}, seen by forward
 
         self.stem = FusedSequential(
             spnn.Conv3d(in_channel, cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]), spnn.ReLU(True),
@@ -149,6 +150,51 @@ class StudentMSP2IFM(nn.Module):
         return _Fork(im, 'camera', _CAMERA_STREAM and _overlap_ok()).on_side(
             lambda: self._camera_stage(im, 0), im)
 
+    @staticmethod
+    def _tokens(coords, stride, zz):
+        """(positions [n, 3], batch index [n]) of the attention tokens of the voxels ``coords``: the mean of the stride-1 voxel
+        features' first three columns per voxel (tsd_full.py: ``point_to_voxel(vox_out, zz)``) -- a function of the input batch
+        only.  (One copy: the plan kernels need contiguous rows.)"""
+        from .lidar.point_voxel import p2v_maps
+        idx_query, counts = p2v_maps(coords, stride, zz)
+        return spf.spvoxelize(zz.F, idx_query, counts)[:, :3].contiguous(), coords[:, 3]
+
+    @torch.no_grad()
+    def prefetch_plans(self, in_mod):
+        """Every index structure of this network's forward and backward that depends on the input batch only, built NOW on the
+        current stream from the prepared geometry ``in_mod['_geometry']``: the point <-> voxel maps of every stride with their
+        scatter / gather plans (core/models/utils.py:40-118 builds them at first use), the attention tokens' positions and the
+        window plans of the four SphereFormer blocks, the point <-> pixel plans of the four fusion points.  In the forward they
+        are ~350 small launches on the student's chain (tools/main_chain_calls.py); a trainer that prepares batch k + 1 while
+        step k runs (train.KDStep) builds them there instead, and ``forward`` finds them: in the caches the lazy path fills
+        (``z.idx_query``, ``z.additional_features``, spf._plan), or in ``x0._u2mkd_kd_plans`` for what the forward derives from
+        tensors of its own.  Same kernels, same inputs, same results; a structure that is not found is built lazily as ever."""
+        from .fusion import prefetch_plans as fusion_plans
+        from .lidar.point_voxel import p2v_maps, v2p_maps
+        z, x0 = in_mod['_geometry']
+        if x0.C.shape[0] == 0:
+            return
+        zz = PointTensor(x0.F, x0.C.float())
+        n_stage = len(self.vox_downs)
+        strides = [x0.s] + [tuple(v * 2 ** (i + 1) for v in x0.s) for i in range(n_stage)]
+        if any(x0.cmaps.get(s3) is None for s3 in strides):
+            return
+        tokens = []
+        for i, s3 in enumerate(strides):
+            coords = x0.cmaps[s3]
+            v2p_maps(coords, s3, z, plans=True)
+            p2v_maps(coords, s3, z, plans=True)
+            if i > 0:
+                p2v_maps(coords, s3, zz, plans=True)
+                tok = self._tokens(coords, s3, zz)
+                self.transformer_blocks[i - 1].attn.plans(tok[0].float(), tok[1], quantised=True)
+                tokens.append(tok)
+        x0.__dict__['_u2mkd_kd_plans'] = {'zz': zz, 'tokens': tokens}
+        im = in_mod['images']
+        shapes = self._fusion_shapes.get((int(im.shape[-2]), int(im.shape[-1])))
+        if shapes is not None and len(shapes) == n_stage:
+            fusion_plans(in_mod['pixel_coordinates'], in_mod['masks'], [shapes[i] for i in range(n_stage)])
+
     def forward(self, in_mod):
         x = in_mod['lidar']
         im = in_mod['images']                                   # [B, ncam, 3, H, W]
@@ -170,7 +216,8 @@ class StudentMSP2IFM(nn.Module):
             cam = self.camera_head(in_mod)
         # points -> stride-1 voxels + all kernel maps (every down-sample sync), prepared ahead by the trainer or here
         z, x0 = in_mod.get('_geometry') or prepare_geometry(x, self.pres, self.vres)
-        zz = PointTensor(x0.F, x0.C.float())
+        ahead = x0.__dict__.get('_u2mkd_kd_plans')      # (prefetch_plans: this batch's index structures, built a step ahead)
+        zz = ahead['zz'] if ahead is not None else PointTensor(x0.F, x0.C.float())
         x0 = self.stem(x0)
         z0 = voxel_to_point(x0, z, nearest=False)
         vox_feats = [point_to_voxel(x0, z0)]
@@ -179,8 +226,10 @@ class StudentMSP2IFM(nn.Module):
             if idx > 0:
                 cam = on_side(lambda: cam_stage(x_im, idx), x_im)      # queued ahead of this stage's LiDAR kernels
             vox_out = self.vox_downs[idx](vox_feats[idx])
-            tmp_p = point_to_voxel(vox_out, zz)
-            coord_xyz, batch = tmp_p.F[:, :3].contiguous(), tmp_p.C[:, 3]      # (one copy: the plan kernels need contiguous rows)
+            if ahead is not None:
+                coord_xyz, batch = ahead['tokens'][idx]
+            else:
+                coord_xyz, batch = self._tokens(vox_out.C, vox_out.s, zz)
             vox_out.F = self.transformer_blocks[idx](vox_out.F, coord_xyz, batch)
             pts_feat = voxel_to_point(vox_out, z0)
             if idx == n_stage - 1:
@@ -189,6 +238,7 @@ class StudentMSP2IFM(nn.Module):
             x_im, skip = cam
             join(x_im, skip)
             _, ifc, ifh, ifw = skip.shape
+            self._fusion_shapes.setdefault((ih, iw), {})[idx] = (ifh, ifw, n_stage - idx)
 
             # LiDAR -> camera: multi-scale scatter-mean of the point features into every camera's map
             l2c_feat_map = l2c_scatter(pts_feat.F, pixel_coordinates, masks, ifh, ifw, n_stage - idx)
@@ -336,20 +386,24 @@ class TSDFull(nn.Module):
         forward while step k's backward -- ~30 ms of queued kernels -- drains, instead of sitting in the next
         forward's first synchronisation for as long."""
         with torch.no_grad():
-            g_s, g_t = prepare_geometry_many([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres),
-                                              (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)])
-        in_mod['student']['_geometry'] = g_s
-        in_mod['teacher']['_geometry'] = g_t
+            g_s, g_t = prepare_geometry_many([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres, 'kd_student'),
+                                              (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres, _TEACHER_TAG)])
+            in_mod['student']['_geometry'] = g_s
+            in_mod['teacher']['_geometry'] = g_t
+            if spf.prefetch_plans_enabled():
+                self.model_s.prefetch_plans(in_mod['student'])
         return in_mod
 
     def prepare_staged(self, in_mod: dict):
         """``prepare`` as a generator that yields in front of each of its two host reads (point_voxel.prepare_geometry_staged):
         train.KDStep resumes it between the phases of the CURRENT step, so the reads find their counts ready.  The caller sets
         ``torch.no_grad()`` (and its stream / autocast contexts) around every ``next()``; returns ``in_mod``."""
-        g_s, g_t = yield from prepare_geometry_staged([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres),
-                                                       (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres)])
+        g_s, g_t = yield from prepare_geometry_staged([(in_mod['student']['lidar'], self.model_s.pres, self.model_s.vres, 'kd_student'),
+                                                       (in_mod['teacher']['lidar'], self.model_t.pres, self.model_t.vres, _TEACHER_TAG)])
         in_mod['student']['_geometry'] = g_s
         in_mod['teacher']['_geometry'] = g_t
+        if spf.prefetch_plans_enabled():
+            self.model_s.prefetch_plans(in_mod['student'])
         return in_mod
 
     def forward(self, in_mod: dict):
@@ -406,6 +460,8 @@ _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
 # MEASURED (round 6, same-box pairs): 63.3-63.6 ms with it against 62.7-63.1 ms without -- single steps drop to 57-58 ms, the mean
 # does not move: the step is bound by the GPU's total kernel time (86 ms over five streams), not by where or when the host
 # issues it (NOTES N10).  Kept as a switch: it is the measurement that settles the question.
+# (U2MKD_PREFETCH_PLANS=2: the teacher's kernel-map schedules a step ahead too; they are off the student's chain either way)
+_TEACHER_TAG = 'kd_teacher' if os.environ.get('U2MKD_PREFETCH_PLANS', '0') == '2' else None
 _TEACHER_AHEAD = int(os.environ.get('U2MKD_TEACHER_AHEAD', '0'))
 
 

@@ -102,7 +102,9 @@ def prepare_geometry_staged(items):
     if not _BATCHED:
         yield
         yield
-        return [_prepare_geometry_level_by_level(x, pres, vres) for x, pres, vres in items]
+        return [_prepare_geometry_level_by_level(*it[:3]) for it in items]
+    tags = [it[3] if len(it) > 3 else None for it in items]      # (network tags: spf.prefetch_kmaps(tag=...))
+    items = [it[:3] for it in items]
     states = [_voxelize_issue(PointTensor(x.F, x.C.float()), pres, vres) for x, pres, vres in items]
     # (the sizes are POSTED to the host mailbox by the slice that produces them and picked up by the next one: the host never
     # waits on a copy queued behind other streams' work, spf.post_counts)
@@ -116,12 +118,12 @@ def prepare_geometry_staged(items):
     yield
     values = spf.wait_counts(mail)                                             # round trip 2
     out, at = [], 0
-    for st, x0, pyr in zip(states, x0s, pyramids):
+    for st, x0, pyr, tag in zip(states, x0s, pyramids, tags):
         if pyr is None:
-            spf.prefetch_kmaps(x0, KMAP_SPECS)
+            spf.prefetch_kmaps(x0, KMAP_SPECS, tag=tag)
         else:
             k = len(totals) + 1
-            spf.prefetch_kmaps(x0, KMAP_SPECS, level_coords=pyr.finish(values[at:at + k]))
+            spf.prefetch_kmaps(x0, KMAP_SPECS, level_coords=pyr.finish(values[at:at + k]), tag=tag)
             at += k
         out.append((st['z'], x0))
     return out
@@ -151,19 +153,28 @@ def prepare_geometry(x: SparseTensor, pres, vres):
     return prepare_geometry_many([(x, pres, vres)])[0]
 
 
+def p2v_maps(coords, stride, z: PointTensor, plans=False):
+    """(idx_query, counts) of the scatter-mean of ``z``'s points into the voxels ``coords`` of tensor stride ``stride``, cached
+    in ``z.additional_features`` as core/models/utils.py:40-65 does.  ``plans``: also the scatter plan spvoxelize hangs on the
+    index (a trainer preparing a batch ahead)."""
+    cache = z.additional_features
+    if cache is None or cache.get('idx_query') is None or cache['idx_query'].get(stride) is None:
+        pc_hash = spf.sphash(_floor_coords(z.C, stride[0]))
+        idx_query = spf.coords_table(coords).query_with_i32(pc_hash)
+        counts = spf.spcount(spf._plan(idx_query, 'i32', lambda: idx_query.int().contiguous()), coords.shape[0])
+        z.additional_features['idx_query'][stride] = idx_query
+        z.additional_features['counts'][stride] = counts
+    else:
+        idx_query = cache['idx_query'][stride]
+        counts = cache['counts'][stride]
+    if plans:
+        spf.voxelize_plan(idx_query, counts.shape[0])
+    return idx_query, counts
+
+
 def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     """Scatter-mean point features into the voxels of ``x`` (utils.py:40-65)."""
-    cache = z.additional_features
-    if cache is None or cache.get('idx_query') is None or cache['idx_query'].get(x.s) is None:
-        pc_hash = spf.sphash(_floor_coords(z.C, x.s[0]))
-        idx_query = spf.coords_table(x.C).query_with_i32(pc_hash)
-        counts = spf.spcount(spf._plan(idx_query, 'i32', lambda: idx_query.int().contiguous()), x.C.shape[0])
-        z.additional_features['idx_query'][x.s] = idx_query
-        z.additional_features['counts'][x.s] = counts
-    else:
-        idx_query = cache['idx_query'][x.s]
-        counts = cache['counts'][x.s]
-
+    idx_query, counts = p2v_maps(x.C, x.s, z)
     inserted_feat = spf.spvoxelize(z.F, idx_query, counts)
     new_tensor = SparseTensor(inserted_feat, x.C, x.s)
     new_tensor.cmaps = x.cmaps
@@ -171,28 +182,33 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     return new_tensor
 
 
-def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTensor:
-    """Trilinear devoxelisation of ``x`` at the points of ``z`` (utils.py:70-118)."""
-    if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None \
-            or z.weights.get(x.s) is None:
-        off = get_kernel_offsets(2, x.s, 1, device=z.F.device)
-        old_hash = spf.sphash(_floor_coords(z.C, x.s[0]), off)          # [8, N]
-        idx_kn = spf.coords_table(x.C.to(z.F.device)).query(old_hash)
-        weights, idx_query = spf.ti_weights_n8(z.C, idx_kn, scale=x.s[0])   # [N,8], [N,8]
+def v2p_maps(coords, stride, z: PointTensor, nearest=False, plans=False):
+    """(idx_query [N, 8], weights [N, 8]) of the trilinear devoxelisation of the voxels ``coords`` (tensor stride
+    ``stride``) at ``z``'s points, cached in ``z.idx_query`` / ``z.weights`` (utils.py:70-118).  ``plans``: also the backward's
+    gather plan (spf.devoxelize_plan)."""
+    if z.idx_query is None or z.weights is None or z.idx_query.get(stride) is None or z.weights.get(stride) is None:
+        off = get_kernel_offsets(2, stride, 1, device=z.F.device)
+        old_hash = spf.sphash(_floor_coords(z.C, stride[0]), off)          # [8, N]
+        idx_kn = spf.coords_table(coords.to(z.F.device)).query(old_hash)
+        weights, idx_query = spf.ti_weights_n8(z.C, idx_kn, scale=stride[0])   # [N,8], [N,8]
         if nearest:
             weights[:, 1:] = 0.
             idx_query[:, 1:] = -1
-        new_feat = spf.spdevoxelize(x.F, idx_query, weights)
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
-        new_tensor.idx_query[x.s] = idx_query
-        new_tensor.weights[x.s] = weights
-        z.idx_query[x.s] = idx_query
-        z.weights[x.s] = weights
+        z.idx_query[stride] = idx_query          # (the tensors voxel_to_point derives from z share these dictionaries)
+        z.weights[stride] = weights
     else:
-        new_feat = spf.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
+        idx_query, weights = z.idx_query.get(stride), z.weights.get(stride)
+    if plans:
+        spf.devoxelize_plan(idx_query, weights, coords.shape[0])
+    return idx_query, weights
+
+
+def voxel_to_point(x: SparseTensor, z: PointTensor, nearest=False) -> PointTensor:
+    """Trilinear devoxelisation of ``x`` at the points of ``z`` (utils.py:70-118)."""
+    idx_query, weights = v2p_maps(x.C, x.s, z, nearest)
+    new_feat = spf.spdevoxelize(x.F, idx_query, weights)
+    new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+    new_tensor.additional_features = z.additional_features
     return new_tensor
 
 

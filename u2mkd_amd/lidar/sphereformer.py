@@ -102,17 +102,32 @@ class SparseMultiheadSASphereConcat(nn.Module):
         self.qkv = PointLinear(embed_dim, embed_dim * 3, bias=True)
         self.proj = PointLinear(embed_dim, embed_dim)
 
+    def plans(self, xyz, batch, quantised=False):
+        """(cubic window plan, spherical window plan, spherical coordinates) of the tokens ``xyz`` [N, 3] float / ``batch`` [N]:
+        everything of the attention that depends on the token POSITIONS only (spherical_transformer.py:31-36, 206-213).  On
+        the device the triple is cached on ``xyz`` (spf._plan), so a caller that knows the positions ahead of the features -- a
+        trainer preparing the next batch, kd.py ``prefetch_plans`` -- builds it there (``quantised``: and the quantised
+        in-window coordinates both branches look their tables up with) and the forward finds it."""
+        if xyz.is_cuda and cart2sphere is _cart2sphere_torch:
+            from ..torchsparse.nn import functional as spf
+            key = 'sptr_pair_%r_%r' % (tuple(float(v) for v in self.window_size), tuple(float(v) for v in self.window_size_sphere))
+            plan, plan_s, xyz_sphere = spf._plan(
+                xyz, key, lambda: sptr.WindowPlan.pair(xyz, batch, self.window_size, self.window_size_sphere), batch)
+        else:
+            xyz_sphere = cart2sphere(xyz)
+            plan = sptr.WindowPlan(xyz, batch, self.window_size)
+            plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
+        if quantised:
+            plan.quant_coords(xyz, self.quant_size, False)
+            plan_s.quant_coords(xyz_sphere, self.quant_size_sphere, True)
+        return plan, plan_s, xyz_sphere
+
     def forward(self, feats, xyz, batch):
         N, C = feats.shape
         qkv = self.qkv(feats).reshape(N, 3, self.num_heads, C // self.num_heads)
         h1 = self.num_heads_brc1
         xyz = xyz.float()
-        if xyz.is_cuda and cart2sphere is _cart2sphere_torch:
-            plan, plan_s, xyz_sphere = sptr.WindowPlan.pair(xyz, batch, self.window_size, self.window_size_sphere)
-        else:
-            xyz_sphere = cart2sphere(xyz)
-            plan = sptr.WindowPlan(xyz, batch, self.window_size)
-            plan_s = sptr.WindowPlan(xyz_sphere, batch, self.window_size_sphere)
+        plan, plan_s, xyz_sphere = self.plans(xyz, batch)
         cubic = (0, h1, xyz, plan, self.quant_size, self.quant_grid_length,
                  (self.relative_pos_query_table, self.relative_pos_key_table, self.relative_pos_value_table), None)
         sphere = (h1, self.num_heads - h1, xyz_sphere, plan_s, self.quant_size_sphere, self.quant_grid_length_sphere,

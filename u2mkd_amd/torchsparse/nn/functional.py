@@ -137,6 +137,20 @@ def _rows(t, b16):
     return t.contiguous().to(torch.bfloat16 if b16 else torch.float32)
 
 
+# U2MKD_PREFETCH_PLANS=0 (default): every derived index structure (tile / pair schedules, weight-gradient pairs, the scatter plans
+# of voxelize / devoxelize, window plans, point <-> pixel plans) is built at its first use inside the forward / backward pass, as in
+# rounds 1-5; 1: a trainer that prepares the next batch's geometry ahead builds them there too (train.KDStep, kd.py; 2: and the
+# teacher's schedules).  Round 6 built it to take ~350 small launches per step off the student's stream -- and measured the step
+# 0.4-0.5 ms SLOWER (2: 1.5 ms; with the geometry stream on a hardware queue of its own 2.4 ms): on the runtime's four hardware
+# queues the geometry stream shares the main stream's queue, so the launches leave the forward but not the queue they wait in, and
+# wherever they do run next to the step's kernels they cost more than in line (NOTES N10.9).  Kept as a switch, results identical.
+_PREFETCH_PLANS = os.environ.get('U2MKD_PREFETCH_PLANS', '0') != '0'
+
+
+def prefetch_plans_enabled():
+    return _PREFETCH_PLANS
+
+
 # ------------------------------------------------- destination-sorted scatter plans
 def _csr_by_destination(keys: torch.Tensor, nv: int):
     """(entry order int32 [E], segment offsets int32 [nv+1]) of the entries with 0 <= key < nv, grouped by key, ascending
@@ -190,7 +204,7 @@ class VoxelizeFunction(Function):
             return torch.zeros(nv, c, dtype=feats.dtype, device=feats.device)
         if c % 4 == 0:
             # deterministic scatter-mean: points grouped by voxel once per map, then a gather-sum
-            order, seg = _plan(coords, 'vox_csr_%d' % nv, lambda: _csr_by_destination(coords, nv))
+            order, seg = voxelize_plan(coords, nv)
             out = _segment_sum(feats, order, None, seg, nv, True)
         else:
             out = torch.zeros(nv, c, dtype=torch.float32, device=feats.device)
@@ -211,12 +225,23 @@ class VoxelizeFunction(Function):
         return gi, None, None
 
 
-def spvoxelize(feats, coords, counts):
+def _idx32(coords):
     # the model caches idx_query (int64, from sphashquery) per stride; keep its int32 form -- and the
     # destination-sorted plan hung on it -- alive on that cached tensor instead of re-deriving per call
     if coords.dtype != torch.int32 or not coords.is_contiguous():
         coords = _plan(coords, 'i32', lambda: coords.int().contiguous())
-    return VoxelizeFunction.apply(feats, coords, counts)
+    return coords
+
+
+def voxelize_plan(coords, nv):
+    """(order, seg) of spvoxelize's scatter-mean: the points grouped by voxel (cached on the index tensor).  ``coords`` = the
+    point -> voxel index as spvoxelize receives it."""
+    coords = _idx32(coords)
+    return _plan(coords, 'vox_csr_%d' % nv, lambda: _csr_by_destination(coords, nv))
+
+
+def spvoxelize(feats, coords, counts):
+    return VoxelizeFunction.apply(feats, _idx32(coords), counts)
 
 
 # --------------------------------------------------------------- devoxelize
@@ -245,16 +270,7 @@ class DevoxelizeFunction(Function):
         if n == 0:
             return torch.zeros(nv, c, dtype=g.dtype, device=g.device), None, None
         if c % 4 == 0:
-            def build():
-                # zero-weight corners dropped, the rest grouped by voxel: keys + counting sort + (row, weight) in one call
-                erow = torch.empty(8 * n, dtype=torch.int32, device=g.device)
-                ew = torch.empty(8 * n, dtype=torch.float32, device=g.device)
-                seg = torch.empty(nv + 1, dtype=torch.int32, device=g.device)
-                ws = torch.empty(max(L.load().u2mkd_devoxelize_plan_workspace_bytes(n, nv), 16), dtype=torch.uint8, device=g.device)
-                L.call('u2mkd_devoxelize_plan', L.ptr(coords), L.ptr(weights), n, nv, L.ptr(ws), L.ptr(erow), L.ptr(ew), L.ptr(seg),
-                       L.stream())
-                return erow, ew, seg
-            erow, ew, seg = _plan(coords, 'devox_csr_%d' % nv, build, weights)
+            erow, ew, seg = devoxelize_plan(coords, weights, nv)
             gi = _segment_sum(g, erow, ew, seg, nv, False)
         else:
             g = g.float()
@@ -262,6 +278,24 @@ class DevoxelizeFunction(Function):
             L.call('u2mkd_devoxelize_backward', L.ptr(g), L.ptr(coords), L.ptr(weights), n, nv, c, L.ptr(gi),
                    L.stream())
         return gi, None, None
+
+
+def devoxelize_plan(coords, weights, nv):
+    """(entry row, entry weight, seg) of spdevoxelize's BACKWARD (a scatter of 8 weighted corners per point, as a gather-sum per
+    voxel): zero-weight corners dropped, the rest grouped by voxel -- keys + counting sort + (row, weight) in one call.  Cached on
+    the index tensor; ``coords`` int32 [n, 8] contiguous, ``weights`` f32 [n, 8] contiguous, as DevoxelizeFunction holds them."""
+    n = coords.shape[0]
+
+    def build():
+        dev = coords.device
+        erow = torch.empty(8 * n, dtype=torch.int32, device=dev)
+        ew = torch.empty(8 * n, dtype=torch.float32, device=dev)
+        seg = torch.empty(nv + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(L.load().u2mkd_devoxelize_plan_workspace_bytes(n, nv), 16), dtype=torch.uint8, device=dev)
+        L.call('u2mkd_devoxelize_plan', L.ptr(coords), L.ptr(weights), n, nv, L.ptr(ws), L.ptr(erow), L.ptr(ew), L.ptr(seg),
+               L.stream())
+        return erow, ew, seg
+    return _plan(coords, 'devox_csr_%d' % nv, build, weights)
 
 
 def spdevoxelize(feats, coords, weights):
@@ -697,6 +731,15 @@ class PairSchedule:
         return out
 
 
+# What a network asked of its kernel maps so far: {(network tag, map key): {('schedule', inverse), 'pair_schedule', 'pairs_plan'}}.
+# The tile schedule, the pair schedule and the weight gradient's compacted pairs are built at a map's FIRST use -- in the middle
+# of a forward / backward pass, on the stream that pass runs on (27 such builds, ~150 small launches, per KD step on the
+# student's chain).  They depend on the map only, and which of them a network needs is a property of the network (channel
+# counts), not of the batch: prefetch_kmaps(tag=...) builds, next to the maps of batch k + 1, what the same network asked of the
+# maps of the batches before (on the stream the geometry is prepared on; a use seen for the first time is built lazily as ever).
+KMAP_USES = {}
+
+
 class KernelMap:
     """Kernel map of one (tensor_stride, kernel_size, stride, dilation) key.
 
@@ -719,6 +762,25 @@ class KernelMap:
         self._pairs = None
         self._sorted = {}
         self._pair_schedule = None
+        self.tag = None          # (network tag, map key): set by prefetch_kmaps(tag=...), see KMAP_USES
+
+    def _note(self, use):
+        if self.tag is not None:
+            uses = KMAP_USES.get(self.tag)
+            if uses is None:
+                uses = KMAP_USES[self.tag] = set()
+            uses.add(use)
+
+    def prebuild(self, uses):
+        """Build the derived structures in ``uses`` now, on the current stream (prefetch_kmaps: what the same network asked
+        of the same map key in earlier steps)."""
+        for use in sorted(uses, key=repr):
+            if use == 'pair_schedule':
+                self.pair_schedule()
+            elif use == 'pairs_plan':
+                self.pairs_plan()
+            elif use[0] == 'schedule' and (not use[1] or self.nbr_inv is not None):
+                self.schedule(use[1])
 
     def sorted_table(self, inverse=False):
         """(table with its rows permuted into schedule order, order int32 [rows])."""
@@ -728,6 +790,7 @@ class KernelMap:
         """The tile schedule of the (inverse) neighbour table (cached)."""
         hit = self._sorted.get(inverse)
         if hit is None:
+            self._note(('schedule', bool(inverse)))
             hit = TileSchedule(self.nbr_inv if inverse else self.nbr)
             self._sorted[inverse] = hit
         return hit
@@ -735,6 +798,7 @@ class KernelMap:
     def pair_schedule(self):
         """The pair schedule of the map (cached; serves forward, transposed and dgrad)."""
         if self._pair_schedule is None:
+            self._note('pair_schedule')
             self._pair_schedule = PairSchedule(self.nbr, self.n_in)
         return self._pair_schedule
 
@@ -744,6 +808,7 @@ class KernelMap:
         kernel.  Built without any host synchronisation: the pair buffer is sized by
         the upper bound K * n_out and only its first P rows are meaningful."""
         if self._pairs is None:
+            self._note('pairs_plan')
             k, n_out = self.k, self.n_out
             dev = self.nbr.device
             nblocks = max((n_out + 1023) // 1024, 1)
@@ -812,7 +877,7 @@ def build_kmap(coords: torch.Tensor, tensor_stride, kernel_size, stride, out_coo
     return KernelMap(nbr, nbr_inv, n_in, n_out, symmetric, out_coords)
 
 
-def prefetch_kmaps(x: SparseTensor, specs, level_coords=None) -> None:
+def prefetch_kmaps(x: SparseTensor, specs, level_coords=None, tag=None) -> None:
     """Build the kernel maps a network is about to ask for, in one go.
 
     ``specs`` lists (kernel_size, stride) of the convs that create maps, in forward order.
@@ -823,7 +888,8 @@ def prefetch_kmaps(x: SparseTensor, specs, level_coords=None) -> None:
     Prefetching moves those stops to the start of the step, where the GPU queue is empty
     anyway; everything after is queued without waiting.  Results land in ``x.kmaps`` /
     ``x.cmaps`` exactly as the lazy path would leave them.  ``level_coords`` = {total stride: coords} from a
-    DownsamplePyramid: the strided maps then take their output coordinates from it and the loop never waits."""
+    DownsamplePyramid: the strided maps then take their output coordinates from it and the loop never waits.  ``tag``: the
+    network these maps are for (any hashable): the schedules it asked of earlier batches' maps are built here too (KMAP_USES)."""
     coords, ts = x.coords, x.stride
     x.cmaps.setdefault(ts, coords)
     one = (1, 1, 1)
@@ -836,6 +902,9 @@ def prefetch_kmaps(x: SparseTensor, specs, level_coords=None) -> None:
             if level_coords is not None and stride != one:
                 nxt = level_coords.get(tuple(ts[k] * stride[k] for k in range(3)))
             kmap = x.kmaps[key] = build_kmap(coords, ts, kernel_size, stride, out_coords=nxt)
+            if tag is not None and _PREFETCH_PLANS:
+                kmap.tag = (tag, key)
+                kmap.prebuild(KMAP_USES.get(kmap.tag, ()))
         if stride != one:
             coords, ts = kmap.out_coords, tuple(ts[k] * stride[k] for k in range(3))
             x.cmaps.setdefault(ts, coords)

@@ -266,7 +266,7 @@ def _tensors_of(obj, seen=None, depth=0):
     PointTensor / SparseTensor with their coordinate and kernel-map dictionaries, KernelMap objects with their tables and
     schedules, tensors' cached `_u2mkd_plans`)."""
     seen = set() if seen is None else seen
-    if id(obj) in seen or depth > 8:
+    if id(obj) in seen or depth > 14:
         return
     seen.add(id(obj))
     if torch.is_tensor(obj):
@@ -407,7 +407,9 @@ class KDStep:
                 KD.teacher_ahead(self.model, done, after=(entry, self._geo_done, after_bwd))
             users = [torch.cuda.current_stream(), KD._side_stream(d['s_feats'], 'teacher'), KD._side_stream(d['s_feats'], 'camera')]
             for key in ('student', 'teacher'):
-                for t in _tensors_of(self._queued[1][key].get('_geometry')):
+                nxt = self._queued[1][key]
+                # (the geometry, and the point <-> pixel plans kd.StudentMSP2IFM.prefetch_plans hung on the batch's masks)
+                for t in _tensors_of([nxt.get('_geometry'), nxt.get('masks')]):
                     for st in users:
                         t.record_stream(st)
             return ld['total'].detach()
@@ -433,7 +435,8 @@ class KDStep:
             # allocator holds its block until those streams have passed that point (~200 tensors, ~0.2 ms of host time a step)
             users = [torch.cuda.current_stream(), KD._side_stream(d['s_feats'], 'teacher'), KD._side_stream(d['s_feats'], 'camera')]
             for key in ('student', 'teacher'):
-                for t in _tensors_of(self._queued[1][key].get('_geometry')):
+                nxt = self._queued[1][key]
+                for t in _tensors_of([nxt.get('_geometry'), nxt.get('masks')]):
                     for st in users:
                         t.record_stream(st)
             return ld['total'].detach()
