@@ -180,19 +180,22 @@ class StudentMSP2IFM(nn.Module):
         if any(x0.cmaps.get(s3) is None for s3 in strides):
             return
         tokens = []
+        parts = spf._PREFETCH_PARTS
         for i, s3 in enumerate(strides):
             coords = x0.cmaps[s3]
-            v2p_maps(coords, s3, z, plans=True)
-            p2v_maps(coords, s3, z, plans=True)
-            if i > 0:
+            if 'A' in parts:
+                v2p_maps(coords, s3, z, plans=True)
+                p2v_maps(coords, s3, z, plans=True)
+            if i > 0 and 'C' in parts:
                 p2v_maps(coords, s3, zz, plans=True)
                 tok = self._tokens(coords, s3, zz)
                 self.transformer_blocks[i - 1].attn.plans(tok[0].float(), tok[1], quantised=True)
                 tokens.append(tok)
-        x0.__dict__['_u2mkd_kd_plans'] = {'zz': zz, 'tokens': tokens}
+        if 'C' in parts:
+            x0.__dict__['_u2mkd_kd_plans'] = {'zz': zz, 'tokens': tokens}
         im = in_mod['images']
         shapes = self._fusion_shapes.get((int(im.shape[-2]), int(im.shape[-1])))
-        if shapes is not None and len(shapes) == n_stage:
+        if shapes is not None and len(shapes) == n_stage and 'D' in parts:
             fusion_plans(in_mod['pixel_coordinates'], in_mod['masks'], [shapes[i] for i in range(n_stage)])
 
     def forward(self, in_mod):

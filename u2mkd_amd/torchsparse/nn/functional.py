@@ -145,6 +145,7 @@ def _rows(t, b16):
 # queues the geometry stream shares the main stream's queue, so the launches leave the forward but not the queue they wait in, and
 # wherever they do run next to the step's kernels they cost more than in line (NOTES N10.9).  Kept as a switch, results identical.
 _PREFETCH_PLANS = os.environ.get('U2MKD_PREFETCH_PLANS', '0') != '0'
+_PREFETCH_PARTS = os.environ.get('U2MKD_PREFETCH_PARTS', 'ABCD')      # (A/B runs: A maps, B kernel-map schedules, C window plans, D fusion plans)
 
 
 def prefetch_plans_enabled():
@@ -902,7 +903,7 @@ def prefetch_kmaps(x: SparseTensor, specs, level_coords=None, tag=None) -> None:
             if level_coords is not None and stride != one:
                 nxt = level_coords.get(tuple(ts[k] * stride[k] for k in range(3)))
             kmap = x.kmaps[key] = build_kmap(coords, ts, kernel_size, stride, out_coords=nxt)
-            if tag is not None and _PREFETCH_PLANS:
+            if tag is not None and _PREFETCH_PLANS and 'B' in _PREFETCH_PARTS:
                 kmap.tag = (tag, key)
                 kmap.prebuild(KMAP_USES.get(kmap.tag, ()))
         if stride != one:
