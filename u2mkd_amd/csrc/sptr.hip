@@ -529,23 +529,39 @@ sptr_bwd_query_body(const float *__restrict__ q, const float *__restrict__ k, co
             float dqi[kHd];
 #pragma unroll
             for (int d = 0; d < kHd; ++d) dqi[d] = 0.f;
+            // the pair's index chain (sorted position -> token id, quantised coordinates) is loaded ONE PAIR AHEAD: with one or two
+            // waves per SIMD nothing else hides the two dependent global latencies of a pair (index, then the token's rows)
+            int64_t tj_n = 0;
+            int qcj_n[3] = {0, 0, 0};
+            float rj_n = 0.f;
+            if (sub < wl) {
+                const int pj = ws + sub;
+                tj_n = sort_idx[pj];
+                qcj_n[0] = qc[pj * 3]; qcj_n[1] = qc[pj * 3 + 1]; qcj_n[2] = qc[pj * 3 + 2];
+                rj_n = radial ? radial[pj] : 0.f;
+            }
             for (int jj = sub; jj < wl; jj += S) {
-                const int pj = ws + jj;
-                const int64_t tj = sort_idx[pj];
-                int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
-                float rj = radial ? radial[pj] : 0.f;
+                const int64_t tj = tj_n;
+                int qcj[3] = {qcj_n[0], qcj_n[1], qcj_n[2]};
+                float rj = rj_n;
                 float xj[kHd], ts[kHd], tks[kHd];
+                float vj[kHd], tvs[kHd];
+                load16(k + tj * hc + hh * kHd, xj);
+                load16(v + tj * hc + hh * kHd, vj);
+                if (jj + S < wl) {
+                    const int pn = ws + jj + S;
+                    tj_n = sort_idx[pn];
+                    qcj_n[0] = qc[pn * 3]; qcj_n[1] = qc[pn * 3 + 1]; qcj_n[2] = qc[pn * 3 + 2];
+                    rj_n = radial ? radial[pn] : 0.f;
+                }
                 int r[3];
                 rel_rows(rc, qci, ri, qcj, rj, r);
-                load16(k + tj * hc + hh * kHd, xj);
                 tab_sum(Tq, r, ts);
                 tab_sum(Tk, r, tks);
                 float s = 0.f;
 #pragma unroll
                 for (int d = 0; d < kHd; ++d) s += qi[d] * (xj[d] + ts[d]) + xj[d] * tks[d];
                 float pr = __expf(s - lse_i);
-                float vj[kHd], tvs[kHd];
-                load16(v + tj * hc + hh * kHd, vj);
                 tab_sum(Tv, r, tvs);
                 float dp = 0.f;
 #pragma unroll
@@ -655,29 +671,47 @@ sptr_bwd_key_body(const float *__restrict__ q, const float *__restrict__ k, cons
             float dki[kHd], dvi[kHd];
 #pragma unroll
             for (int d = 0; d < kHd; ++d) { dki[d] = 0.f; dvi[d] = 0.f; }
+            // (the query's index chain and its two scalars one pair ahead, as in the query role)
+            int64_t tj_n = 0;
+            int qcj_n[3] = {0, 0, 0};
+            float rj_n = 0.f, lse_n = 0.f, del_n = 0.f;
+            if (sub < wl) {
+                const int pj = ws + sub;
+                tj_n = sort_idx[pj];
+                qcj_n[0] = qc[pj * 3]; qcj_n[1] = qc[pj * 3 + 1]; qcj_n[2] = qc[pj * 3 + 2];
+                rj_n = radial ? radial[pj] : 0.f;
+                lse_n = lse[pj * h + hh]; del_n = delta[pj * h + hh];
+            }
             for (int jj = sub; jj < wl; jj += S) {
-                const int pj = ws + jj;                       // the QUERY of this pair
-                const int64_t tj = sort_idx[pj];
-                int qcj[3] = {qc[pj * 3], qc[pj * 3 + 1], qc[pj * 3 + 2]};
-                float rj = radial ? radial[pj] : 0.f;
-                int r[3];
-                rel_rows(rc, qcj, rj, qci, ri, r);
+                const int64_t tj = tj_n;                      // the QUERY of this pair
+                int qcj[3] = {qcj_n[0], qcj_n[1], qcj_n[2]};
+                float rj = rj_n;
+                const float lse_j = lse_n, del_j = del_n;
                 float qj[kHd], doj[kHd], ts[kHd], tks[kHd], tvs[kHd];
                 load16(q + tj * hc + hh * kHd, qj);
+                load16(dout + tj * (size_t)ly.ld_out + hh * kHd, doj);
+                if (jj + S < wl) {
+                    const int pn = ws + jj + S;
+                    tj_n = sort_idx[pn];
+                    qcj_n[0] = qc[pn * 3]; qcj_n[1] = qc[pn * 3 + 1]; qcj_n[2] = qc[pn * 3 + 2];
+                    rj_n = radial ? radial[pn] : 0.f;
+                    lse_n = lse[pn * h + hh]; del_n = delta[pn * h + hh];
+                }
+                int r[3];
+                rel_rows(rc, qcj, rj, qci, ri, r);
 #pragma unroll
                 for (int d = 0; d < kHd; ++d) qj[d] *= ly.q_scale;
-                load16(dout + tj * (size_t)ly.ld_out + hh * kHd, doj);
                 tab_sum(Tq, r, ts);
                 tab_sum(Tk, r, tks);
                 float s2 = 0.f;
 #pragma unroll
                 for (int d = 0; d < kHd; ++d) s2 += qj[d] * (ki[d] + ts[d]) + ki[d] * tks[d];
-                float pr2 = __expf(s2 - lse[pj * h + hh]);
+                float pr2 = __expf(s2 - lse_j);
                 tab_sum(Tv, r, tvs);
                 float dp2 = 0.f;
 #pragma unroll
                 for (int d = 0; d < kHd; ++d) dp2 += doj[d] * (vi[d] + tvs[d]);
-                float ds2 = pr2 * (dp2 - delta[pj * h + hh]);
+                float ds2 = pr2 * (dp2 - del_j);
 #pragma unroll
                 for (int d = 0; d < kHd; ++d) {
                     dki[d] += ds2 * (qj[d] + tks[d]);
