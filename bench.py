@@ -280,7 +280,7 @@ def roofline_leg(coords_dev, iters=200, cold_sets=8):
     # HBM bytes per launch group from the committed PMC run (rocprofv3 cannot run inside this process);
     # only quoted when it was taken on the same map (same N and P)
     traffic = None
-    for name in ('r5_traffic.json', 'r4_traffic.json'):
+    for name in ('r6_traffic.json', 'r5_traffic.json', 'r4_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 tj = json.load(f)
