@@ -444,6 +444,23 @@ int u2mkd_maxpool3s2_backward(const float *dy, const uint8_t *code, int64_t plan
 /* out[b][j][i] = in[b][i][j] (fp32): the NCHW <-> channel-last-rows copies around the point <-> pixel gathers
  * (`features.permute(...)` of core/models/fusion_blocks.py:241-254, tsd_full.py:482-495) as an LDS-tiled transpose      */
 int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, u2mkd_stream_t s);
+/* the same with every element multiplied by `scale` */
+int u2mkd_transpose_batched_scaled(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, float scale,
+                                   u2mkd_stream_t s);
+
+/* LiDAR -> camera scatter, the combination of its grids (spvcnn_swiftnet18_spformer_tsd_full.py:448-478: the per-scale pixel
+ * means are up-sampled to the feature map's size -- F.interpolate(bilinear, align_corners=True) -- and averaged).
+ *   u2mkd_l2c_combine_forward   out_rows[img][y][x][:] = g0[img][y][x][:] + sum_{s >= 1} bilinear(g_s[img])(y, x)[:]
+ *                               g0 [n_img, h, w, c] and g_s [n_img, ch_s, cw_s, c] channel-last rows (the segment means),
+ *                               out_rows [n_img*h*w, c]; the caller's scaled transpose (1 / n_grids) makes the NCHW map.
+ *   u2mkd_l2c_combine_backward  d_grid[img][i][j][:] = sum over the (y, x) that read cell (i, j) of weight * g_rows[img][y][x][:]
+ *                               (the exact adjoint of the forward's taps, a gather in fixed order: reproducible; torch's
+ *                               up-sampling gradient adds atomically); the full-resolution grid's gradient is g_rows itself. */
+int u2mkd_l2c_combine_forward(const float *g0, const float *g1, const float *g2, const float *g3, int32_t n_grids, int32_t n_img,
+                              int32_t h, int32_t w, int32_t c, int32_t ch1, int32_t cw1, int32_t ch2, int32_t cw2, int32_t ch3,
+                              int32_t cw3, float *out_rows, u2mkd_stream_t s);
+int u2mkd_l2c_combine_backward(const float *g_rows, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t ch, int32_t cw,
+                               float *d_grid, u2mkd_stream_t s);
 
 /* One fusion stage's camera -> LiDAR select and pseudo-feature loss (spvcnn_swiftnet18_spformer_tsd_full.py:489-498):
  * out = fov ? gathered : pseudo (rows), loss = mean over the fov rows of (pseudo - gathered)^2 (nn.MSELoss on the

@@ -77,3 +77,31 @@ def test_select_and_mse_equals_the_torch_formulation(hip, n, c, frac):
     # reproducible: the partial sums are merged in workgroup order
     o3, l3 = kd._select_and_mse(gathered.detach(), pseudo.detach(), fov)
     assert torch.equal(l1.detach(), l3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw,n_scales,c', [((23, 40), 3, 64), ((12, 20), 1, 32), ((45, 80), 4, 16), ((9, 7), 2, 8)])
+def test_l2c_combine_equals_the_torch_formulation(hw, n_scales, c, monkeypatch):
+    """l2c_scatter's grids combined by csrc/pixhead.hip (l2c_combine_*: one full-resolution sum over the channel-last grids + a
+    scaled transpose; backward: the scaled transpose and one gather per coarse grid) against the torch formulation it replaces
+    (F.interpolate(bilinear, align_corners=True) per scale, adds, a division, a layout copy): values and the gradient with
+    respect to the point features."""
+    from u2mkd_amd import fusion
+    torch.manual_seed(3)
+    ncam, n_pts = 3, 700
+    coords = [(torch.rand(ncam, n_pts, 2, device='cuda') * 2.2 - 1.1), (torch.rand(ncam, 311, 2, device='cuda') * 2.2 - 1.1)]
+    masks = [torch.rand(ncam, n_pts, device='cuda') < 0.6, torch.rand(ncam, 311, device='cuda') < 0.6]
+    feats = torch.randn(n_pts + 311, c, device='cuda')
+    wgt = torch.randn(len(masks) * ncam, c, *hw, device='cuda')
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(fusion, '_L2C_COMBINE', on)
+        x = feats.clone().requires_grad_(True)
+        out = fusion.l2c_scatter(x, coords, [m.clone() for m in masks], hw[0], hw[1], n_scales)
+        assert out.shape == wgt.shape and out.is_contiguous()
+        (out * wgt).sum().backward()
+        res[on] = (out.detach(), x.grad.detach())
+    scale = float(res[False][0].abs().max()) + 1e-12
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-6 * max(scale, 1.0)
+    gscale = float(res[False][1].abs().max()) + 1e-12
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-5 * max(gscale, 1.0)

@@ -163,6 +163,9 @@ SIGNATURES = {
     'u2mkd_maxpool3s2_forward': (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_maxpool3s2_backward': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     'u2mkd_transpose_batched': (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    'u2mkd_transpose_batched_scaled': (C.c_int, [_p, _p, _i32, _i32, _i32, C.c_float, _p]),
+    'u2mkd_l2c_combine_forward': (C.c_int, [_p, _p, _p, _p] + [_i32] * 11 + [_p, _p]),
+    'u2mkd_l2c_combine_backward': (C.c_int, [_p] + [_i32] * 6 + [_p, _p]),
     'u2mkd_up_plan': (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p, _p]),
     'u2mkd_upbn_stats': (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_upbn_dense_grad': (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),

@@ -430,7 +430,9 @@ static int bn_train_forward_impl(const T *x, const T *res, int64_t n, int32_t c,
     U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward: null pointer");
     hipStream_t st = as_stream(s);
     int nslab = (int)u2mkd_bn_num_slabs(n);
+#ifndef U2MKD_EXP_SKIP_BN_STATS      // (tools/build_variant.sh: an UPPER BOUND on what statistics taken in the producer's store could buy)
     hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(nslab), dim3(kBnThreads), bn_lds_bytes(c, 1), st, x, n, c, partial);
+#endif
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, nslab, n, c,
                        eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked);
     int64_t total4 = n * (c / 4);

@@ -137,7 +137,7 @@ upbn_dense_grad_kernel(const float *__restrict__ X, int C, int h, int w, const f
 // (torch's permute().contiguous() runs this copy at ~0.7 TB/s: 0.5 ms for the 177 MB decoder map.)
 constexpr int kTrTile = 64;
 __global__ void __launch_bounds__(256)
-transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols, float scale = 1.f) {
     __shared__ float tile[kTrTile][kTrTile + 1];
     const size_t plane = (size_t)blockIdx.z * rows * cols;
     const int c0 = blockIdx.x * kTrTile, r0 = blockIdx.y * kTrTile;
@@ -151,8 +151,93 @@ transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows
 #pragma unroll
     for (int k = 0; k < kTrTile; k += 4) {
         const int c = c0 + ty + k, r = r0 + tx;
-        if (c < cols && r < rows) out[plane + (size_t)c * rows + r] = tile[tx][ty + k];
+        if (c < cols && r < rows) out[plane + (size_t)c * rows + r] = tile[tx][ty + k] * scale;
     }
+}
+
+// ---- LiDAR -> camera: the multi-scale pixel-mean grids of one fusion point combined (tsd_full.py:448-478) ---------------------
+// l2c_scatter averages n grids -- the points' pixel-mean map on the (H, W) feature grid and on (H/2, W/2), (H/4, W/4), ... --
+// after up-sampling each to (H, W) (bilinear, align_corners=True).  As torch operations that was n - 1 up-samplings, n - 1
+// additions, a division and a layout copy over maps the LiDAR and the camera branch both wait for (1.1 GB of traffic per KD step
+// forward, 1.5 GB backward with an atomic up-sampling gradient).  Here: the grids are channel-last rows [img][y][x][C]
+// (what the segment-mean produces); ONE kernel sums them at full resolution (rows out, coalesced over the channels), a scaled
+// LDS transpose makes the NCHW map; backward: the scaled transpose of the gradient IS the full-resolution grid's gradient,
+// and every coarse grid gathers its own (tent weights, fixed order: reproducible).
+struct L2cGrids {
+    const float *g[4];
+    int ch[4], cw[4];
+    float ry[4], rx[4];
+    int n;
+};
+
+__device__ __forceinline__ void l2c_taps(int d, float r, int n_src, int &i0, int &i1, float &f) {
+    const float s = r * (float)d;                 // align_corners: source index = dst * (in - 1) / (out - 1)
+    i0 = (int)s;
+    if (i0 > n_src - 1) i0 = n_src - 1;
+    f = s - (float)i0;
+    i1 = i0 + (i0 < n_src - 1 ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(256)
+l2c_combine_rows_kernel(L2cGrids G, int n_img, int H, int W, int c4, float4 *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n_img * H * W * c4) return;
+    const int c = (int)(t % c4);
+    const int64_t pix = t / c4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), img = (int)(pix / ((int64_t)W * H));
+    float4 acc = reinterpret_cast<const float4 *>(G.g[0])[t];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {      // (static indices into the argument block)
+        if (s >= G.n) break;
+        int y0, y1, x0, x1;
+        float fy, fx;
+        l2c_taps(y, G.ry[s], G.ch[s], y0, y1, fy);
+        l2c_taps(x, G.rx[s], G.cw[s], x0, x1, fx);
+        const float4 *g = reinterpret_cast<const float4 *>(G.g[s]) + (int64_t)img * G.ch[s] * G.cw[s] * c4 + c;
+        const float4 a = g[((int64_t)y0 * G.cw[s] + x0) * c4], b = g[((int64_t)y0 * G.cw[s] + x1) * c4];
+        const float4 d = g[((int64_t)y1 * G.cw[s] + x0) * c4], e = g[((int64_t)y1 * G.cw[s] + x1) * c4];
+        const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+        acc.x += w00 * a.x + w01 * b.x + w10 * d.x + w11 * e.x;
+        acc.y += w00 * a.y + w01 * b.y + w10 * d.y + w11 * e.y;
+        acc.z += w00 * a.z + w01 * b.z + w10 * d.z + w11 * e.z;
+        acc.w += w00 * a.w + w01 * b.w + w10 * d.w + w11 * e.w;
+    }
+    out[t] = acc;
+}
+
+// d[img][i][j][c] = sum over the full-resolution pixels (y, x) that read cell (i, j): weight(y, i) * weight(x, j) * g[img][y][x][c],
+// with the weights of the forward's taps (both taps of a pixel may be the same clamped cell)
+__global__ void __launch_bounds__(256)
+l2c_combine_rows_bwd_kernel(const float4 *__restrict__ g, int n_img, int H, int W, int c4, int ch, int cw, float ry, float rx,
+                            float4 *__restrict__ d) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n_img * ch * cw * c4) return;
+    const int c = (int)(t % c4);
+    const int64_t cell = t / c4;
+    const int j = (int)(cell % cw), i = (int)((cell / cw) % ch), img = (int)(cell / ((int64_t)cw * ch));
+    // pixels whose source index lies in (i - 1, i + 1): a margin of one pixel either side, the exact test is inside
+    int ylo = 0, yhi = H - 1, xlo = 0, xhi = W - 1;
+    if (ry > 0.f) { ylo = max(0, (int)floorf((float)(i - 1) / ry) - 1); yhi = min(H - 1, (int)ceilf((float)(i + 1) / ry) + 1); }
+    if (rx > 0.f) { xlo = max(0, (int)floorf((float)(j - 1) / rx) - 1); xhi = min(W - 1, (int)ceilf((float)(j + 1) / rx) + 1); }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = ylo; y <= yhi; ++y) {
+        int y0, y1;
+        float fy;
+        l2c_taps(y, ry, ch, y0, y1, fy);
+        const float wy = (y0 == i ? 1.f - fy : 0.f) + (y1 == i ? fy : 0.f);
+        if (wy == 0.f) continue;
+        const float4 *row = g + ((int64_t)img * H + y) * W * c4 + c;
+        for (int x = xlo; x <= xhi; ++x) {
+            int x0, x1;
+            float fx;
+            l2c_taps(x, rx, cw, x0, x1, fx);
+            const float w = wy * ((x0 == j ? 1.f - fx : 0.f) + (x1 == j ? fx : 0.f));
+            if (w == 0.f) continue;
+            const float4 v = row[(int64_t)x * c4];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+    }
+    d[t] = acc;
 }
 
 // ---- MaxPool2d(kernel 3, stride 2, padding 1) of the SwiftNet stem (swiftnet.py: self.maxpool) -------------------------
@@ -408,6 +493,50 @@ int u2mkd_transpose_batched(const float *in, float *out, int32_t batch, int32_t 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, kTrTile), (unsigned)ceil_div(rows, kTrTile), (unsigned)batch),
                        dim3(256), 0, as_stream(s), in, out, rows, cols);
     return check_launch("u2mkd_transpose_batched");
+}
+
+int u2mkd_transpose_batched_scaled(const float *in, float *out, int32_t batch, int32_t rows, int32_t cols, float scale,
+                                   u2mkd_stream_t s) {
+    if (batch == 0 || rows == 0 || cols == 0) return 0;
+    U2_REQUIRE(in && out && batch > 0 && rows > 0 && cols > 0, "u2mkd_transpose_batched_scaled: bad arguments");
+    U2_REQUIRE(batch <= 65535 && ceil_div(rows, kTrTile) <= 65535, "u2mkd_transpose_batched_scaled: grid too large");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, kTrTile), (unsigned)ceil_div(rows, kTrTile), (unsigned)batch),
+                       dim3(256), 0, as_stream(s), in, out, rows, cols, scale);
+    return check_launch("u2mkd_transpose_batched_scaled");
+}
+
+static float l2c_ratio(int n_src, int n_dst) { return n_dst > 1 ? (float)(n_src - 1) / (float)(n_dst - 1) : 0.f; }
+
+int u2mkd_l2c_combine_forward(const float *g0, const float *g1, const float *g2, const float *g3, int32_t n_grids, int32_t n_img,
+                              int32_t h, int32_t w, int32_t c, int32_t ch1, int32_t cw1, int32_t ch2, int32_t cw2, int32_t ch3,
+                              int32_t cw3, float *out_rows, u2mkd_stream_t s) {
+    U2_REQUIRE(n_grids >= 1 && n_grids <= 4 && c > 0 && c % 4 == 0 && n_img > 0 && h > 0 && w > 0,
+               "u2mkd_l2c_combine_forward: %d grids of %d channels (1..4 grids, channels a multiple of 4)", n_grids, c);
+    U2_REQUIRE(g0 && out_rows && (n_grids < 2 || g1) && (n_grids < 3 || g2) && (n_grids < 4 || g3), "u2mkd_l2c_combine_forward: null pointer");
+    L2cGrids G;
+    const float *gp[4] = {g0, g1, g2, g3};
+    const int chs[4] = {h, ch1, ch2, ch3}, cws[4] = {w, cw1, cw2, cw3};
+    for (int i = 0; i < 4; ++i) {
+        G.g[i] = gp[i]; G.ch[i] = chs[i]; G.cw[i] = cws[i];
+        G.ry[i] = l2c_ratio(chs[i], h); G.rx[i] = l2c_ratio(cws[i], w);
+        U2_REQUIRE(i >= n_grids || (chs[i] > 0 && cws[i] > 0 && chs[i] <= h && cws[i] <= w), "u2mkd_l2c_combine_forward: grid %d is %dx%d", i, chs[i], cws[i]);
+    }
+    G.n = n_grids;
+    const int64_t total = (int64_t)n_img * h * w * (c / 4);
+    hipLaunchKernelGGL(l2c_combine_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), G, n_img, h, w,
+                       c / 4, reinterpret_cast<float4 *>(out_rows));
+    return check_launch("u2mkd_l2c_combine_forward");
+}
+
+int u2mkd_l2c_combine_backward(const float *g_rows, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t ch, int32_t cw,
+                               float *d_grid, u2mkd_stream_t s) {
+    U2_REQUIRE(g_rows && d_grid && c > 0 && c % 4 == 0 && n_img > 0 && h > 0 && w > 0 && ch > 0 && cw > 0 && ch <= h && cw <= w,
+               "u2mkd_l2c_combine_backward: bad arguments");
+    const int64_t total = (int64_t)n_img * ch * cw * (c / 4);
+    hipLaunchKernelGGL(l2c_combine_rows_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const float4 *>(g_rows), n_img, h, w, c / 4, ch, cw, l2c_ratio(ch, h), l2c_ratio(cw, w),
+                       reinterpret_cast<float4 *>(d_grid));
+    return check_launch("u2mkd_l2c_combine_backward");
 }
 
 int u2mkd_maxpool3s2_forward(const float *x, int64_t planes, int32_t h, int32_t w, float *y, uint8_t *code, u2mkd_stream_t s) {

@@ -116,8 +116,12 @@ def stream(device_index: int, role: str) -> torch.cuda.Stream:
     key = (device_index, _ALIAS.get(role, role))
     s = _STREAMS.get(key)
     if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=torch.device('cuda', device_index))
+        s = _STREAMS[key] = torch.cuda.Stream(device=torch.device('cuda', device_index), priority=_PRIORITY.get(key[1], 0))
     return s
+
+
+# U2MKD_STREAM_PRIORITY="camera=-1,teacher=0": HIP stream priority per role (-1 = high; default 0 everywhere).  A/B runs.
+_PRIORITY = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in _os.environ.get('U2MKD_STREAM_PRIORITY', '').split(',') if '=' in kv}
 
 
 _FAST_WAIT = _os.environ.get('U2MKD_FAST_STREAM_WAIT', '1') != '0'

@@ -20,6 +20,8 @@ plain torch formulations of the same maths are kept as ``l2c_scatter_torch`` / `
 (pinned against the reference's loops by the host-side tests); the product functions run on the
 HIP device only.
 Fusion modules keep the reference's parameter names."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -377,6 +379,49 @@ def _l2c_plan(pixel_coordinates, masks, ch, cw):
     return (fwd_row, fwd_w, seg_d), (bwd_pix, bwd_w, seg_s), n_dst
 
 
+# U2MKD_L2C_COMBINE=0: the grids of l2c_scatter up-sampled, added, divided and laid out NCHW by torch operations (rounds 1-5)
+_L2C_COMBINE = os.environ.get('U2MKD_L2C_COMBINE', '1') != '0'
+
+
+class _L2cCombine(torch.autograd.Function):
+    """mean over the scales of the grids up-sampled to the first one's size, as a plain NCHW map: ``grids[s]`` channel-last rows
+    [n_img * ch_s * cw_s, C] (fp32), ``sizes[s]`` = (ch_s, cw_s), sizes[0] = the map's (csrc/pixhead.hip: l2c_combine_*)."""
+
+    @staticmethod
+    def forward(ctx, n_img, sizes, *grids):
+        from . import _lib as L
+        n = len(grids)
+        (h, w), c = sizes[0], grids[0].shape[1]
+        ctx.meta = (n_img, sizes, c)
+        out = torch.empty(n_img, c, h, w, dtype=torch.float32, device=grids[0].device)
+        if n == 1:
+            rows = grids[0]
+        else:
+            rows = torch.empty(n_img * h * w, c, dtype=torch.float32, device=grids[0].device)
+            gp = [L.ptr(g) for g in grids] + [None] * (4 - n)
+            dims = [v for s in list(sizes[1:]) + [(0, 0)] * (4 - n) for v in s]
+            L.call('u2mkd_l2c_combine_forward', *gp, n, n_img, h, w, c, *dims, L.ptr(rows), L.stream())
+        L.call('u2mkd_transpose_batched_scaled', L.ptr(rows), L.ptr(out), n_img, h * w, c, 1.0 / n, L.stream())
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib as L
+        n_img, sizes, c = ctx.meta
+        n = len(sizes)
+        h, w = sizes[0]
+        g = g.contiguous()
+        g_rows = torch.empty(n_img * h * w, c, dtype=torch.float32, device=g.device)      # = the full-resolution grid's gradient
+        L.call('u2mkd_transpose_batched_scaled', L.ptr(g), L.ptr(g_rows), n_img, c, h * w, 1.0 / n, L.stream())
+        grads = [g_rows]
+        for ch, cw in sizes[1:]:
+            d = torch.empty(n_img * ch * cw, c, dtype=torch.float32, device=g.device)
+            L.call('u2mkd_l2c_combine_backward', L.ptr(g_rows), n_img, h, w, c, ch, cw, L.ptr(d), L.stream())
+            grads.append(d)
+        return (None, None) + tuple(grads)
+
+
 def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
     """LiDAR -> camera multi-scale scatter-mean (tsd_full.py:448-478).  point_feats [sum N_b, C];
     returns [B*ncam, C, ifh, ifw]: for scale s in 0..n_scales-1 the (masked) points of a camera are
@@ -388,8 +433,14 @@ def l2c_scatter(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales):
         return l2c_scatter_torch(point_feats, pixel_coordinates, masks, ifh, ifw, n_scales)   # torch ops on the GPU
     from .torchsparse.nn import functional as spf
     B, ncam, C = len(masks), masks[0].shape[0], point_feats.shape[1]
+    sizes = list(_l2c_grids(ifh, ifw, n_scales))
+    if (_L2C_COMBINE and point_feats.dtype == torch.float32 and not spf.bf16_rows() and 1 <= n_scales <= 4 and B * ncam <= 65535
+            and sizes[0] == (ifh, ifw)):
+        grids = [_SegmentMap.apply(point_feats, *l2c_plan(pixel_coordinates, masks, ch, cw)) for ch, cw in sizes]
+        if all(g.dtype == torch.float32 for g in grids):
+            return _L2cCombine.apply(B * ncam, tuple(sizes), *grids)
     total = None
-    for ch, cw in _l2c_grids(ifh, ifw, n_scales):
+    for ch, cw in sizes:
         fwd, bwd, n_dst = l2c_plan(pixel_coordinates, masks, ch, cw)
         grid = _SegmentMap.apply(point_feats, fwd, bwd, n_dst).view(B * ncam, ch, cw, C).permute(0, 3, 1, 2)
         up = grid if (ch, cw) == (ifh, ifw) else F.interpolate(grid, (ifh, ifw), mode='bilinear', align_corners=True)
