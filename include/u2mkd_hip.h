@@ -503,6 +503,14 @@ int u2mkd_ce_forward(const float *x, const int64_t *labels, int32_t ignore_index
                      float *stats, u2mkd_stream_t s);
 int u2mkd_ce_backward(const float *g_out, const float *stats, const float *x, const float *lse, const int64_t *labels,
                       int32_t ignore_index, int64_t n, int32_t c, float *dx, u2mkd_stream_t s);
+/* nn.KLDivLoss(reduction='batchmean') on log_softmax(s_logits) against softmax(t_logits[t_index]) (the `kl` term of the KD step,
+ * core/nusc_trainers.py:330-336, with the teacher -> student row re-indexing of :288-324 folded in: t_index [n] int64 or NULL =
+ * identity).  u2mkd_kl_forward: rows [n, 3] = (lse_s, lse_t, sum p_t) kept for the backward, partial: u2mkd_ce_partials(n) floats,
+ * stats[0] = the loss.  u2mkd_kl_backward: ds [n, c] = g_out[0] / n * (softmax(s) * sum p_t - p_t).                          */
+int u2mkd_kl_forward(const float *s_logits, const float *t_logits, const int64_t *t_index, int64_t n, int32_t c, float *rows,
+                     float *partial, float *stats, u2mkd_stream_t s);
+int u2mkd_kl_backward(const float *g_out, const float *s_logits, const float *t_logits, const int64_t *t_index, const float *rows,
+                      int64_t n, int32_t c, float *ds, u2mkd_stream_t s);
 /* ---- point <-> pixel index plans of the LiDAR / camera fusion (csrc/fusion.hip) --------------------------------------
  * replace the index arithmetic of the reference's Python loops over (sample, camera, scale): Feature_Gather + the
  * per-camera masked overwrite (core/models/fusion_blocks.py:241-254, spvcnn_swiftnet18_spformer_tsd_full.py:482-495) and

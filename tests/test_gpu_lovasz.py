@@ -115,3 +115,26 @@ def test_fused_cross_entropy_equals_torchs(hip, n, c, frac_ignored):
         losses._FUSED_CE = old
     assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
     assert float((xb.grad - xc.grad).abs().max()) <= 1e-6 * float(xc.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c,indexed', [(80000, 17, True), (777, 17, False), (65, 5, True), (1, 3, False)])
+def test_fused_kl_matches_torch(n, c, indexed, monkeypatch):
+    """losses.kl_div_logits (csrc/lovasz.hip: kl_forward / kl_backward, the teacher's rows re-indexed inside the pass) against
+    nn.KLDivLoss(reduction='batchmean')(log_softmax(s), softmax(t[index])): value and the gradient of the student's logits."""
+    from u2mkd_amd import losses
+    torch.manual_seed(n + c)
+    s0 = (3.0 * torch.randn(n, c, device='cuda'))
+    t = (3.0 * torch.randn(n + 13 if indexed else n, c, device='cuda'))
+    t[0, 0] = 80.0                      # a row whose other probabilities underflow to 0 (xlogy's 0 log 0 = 0)
+    idx = torch.randint(0, t.shape[0], (n,), device='cuda') if indexed else None
+    crit = torch.nn.KLDivLoss(reduction='batchmean')
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(losses, '_FUSED_KL', fused)
+        s = s0.clone().requires_grad_(True)
+        loss = losses.kl_div_logits(s, t, idx, crit)
+        (2.5 * loss).backward()
+        out[fused] = (float(loss), s.grad.clone())
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * max(1.0, abs(out[False][0])), (out[True][0], out[False][0])
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-6 * max(float(out[False][1].abs().max()), 1e-12) + 1e-9

@@ -177,6 +177,8 @@ SIGNATURES = {
     'u2mkd_ce_partials': (_i64, [_i64]),
     'u2mkd_ce_forward': (C.c_int, [_p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
     'u2mkd_ce_backward': (C.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
+    'u2mkd_kl_forward': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    'u2mkd_kl_backward': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     'u2mkd_lovasz_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
     'u2mkd_csr_build': (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p]),
     'u2mkd_devoxelize_plan_workspace_bytes': (C.c_size_t, [_i64, _i64]),

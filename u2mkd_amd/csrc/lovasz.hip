@@ -197,6 +197,71 @@ ce_backward_kernel(const float *__restrict__ g, const float *__restrict__ stats,
     dx[t] = d;
 }
 
+// ---- KL divergence of two logit matrices, reduction 'batchmean' (nn.KLDivLoss on log_softmax(student) / softmax(teacher),
+// core/nusc_trainers.py:330-336) ---------------------------------------------------------------------------------------------
+// As torch operations: an index_select of the teacher's rows, log_softmax, softmax, kl_div's point-wise kernel and a sum (then
+// five more in the backward), all on the critical stream between the forward and the backward.  One pass per direction:
+//   kl_forward_kernel   per row lse_s, lse_t, sum p_t (saved) and sum_c p_t ((t_c - lse_t) - (s_c - lse_s)); the teacher's row
+//                       is t[idx[p]] when an index is given; per-workgroup partials, fixed-order finish -> stats[0] = sum / P
+//   kl_backward_kernel  ds = g / P * (exp(s - lse_s) * sum p_t - p_t): kl_div's and log_softmax's backward, composed
+__global__ void __launch_bounds__(kCeThreads)
+kl_forward_kernel(const float *__restrict__ s, const float *__restrict__ t, const int64_t *__restrict__ idx, int64_t P, int C,
+                  float *__restrict__ rows /*[P][3]*/, float *__restrict__ partial /*[grid][2]*/) {
+    const int64_t p = (int64_t)blockIdx.x * kCeThreads + threadIdx.x;
+    float loss = 0.f;
+    if (p < P) {
+        const float *sr = s + p * C, *tr = t + (idx ? idx[p] : p) * C;
+        float ms = sr[0], mt = tr[0];
+        for (int c = 1; c < C; ++c) { ms = fmaxf(ms, sr[c]); mt = fmaxf(mt, tr[c]); }
+        float es = 0.f, et = 0.f;
+        for (int c = 0; c < C; ++c) { es += expf(sr[c] - ms); et += expf(tr[c] - mt); }
+        const float ls = ms + logf(es), lt = mt + logf(et);
+        float sp = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float lpt = tr[c] - lt, pt = expf(lpt);
+            sp += pt;
+            if (pt > 0.f) loss += pt * (lpt - (sr[c] - ls));      // (xlogy: 0 where the target is 0)
+        }
+        rows[3 * p] = ls; rows[3 * p + 1] = lt; rows[3 * p + 2] = sp;
+    }
+    __shared__ float s_l[kCeThreads / 64];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) loss += __shfl_xor(loss, off);
+    if ((threadIdx.x & 63) == 0) s_l[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+        partial[2 * blockIdx.x + 1] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+kl_finish_kernel(const float *__restrict__ partial, int n, float inv_rows, float *__restrict__ stats) {
+    __shared__ double s_l[256];
+    double l = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) l += partial[2 * i];
+    s_l[threadIdx.x] = l;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s_l[threadIdx.x] += s_l[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[0] = (float)(s_l[0] * (double)inv_rows);
+}
+
+__global__ void __launch_bounds__(kCeThreads)
+kl_backward_kernel(const float *__restrict__ g, const float *__restrict__ s, const float *__restrict__ t,
+                   const int64_t *__restrict__ idx, const float *__restrict__ rows, int64_t P, int C, float inv_rows,
+                   float *__restrict__ ds) {
+    const int64_t e = (int64_t)blockIdx.x * kCeThreads + threadIdx.x;
+    if (e >= P * C) return;
+    const int64_t p = e / C;
+    const int c = (int)(e - p * C);
+    const float ls = rows[3 * p], lt = rows[3 * p + 1], sp = rows[3 * p + 2];
+    const float pt = expf(t[(idx ? idx[p] : p) * C + c] - lt);
+    ds[e] = (g[0] * inv_rows) * (expf(s[e] - ls) * sp - pt);
+}
+
 }  // namespace u2mkd
 
 using namespace u2mkd;
@@ -255,6 +320,23 @@ int u2mkd_ce_forward(const float *x, const int64_t *labels, int32_t ignore_index
     hipLaunchKernelGGL(ce_forward_kernel, dim3(grid), dim3(kCeThreads), 0, as_stream(s), x, labels, ignore_index, n, c, lse, partial);
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, as_stream(s), partial, grid, stats);
     return check_launch("u2mkd_ce_forward");
+}
+
+int u2mkd_kl_forward(const float *s_logits, const float *t_logits, const int64_t *t_index, int64_t n, int32_t c, float *rows,
+                     float *partial, float *stats, u2mkd_stream_t s) {
+    U2_REQUIRE(n > 0 && c > 0 && s_logits && t_logits && rows && partial && stats, "u2mkd_kl_forward: bad arguments");
+    const int grid = (int)ceil_div(n, kCeThreads);
+    hipLaunchKernelGGL(kl_forward_kernel, dim3(grid), dim3(kCeThreads), 0, as_stream(s), s_logits, t_logits, t_index, n, c, rows, partial);
+    hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(256), 0, as_stream(s), partial, grid, 1.f / (float)n, stats);
+    return check_launch("u2mkd_kl_forward");
+}
+
+int u2mkd_kl_backward(const float *g_out, const float *s_logits, const float *t_logits, const int64_t *t_index, const float *rows,
+                      int64_t n, int32_t c, float *ds, u2mkd_stream_t s) {
+    U2_REQUIRE(n > 0 && c > 0 && g_out && s_logits && t_logits && rows && ds, "u2mkd_kl_backward: bad arguments");
+    hipLaunchKernelGGL(kl_backward_kernel, dim3((unsigned)ceil_div(n * c, kCeThreads)), dim3(kCeThreads), 0, as_stream(s), g_out,
+                       s_logits, t_logits, t_index, rows, n, c, 1.f / (float)n, ds);
+    return check_launch("u2mkd_kl_backward");
 }
 
 int u2mkd_ce_backward(const float *g_out, const float *stats, const float *x, const float *lse, const int64_t *labels,

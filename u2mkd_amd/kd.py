@@ -26,7 +26,7 @@ from .lidar.point_voxel import (initial_voxelize, point_to_voxel, prepare_geomet
 from .torchsparse.nn import functional as spf
 from .lidar.sphereformer import SphereFormer
 from .lidar.spvcnn_spformer import SPVCNN_SPFORMER
-from .losses import MixLovaszCrossEntropy
+from .losses import MixLovaszCrossEntropy, kl_div_logits
 from .torchsparse import PointTensor
 from .torchsparse import nn as spnn
 
@@ -559,6 +559,11 @@ def teacher_to_student(x_t, inverse_map, inds_s, num_pts, num_vox_t, keyframe_ma
     """Re-index a per-teacher-voxel tensor to the student's voxels:
     ``x_t[inv][keyframe][inds]`` per sample (core/nusc_trainers.py:288-324), as ONE gather:
     the composed index is built from the per-sample offsets, no Python-side tensor slicing."""
+    return x_t.index_select(0, teacher_to_student_index(inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full))
+
+
+def teacher_to_student_index(inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full=None):
+    """The composed row index of ``teacher_to_student`` (int64 [student voxels])."""
     idx = []
     cur_v = cur_p = 0
     for n_p, n_v, inds in zip(num_pts, num_vox_t, inds_s):
@@ -568,7 +573,7 @@ def teacher_to_student(x_t, inverse_map, inds_s, num_pts, num_vox_t, keyframe_ma
         idx.append(inv[inds[0]] + cur_v)
         cur_v += n_v
         cur_p += n_p
-    return x_t.index_select(0, torch.cat(idx))
+    return torch.cat(idx) if len(idx) > 1 else idx[0]
 
 
 class KDCriterion(nn.Module):
@@ -585,16 +590,16 @@ class KDCriterion(nn.Module):
 def kd_losses(outputs, targets, fov_mask, inverse_map, inds_s, num_pts, num_vox_t, crit: KDCriterion,
               keyframe_mask_full=None):
     """Loss terms and total of the KD step (core/nusc_trainers.py:288-358)."""
-    x_vox_t2s = teacher_to_student(outputs['t']['x_vox'], inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full)
-    feat_t2s = teacher_to_student(outputs['t']['pts_feats'][0], inverse_map, inds_s, num_pts, num_vox_t,
-                                  keyframe_mask_full)
+    # (the teacher -> student row index once for both re-indexed tensors; the logits' re-indexing happens inside the KL pass)
+    t2s = teacher_to_student_index(inverse_map, inds_s, num_pts, num_vox_t, keyframe_mask_full)
+    feat_t2s = outputs['t']['pts_feats'][0].index_select(0, t2s)
     x_vox, x_pix = outputs['stu']['x_vox'], outputs['stu']['x_pix']
     ld = {'ce_vox': crit.lovasz(x_vox, targets),
           # the reference compacts the rows a camera sees (`x_pix[fov_mask]`, two host synchronisations right after
           # the forward); the criterion drops ignore-labelled rows itself (mask-based Lovasz, CE ignore_index), so
           # the rows outside the field of view take the ignore label instead: same value, same gradient, no sync
           'ce_pix': crit.lovasz(x_pix, torch.where(fov_mask, targets, torch.full_like(targets, crit.lovasz.ignore_index))),
-          'kl': crit.kl(F.log_softmax(x_vox, dim=1), F.softmax(x_vox_t2s.detach(), dim=1)),
+          'kl': kl_div_logits(x_vox.float(), outputs['t']['x_vox'].float(), t2s, crit.kl),
           'mse': outputs['stu']['mse_loss']}
     pts_feat_s = outputs['stu']['pts_feats'][0]
     if crit.mse_norm_feat:

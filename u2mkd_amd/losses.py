@@ -153,6 +153,52 @@ class _CrossEntropyFunction(torch.autograd.Function):
         return dx, None, None
 
 
+class _KLDivFunction(torch.autograd.Function):
+    """nn.KLDivLoss(reduction='batchmean')(log_softmax(s, 1), softmax(t[index], 1)) on [P, C] fp32 logits, the target side
+    without gradient, as one pass per direction (csrc/lovasz.hip: kl_forward / kl_backward)."""
+
+    @staticmethod
+    def forward(ctx, s, t, index):
+        from . import _lib as L
+        s, t = s.contiguous(), t.contiguous()
+        index = index.contiguous() if index is not None else None
+        P, C = s.shape
+        rows = torch.empty(P, 3, dtype=torch.float32, device=s.device)
+        partial = torch.empty(int(L.load().u2mkd_ce_partials(P)), dtype=torch.float32, device=s.device)
+        stats = torch.empty(1, dtype=torch.float32, device=s.device)
+        L.call('u2mkd_kl_forward', L.ptr(s), L.ptr(t), L.ptr(index), P, C, L.ptr(rows), L.ptr(partial), L.ptr(stats), L.stream())
+        ctx.save_for_backward(s, t, index, rows)
+        return stats[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib as L
+        s, t, index, rows = ctx.saved_tensors
+        P, C = s.shape
+        g = g.contiguous().float().reshape(1)
+        ds = torch.empty_like(s)
+        L.call('u2mkd_kl_backward', L.ptr(g), L.ptr(s), L.ptr(t), L.ptr(index), L.ptr(rows), P, C, L.ptr(ds), L.stream())
+        return ds, None, None
+
+
+_FUSED_KL = os.environ.get('U2MKD_FUSED_KL', '1') != '0'      # 0: log_softmax / softmax / nn.KLDivLoss as torch runs them
+
+
+def kl_div_logits(s, t, index=None, criterion=None):
+    """``criterion(log_softmax(s, 1), softmax(t[index], 1))`` for an nn.KLDivLoss(reduction='batchmean') -- the KD step's `kl` term
+    (t detached); on the device in one pass per direction."""
+    if (_FUSED_KL and s.is_cuda and s.dim() == 2 and s.dtype == torch.float32 and t.dtype == torch.float32 and s.shape[0] > 0
+            and (criterion is None or (isinstance(criterion, nn.KLDivLoss) and criterion.reduction == 'batchmean'
+                                       and not criterion.log_target))
+            and (index is None or (index.dtype == torch.int64 and index.shape[0] == s.shape[0]))
+            and (index is not None or t.shape == s.shape) and t.shape[1] == s.shape[1]):
+        return _KLDivFunction.apply(s, t.detach(), index)
+    tt = t.detach() if index is None else t.detach().index_select(0, index)
+    crit = criterion if criterion is not None else nn.KLDivLoss(reduction='batchmean')
+    return crit(F.log_softmax(s, dim=1), F.softmax(tt, dim=1))
+
+
 _FUSED_CE = os.environ.get('U2MKD_FUSED_CE', '1') != '0'      # 0: torch's log_softmax + nll_loss (the formulation the fused pass is tested against)
 
 
