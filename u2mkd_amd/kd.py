@@ -225,9 +225,13 @@ class StudentMSP2IFM(nn.Module):
         z0 = voxel_to_point(x0, z, nearest=False)
         vox_feats = [point_to_voxel(x0, z0)]
         img_feats, mse_loss, pts_feats = [], [], []
+        x_im_ready = None
         for idx in range(n_stage):
             if idx > 0:
-                cam = on_side(lambda: cam_stage(x_im, idx), x_im)      # queued ahead of this stage's LiDAR kernels
+                # queued ahead of this stage's LiDAR kernels, ordered behind the L2C block that made x_im -- NOT behind the
+                # camera -> LiDAR half of the previous fusion point that the main stream has queued since (gather, learner,
+                # fusion MLPs, point_to_voxel: none of it feeds the camera branch; U2MKD_CAMERA_FORK_EARLY=0: behind all of it)
+                cam = on_side(lambda: cam_stage(x_im, idx), x_im, after=x_im_ready if _CAMERA_FORK_EARLY else None)
             vox_out = self.vox_downs[idx](vox_feats[idx])
             if ahead is not None:
                 coord_xyz, batch = ahead['tokens'][idx]
@@ -246,6 +250,7 @@ class StudentMSP2IFM(nn.Module):
             # LiDAR -> camera: multi-scale scatter-mean of the point features into every camera's map
             l2c_feat_map = l2c_scatter(pts_feat.F, pixel_coordinates, masks, ifh, ifw, n_stage - idx)
             x_im, skip = self._piece('l2c%d' % idx)(l2c_feat_map, skip)
+            x_im_ready = fork.mark()
             img_feats.append(skip)
 
             # camera -> LiDAR: bilinear gather, later cameras overwrite; points no camera sees take the
@@ -465,6 +470,7 @@ _TEACHER_STREAM = os.environ.get('U2MKD_TEACHER_STREAM', '1') != '0'
 # issues it (NOTES N10).  Kept as a switch: it is the measurement that settles the question.
 # (U2MKD_PREFETCH_PLANS=2: the teacher's kernel-map schedules a step ahead too; they are off the student's chain either way)
 _TEACHER_TAG = 'kd_teacher' if os.environ.get('U2MKD_PREFETCH_PLANS', '0') == '2' else None
+_CAMERA_FORK_EARLY = os.environ.get('U2MKD_CAMERA_FORK_EARLY', '1') != '0'
 _TEACHER_AHEAD = int(os.environ.get('U2MKD_TEACHER_AHEAD', '0'))
 
 

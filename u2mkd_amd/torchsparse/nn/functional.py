@@ -1219,6 +1219,25 @@ def _dense(x, w_oc_ic, bias=None):
     return y[:n]
 
 
+_VIEW_NODES = ('SqueezeBackward0', 'SqueezeBackward1', 'UnsqueezeBackward0', 'ViewBackward0', 'UnsafeViewBackward0', 'AliasBackward0')
+_LEAF_VIEWS = os.environ.get('U2MKD_DEFER_VIEW_WGRAD', '1') != '0'      # 0: only a leaf parameter's own weight gradient is deferred
+
+
+def _leaf_behind_view(w):
+    """The leaf parameter ``w`` is a pure reshaping view of (same elements, same memory, contiguous both, ONE metadata-only
+    autograd node between them), else None."""
+    base = w._base
+    fn = w.grad_fn
+    if (not _LEAF_VIEWS or base is None or fn is None or not base.is_leaf or not base.requires_grad or base.numel() != w.numel()
+            or base.data_ptr() != w.data_ptr() or base.dtype != w.dtype or not base.is_contiguous() or not w.is_contiguous()
+            or type(fn).__name__ not in _VIEW_NODES or len(fn.next_functions) != 1):
+        return None
+    acc = fn.next_functions[0][0]
+    if acc is None or type(acc).__name__ != 'AccumulateGrad' or getattr(acc, 'variable', None) is not base:
+        return None
+    return base
+
+
 class LinearFunction(Function):
     """y = x @ weight.T + bias (nn.Linear semantics) on the conv pipeline: forward and input
     gradient on the pair kernel's dense mode, weight gradient on the pair-list wgrad kernel."""
@@ -1228,8 +1247,12 @@ class LinearFunction(Function):
         L.require_cuda(x, weight)
         param = weight
         weight = weight.contiguous().float()
-        # the saved weight IS the parameter (no contiguous / cast copy): its gradient goes to AccumulateGrad untouched
-        ctx.weight_is_param = param.is_leaf and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype
+        # the saved weight IS the parameter (no contiguous / cast copy): its gradient goes to AccumulateGrad untouched -- or it is a
+        # pure reshaping view of one (`conv.weight.squeeze(-1)` of a k = 1 Conv1d: fusion_blocks.py's Conv1d layers evaluated on
+        # rows), whose gradient reaches the parameter's AccumulateGrad through a metadata-only node
+        owner = param if param.is_leaf else _leaf_behind_view(param)
+        ctx.weight_owner = owner if (owner is not None and weight.data_ptr() == param.data_ptr() and weight.dtype == param.dtype) else None
+        ctx.weight_is_param = ctx.weight_owner is not None
         # the bias IS a leaf parameter (not a padded / cast copy): its gradient, too, is read by nobody before the backward ends
         ctx.bias_param = bias if (bias is not None and bias.is_leaf and bias.requires_grad and bias.dtype == torch.float32) else None
         ctx.overlap_ok = _deferred_overlap_ok()
@@ -1269,8 +1292,8 @@ class LinearFunction(Function):
             nbytes = lib.u2mkd_conv_wgrad_pairs_workspace_bytes(n, cout, cin, 1)
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
             gw = torch.empty_like(weight)
-            side, deferred_join = _wgrad_side(weight, ctx.weight_is_param, g.device, ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan,
-                                               allow=getattr(ctx, 'overlap_ok', True))
+            side, deferred_join = _wgrad_side(ctx.weight_owner if ctx.weight_is_param else weight, ctx.weight_is_param, g.device,
+                                               ctx.needs_input_grad[0], x, g, ws, gw, pairs, plan, allow=getattr(ctx, 'overlap_ok', True))
             L.call('u2mkd_conv_wgrad_pairs_bf16' if b16 else 'u2mkd_conv_wgrad_pairs', L.ptr(g), cout, L.ptr(x), cin,
                    L.ptr(pairs), L.ptr(plan), n, 1, 0, L.ptr(ws), nbytes, L.ptr(gw), side.cuda_stream if side is not None else L.stream())
         if ctx.needs_input_grad[0] and ctx.x3:
