@@ -200,6 +200,14 @@ int u2mkd_conv_forward_tiles_ep(const float *in, int64_t n_in, int32_t cin, cons
                                 const int32_t *n_items, int64_t n_out, int32_t k, int32_t kflip, int32_t arith,
                                 const float *scale /*[cout]*/, const float *shift /*[cout]*/, const float *res /*[n_out,cout] or NULL*/,
                                 int32_t relu, float *out, u2mkd_stream_t s);
+/* u2mkd_pairs_gather_sum with the BatchNorm statistics of its output taken in the store (spnn.Conv3d -> spnn.BatchNorm in
+ * training mode, core/models/build_blocks.py:25-31,59-70): partial [ceil(n_rows / slab_rows)][2][cout] = (mean, M2) per slab of
+ * u2mkd_pairs_gather_sum_stats_slab_rows() consecutive output rows, for u2mkd_bn_train_forward_from_partial.  cout: a multiple
+ * of 4 in 8..512 (u2mkd_pairs_gather_sum_stats_supported).                                                                */
+int32_t u2mkd_pairs_gather_sum_stats_slab_rows(void);
+int32_t u2mkd_pairs_gather_sum_stats_supported(int32_t cout);
+int u2mkd_pairs_gather_sum_stats(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,
+                                 float *partial, u2mkd_stream_t s);
 int u2mkd_pairs_gather_sum_ep(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, const float *scale,
                               const float *shift, const float *res, int32_t relu, float *out, u2mkd_stream_t s);
 /* Tuning / A-B experiments only (tools/ab_*.py), NOT part of the drop-in boundary:
@@ -547,6 +555,14 @@ int u2mkd_bn_train_forward(const float *x /*[n,c]*/, int64_t n, int32_t c, const
                            u2mkd_stream_t s);
 /* the same with nn.BatchNorm's step counter: *num_batches_tracked (device int64, may be NULL) += 1 in the
  * statistics kernel instead of a one-element launch of its own per layer and step                        */
+/* Train-mode forward FROM slab partials computed elsewhere: `partial` [ceil(n / slab_rows)][2][c] = per slab of slab_rows
+ * consecutive rows the per-channel (mean, centred second moment), as u2mkd_pairs_gather_sum_stats writes them in the producing
+ * convolution's store.  Merge (running statistics, step counter) + normalise (+ residual, + ReLU): the statistics pass of
+ * u2mkd_bn_train_forward_res is not run.  fp32 rows.                                                                        */
+int u2mkd_bn_train_forward_from_partial(const float *x, const float *res, int64_t n, int32_t c, const float *gamma,
+                                        const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                        int64_t *num_batches_tracked, int32_t relu, const float *partial, int32_t slab_rows,
+                                        float *mean /*[c] out*/, float *invstd /*[c] out*/, float *y, u2mkd_stream_t s);
 int u2mkd_bn_train_forward_counted(const float *x /*[n,c]*/, int64_t n, int32_t c, const float *gamma, const float *beta,
                                    float eps, float momentum, float *running_mean, float *running_var,
                                    int64_t *num_batches_tracked, int32_t relu, float *partial, float *mean /*[c] out*/,

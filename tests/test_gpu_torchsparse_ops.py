@@ -697,3 +697,45 @@ def test_optimizer_step_refreshes_every_fragment_image_in_one_launch(F, monkeypa
         for m in net:
             b = m(b)
     assert torch.equal(a.F, b.F)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout', [(9000, 128, 128), (3001, 64, 160), (70, 256, 96), (20000, 96, 96)])
+def test_conv_store_takes_the_batch_norm_statistics(n, cin, cout, monkeypatch):
+    """spnn.Conv3d -> spnn.BatchNorm (-> ReLU) in training mode: the wide layers' gather-sum writes the BatchNorm's slab
+    statistics with its output (u2mkd_pairs_gather_sum_stats) and the BatchNorm starts at its merge step
+    (u2mkd_bn_train_forward_from_partial).  Against the same sequence with U2MKD_CONV_BN_STATS off (the BatchNorm's own statistics
+    pass): outputs, running statistics, step counter, and every gradient."""
+    import torch.nn as nn
+    from u2mkd_amd import torchsparse as ts
+    from u2mkd_amd.lidar.blocks import FusedSequential
+    from u2mkd_amd.torchsparse import nn as spnn
+    from u2mkd_amd.torchsparse.nn import functional as F
+    from u2mkd_amd import _lib as L
+    rng = np.random.default_rng(n)
+    pts = np.unique(rng.integers(0, 40, size=(n, 3)), axis=0)
+    coords = torch.from_numpy(np.concatenate([pts, np.zeros((len(pts), 1), dtype=np.int64)], 1)).int().cuda()
+    feats0 = (torch.randn(len(pts), cin, device='cuda') * 2.0 + 0.7)
+    torch.manual_seed(5)
+    seq0 = FusedSequential(spnn.Conv3d(cin, cout, kernel_size=3), spnn.BatchNorm(cout), spnn.ReLU(True)).cuda().train()
+    state = {k: v.clone() for k, v in seq0.state_dict().items()}
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, '_CONV_BN_STATS', on)
+        seq = FusedSequential(spnn.Conv3d(cin, cout, kernel_size=3), spnn.BatchNorm(cout), spnn.ReLU(True)).cuda().train()
+        seq.load_state_dict(state)
+        seen = []
+        real = L.call
+        monkeypatch.setattr(L, 'call', lambda name, *a: (seen.append(name), real(name, *a))[1])
+        x = ts.SparseTensor(feats0.clone().requires_grad_(True), coords)
+        y = seq(x)
+        monkeypatch.setattr(L, 'call', real)
+        (y.F * torch.linspace(0.5, 1.5, cout, device='cuda')).sum().backward()
+        res[on] = (y.F.detach(), x.F.grad.detach(), seq[0].kernel.grad.detach(), seq[1].weight.grad.detach(), seq[1].bias.grad.detach(),
+                   seq[1].running_mean.clone(), seq[1].running_var.clone(), int(seq[1].num_batches_tracked))
+        took = 'u2mkd_pairs_gather_sum_stats' in seen and 'u2mkd_bn_train_forward_from_partial' in seen
+        assert took == (on and F._pairs_mode(cin, cout, len(pts))), (on, sorted(set(seen)))
+    assert res[True][7] == res[False][7] == 1
+    for a, b in zip(res[True][:7], res[False][:7]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale

@@ -53,6 +53,9 @@ SIGNATURES = {
     'u2mkd_conv_forward_tiles': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     'u2mkd_conv_forward_tiles_ep': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p]),
     'u2mkd_pairs_gather_sum_ep': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p]),
+    'u2mkd_pairs_gather_sum_stats_slab_rows': (_i32, []),
+    'u2mkd_pairs_gather_sum_stats_supported': (_i32, [_i32]),
+    'u2mkd_pairs_gather_sum_stats': (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_debug_conv_tile_pairs_stamps': (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     'u2mkd_debug_wgrad_stamps': (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     'u2mkd_conv_forward_pairs': (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
@@ -95,6 +98,7 @@ SIGNATURES = {
     'u2mkd_bn_train_forward_counted': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     'u2mkd_bn_eval_forward': (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_train_forward_res': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    'u2mkd_bn_train_forward_from_partial': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     'u2mkd_bn_eval_forward_res': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p, _i32, _p, _p, _p]),
     'u2mkd_bn_backward_res': (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     'u2mkd_bn_backward': (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),

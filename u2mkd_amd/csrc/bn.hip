@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256)
 bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n, int c, float eps,
                          float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
                          float *__restrict__ mean_out, float *__restrict__ invstd_out, float *__restrict__ m2_out,
-                         int64_t *__restrict__ num_batches_tracked = nullptr) {
+                         int64_t *__restrict__ num_batches_tracked = nullptr, int slab_rows = kBnSlabRows) {
     // nn.BatchNorm's step counter (a separate one-element add_ launch per layer otherwise)
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     __shared__ float s_n[kBnFinLanes][kBnFinCh], s_m[kBnFinLanes][kBnFinCh], s_q[kBnFinLanes][kBnFinCh];
@@ -114,7 +114,7 @@ bn_stats_finalize_kernel(const float *__restrict__ partial, int nslab, int64_t n
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int b = b0 + u * kBnFinLanes;
-                nb[u] = b < nslab ? (float)min((int64_t)kBnSlabRows, n - (int64_t)b * kBnSlabRows) : 0.f;
+                nb[u] = b < nslab ? (float)min((int64_t)slab_rows, n - (int64_t)b * slab_rows) : 0.f;
                 mb[u] = b < nslab ? partial[(size_t)b * 2 * c + ch] : 0.f;
                 qb[u] = b < nslab ? partial[(size_t)b * 2 * c + c + ch] : 0.f;
             }
@@ -441,6 +441,28 @@ static int bn_train_forward_impl(const T *x, const T *res, int64_t n, int32_t c,
     return check_launch("u2mkd_bn_train_forward");
 }
 
+// train-mode forward from slab partials somebody else computed (the gather-sum of the producing convolution:
+// u2mkd_pairs_gather_sum_stats, slabs of `slab_rows` rows): merge + apply
+static int bn_train_forward_from_partial_impl(const float *x, const float *res, int64_t n, int32_t c, const float *gamma,
+                                              const float *beta, float eps, float momentum, float *running_mean,
+                                              float *running_var, int64_t *num_batches_tracked, int32_t relu,
+                                              const float *partial, int32_t slab_rows, float *mean, float *invstd, float *y,
+                                              u2mkd_stream_t s) {
+    U2_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, "u2mkd_bn_train_forward_from_partial: c=%d must be a multiple of 4 in 4..1024", c);
+    U2_REQUIRE(n > 0 && slab_rows > 0, "u2mkd_bn_train_forward_from_partial: n=%lld rows in slabs of %d", (long long)n, slab_rows);
+    U2_REQUIRE(x && partial && mean && invstd && y, "u2mkd_bn_train_forward_from_partial: null pointer");
+    U2_REQUIRE(res == nullptr || relu, "u2mkd_bn_train_forward_from_partial: a residual input is only fused with the ReLU form");
+    hipStream_t st = as_stream(s);
+    const int64_t nslab = ceil_div(n, (int64_t)slab_rows);
+    U2_REQUIRE(nslab < ((int64_t)1 << 31), "u2mkd_bn_train_forward_from_partial: too many slabs");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((unsigned)ceil_div(c, kBnFinCh)), dim3(256), 0, st, partial, (int)nslab, n, c,
+                       eps, momentum, running_mean, running_var, mean, invstd, (float *)nullptr, num_batches_tracked, (int)slab_rows);
+    int64_t total4 = n * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, x, total4, c / 4, mean,
+                       invstd, gamma, beta, relu, y, res);
+    return check_launch("u2mkd_bn_train_forward_from_partial");
+}
+
 template <typename T>
 static int bn_eval_forward_impl(const T *x, const T *res, int64_t n, int32_t c, const float *gamma, const float *beta,
                                 float eps, const float *running_mean, const float *running_var, int32_t relu, float *invstd,
@@ -560,6 +582,14 @@ int u2mkd_bn_train_forward_res(const float *x, const float *res, int64_t n, int3
                                u2mkd_stream_t s) {
     return bn_train_forward_impl<float>(x, res, n, c, gamma, beta, eps, momentum, running_mean, running_var,
                                         num_batches_tracked, relu, partial, mean, invstd, y, s);
+}
+
+int u2mkd_bn_train_forward_from_partial(const float *x, const float *res, int64_t n, int32_t c, const float *gamma,
+                                        const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                        int64_t *num_batches_tracked, int32_t relu, const float *partial, int32_t slab_rows,
+                                        float *mean, float *invstd, float *y, u2mkd_stream_t s) {
+    return bn_train_forward_from_partial_impl(x, res, n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                                              num_batches_tracked, relu, partial, slab_rows, mean, invstd, y, s);
 }
 
 int u2mkd_bn_train_forward_counted(const float *x, int64_t n, int32_t c, const float *gamma, const float *beta, float eps,

@@ -902,6 +902,84 @@ pairs_gather_sum_kernel(const float *__restrict__ y, const int32_t *__restrict__
     reinterpret_cast<float4 *>(out)[r * c4 + c] = acc;
 }
 
+// The same sum with the BatchNorm statistics of its output taken in the store (round 6): a workgroup owns kGsSlabRows consecutive
+// output rows -- rl = 256 / c4 row lanes x c4 float4 columns, 32 / rl rows per thread, their sums kept in registers -- and writes,
+// next to the rows, the slab's per-channel (mean, centred second moment M2) in the layout of bn.hip's slab partials
+// (`partial` [slabs][2][C]; rows of slab b = min(kGsSlabRows, n_rows - b * kGsSlabRows)): the BatchNorm that follows a wide
+// convolution then starts at its merge step (u2mkd_bn_train_forward_from_partial) -- its statistics pass, one launch and two
+// reads of the feature matrix per layer, is gone (no statistics pass at all: -2.3 ms of KD step, NOTES N10.13).  Two passes over
+// the registers (mean first, then M2 around it): cancellation-safe like the pass it replaces, fixed order: reproducible.
+constexpr int kGsSlabRows = 32, kGsMaxIt = 16;
+
+__global__ void __launch_bounds__(256)
+pairs_gather_sum_stats_kernel(const float *__restrict__ y, const int32_t *__restrict__ pos, int64_t n_rows, int K, int c4,
+                              float *__restrict__ out, float *__restrict__ partial) {
+    __shared__ float4 red[256];
+    const int rl = 256 / c4;                          // row lanes (c4 <= 128: rl >= 2, at most kGsMaxIt rows per thread)
+    const int ry = threadIdx.x / c4, j = threadIdx.x - ry * c4;
+    const bool lane_on = ry < rl;
+    const int64_t r0 = (int64_t)blockIdx.x * kGsSlabRows;
+    const int rows = (int)min((int64_t)kGsSlabRows, n_rows - r0);
+    float4 vals[kGsMaxIt];
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < kGsMaxIt; ++it) {
+        const int rr = it * rl + ry;
+        vals[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_on && rr < rows) {
+            const int64_t r = r0 + rr;
+            const int32_t *pr = pos + r * K;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                int p[8];
+                float4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p[i] = k0 + i < K ? pr[k0 + i] : -1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = p[i] >= 0 ? reinterpret_cast<const float4 *>(y)[(int64_t)p[i] * c4 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+            }
+            reinterpret_cast<float4 *>(out)[r * c4 + j] = acc;
+            vals[it] = acc;
+            sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;
+        }
+    }
+    if (lane_on) red[ry * c4 + j] = sum;
+    __syncthreads();
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane_on) {
+        for (int g = 0; g < rl; ++g) {
+            const float4 v = red[g * c4 + j];
+            mean.x += v.x; mean.y += v.y; mean.z += v.z; mean.w += v.w;
+        }
+        const float inv = 1.f / (float)rows;
+        mean.x *= inv; mean.y *= inv; mean.z *= inv; mean.w *= inv;
+    }
+    __syncthreads();
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < kGsMaxIt; ++it) {
+        if (lane_on && it * rl + ry < rows) {
+            const float dx = vals[it].x - mean.x, dy = vals[it].y - mean.y, dz = vals[it].z - mean.z, dw = vals[it].w - mean.w;
+            m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+        }
+    }
+    if (lane_on) red[ry * c4 + j] = m2;
+    __syncthreads();
+    if (lane_on && ry == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < rl; ++g) {
+            const float4 v = red[g * c4 + j];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        float *p = partial + (size_t)blockIdx.x * 2 * (4 * c4);
+        *reinterpret_cast<float4 *>(p + 4 * j) = mean;
+        *reinterpret_cast<float4 *>(p + 4 * c4 + 4 * j) = t;
+    }
+}
+
 // the same over bf16 rows (bf16 storage, BASELINE.json configs[4]): 8 channels = 16 bytes per thread, fp32 sum in ascending
 // offset order, one rounding to bf16 at the store
 __global__ void __launch_bounds__(256)
@@ -1275,6 +1353,22 @@ int u2mkd_pairs_gather_sum(const float *y, const int32_t *pos, int64_t n_rows, i
     hipLaunchKernelGGL(pairs_gather_sum_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(s), y, pos,
                        n_rows, k, c4, out, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0);
     return check_launch("u2mkd_pairs_gather_sum");
+}
+
+int32_t u2mkd_pairs_gather_sum_stats_slab_rows(void) { return kGsSlabRows; }
+
+int32_t u2mkd_pairs_gather_sum_stats_supported(int32_t cout) { return cout >= 8 && cout % 4 == 0 && cout <= 512; }
+
+int u2mkd_pairs_gather_sum_stats(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, float *out,
+                                 float *partial, u2mkd_stream_t s) {
+    if (n_rows == 0) return 0;
+    U2_REQUIRE(y && pos && out && partial, "u2mkd_pairs_gather_sum_stats: null pointer");
+    U2_REQUIRE(k > 0 && u2mkd_pairs_gather_sum_stats_supported(cout), "u2mkd_pairs_gather_sum_stats: cout=%d must be a multiple of 4 in 8..512", cout);
+    const int64_t slabs = ceil_div(n_rows, (int64_t)kGsSlabRows);
+    U2_REQUIRE(slabs < ((int64_t)1 << 31), "u2mkd_pairs_gather_sum_stats: too many rows");
+    hipLaunchKernelGGL(pairs_gather_sum_stats_kernel, dim3((unsigned)slabs), dim3(256), 0, as_stream(s), y, pos, n_rows, k, cout / 4,
+                       out, partial);
+    return check_launch("u2mkd_pairs_gather_sum_stats");
 }
 
 int u2mkd_pairs_gather_sum_ep(const float *y, const int32_t *pos, int64_t n_rows, int32_t k, int32_t cout, const float *scale,

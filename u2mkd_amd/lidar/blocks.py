@@ -39,6 +39,7 @@ _FOLDABLE_BN = ('BatchNorm', 'SparseSyncBatchNorm')      # (eval mode: a SyncBat
 
 # BatchNorm flavours whose forward is spf.batch_norm (plain and the SyncBatchNorm conversions of point_voxel.py)
 _FUSABLE_BN = ('BatchNorm', 'PointBatchNorm1d', 'SparseSyncBatchNorm', 'PointSyncBatchNorm1d')
+_STATS_BN = ('BatchNorm',)      # the BatchNorm whose statistics pass a convolution's store can stand in for (spnn.BatchNorm, not synchronised)
 
 
 class FusedSequential(nn.Sequential):
@@ -54,6 +55,7 @@ class FusedSequential(nn.Sequential):
         # inference: spnn.Conv3d -> eval-mode BatchNorm (-> ReLU | + residual -> ReLU) as ONE convolution whose store applies the
         # folded affine (functional.conv_eval_affine): the frozen teacher's ~49 BatchNorm passes disappear
         fold = _FOLD_EVAL_BN and isinstance(x, SparseTensor) and not torch.is_grad_enabled()
+        stats = None
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
@@ -68,21 +70,37 @@ class FusedSequential(nn.Sequential):
                     x = y
                     i += 2 if last_bn or not relu else 3
                     continue
+            if (isinstance(m, spnn.Conv3d) and m.bias is None and type(nxt).__name__ in _STATS_BN and nxt.training
+                    and isinstance(x, SparseTensor) and torch.is_grad_enabled() and spf.conv_bn_stats_enabled()):
+                # spnn.Conv3d -> train-mode BatchNorm: the convolution's store may take the BatchNorm's slab statistics with it
+                # (functional.BnStats: the wide layers' gather-sum does), the BatchNorm then starts at its merge step
+                stats = spf.BnStats()
+                spf.BN_STATS_SINK[0] = stats
+                try:
+                    x = m(x)
+                finally:
+                    spf.BN_STATS_SINK[0] = None
+                i += 1
+                continue
+            st, stats = stats, None            # (the statistics of the tensor the previous module produced, if it left any)
             fusable = (type(m).__name__ in _FUSABLE_BN and type(nxt) in (spnn.ReLU, nn.ReLU))
             if residual is not None and i == len(mods) - 1:
                 assert type(m).__name__ in _FUSABLE_BN, type(m).__name__
                 r = residual.F if isinstance(residual, SparseTensor) else residual
                 if isinstance(x, SparseTensor):
-                    x = fapply(x, spf.batch_norm, m, True, r)
+                    x = fapply(x, spf.batch_norm, m, True, r, st)
                 else:
-                    x = spf.batch_norm(x, m, True, r)
+                    x = spf.batch_norm(x, m, True, r, st)
                 i += 1
             elif fusable:
                 if isinstance(x, SparseTensor):
-                    x = fapply(x, spf.batch_norm, m, True)
+                    x = fapply(x, spf.batch_norm, m, True, None, st)
                 else:
-                    x = spf.batch_norm(x, m, True)
+                    x = spf.batch_norm(x, m, True, None, st)
                 i += 2
+            elif st is not None and type(m).__name__ in _STATS_BN:
+                x = fapply(x, spf.batch_norm, m, False, None, st)      # (BatchNorm without a ReLU behind it)
+                i += 1
             elif isinstance(m, PointLinear) and type(nxt).__name__ in _FUSABLE_BN and nxt.training and not isinstance(x, SparseTensor):
                 x = spf.linear(x, m.weight, m.bias, bias_feeds_batchnorm=True)     # (its bias gradient is identically zero)
                 i += 1

@@ -667,6 +667,42 @@ class TileSchedule:
         return out
 
 
+class BnStats:
+    """What a convolution's store can hand the train-mode BatchNorm that follows it: slab partials of its output (``partial``
+    [slabs][2][C], slabs of ``slab_rows`` rows) and which tensor they describe (``of`` = (address, rows, channels))."""
+    __slots__ = ('partial', 'slab_rows', 'of')
+
+    def __init__(self):
+        self.partial = self.slab_rows = self.of = None
+
+    def describes(self, x):
+        return self.partial is not None and self.of == (x.data_ptr(), x.shape[0], x.shape[1]) and x.dtype == torch.float32
+
+
+# the sink a caller opens around ONE convolution whose output goes straight into a train-mode BatchNorm (lidar.blocks.
+# FusedSequential); a store that can take the statistics fills it (PairSchedule.run), anything else leaves it empty and the
+# BatchNorm runs its own statistics pass.  U2MKD_CONV_BN_STATS=1 opens it; default 0: built, verified
+# (tests/test_gpu_torchsparse_ops.py::test_conv_store_takes_the_batch_norm_statistics), and measured without gain -- 29 of the
+# KD student's BatchNorms lose their statistics launch, the step stays within +-0.15 ms: the gather-sum that owns 32-row slabs
+# is 4-18 us slower than the flat one and the merge reads four times the partials (tools/exp_gather_sum_stats.py, NOTES N10.14).
+BN_STATS_SINK = [None]
+_CONV_BN_STATS = os.environ.get('U2MKD_CONV_BN_STATS', '0') != '0'
+
+
+def conv_bn_stats_enabled():
+    return _CONV_BN_STATS
+
+
+# where the gather-sum with statistics + the BatchNorm from partials beat gather-sum + the BatchNorm's own three launches
+# (tools/exp_gather_sum_stats.py, MI355X): a workgroup of the statistics form owns 32 rows, so on long, narrow outputs it has a
+# third of the plain form's workgroups in flight -- 80 000 x 96: 54 -> 69 us the pair, 32 000 x 256: 63 -> 60, 16 000 x 256: 47 -> 45
+_STATS_MAX_ROWS, _STATS_MIN_COUT = (int(v) for v in os.environ.get('U2MKD_CONV_BN_STATS_SHAPES', '100000000,8').split(','))
+
+
+def _stats_in_store(n_rows, cout):
+    return n_rows <= _STATS_MAX_ROWS and cout >= _STATS_MIN_COUT and bool(L.load().u2mkd_pairs_gather_sum_stats_supported(cout))
+
+
 class PairSchedule:
     """Offset-grouped pair list of a kernel map (u2mkd_pairs_build): every (input i, output j)
     pair, grouped by offset and padded to 128 entries per offset (two 64-pair tiles).  A conv is two launches: one
@@ -727,6 +763,14 @@ class PairSchedule:
             sc, sh, res, relu = epilogue
             L.call('u2mkd_pairs_gather_sum_ep', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(sc), L.ptr(sh), L.ptr(res), int(relu),
                    L.ptr(out), st)
+            return out
+        sink = BN_STATS_SINK[0]
+        if sink is not None and sink.partial is None and out.dtype == torch.float32 and _stats_in_store(n_rows, cout):
+            # a train-mode BatchNorm follows (lidar.blocks.FusedSequential asked): its slab statistics in this store
+            rows = int(L.load().u2mkd_pairs_gather_sum_stats_slab_rows())
+            partial = torch.empty((n_rows + rows - 1) // rows * 2 * cout, dtype=torch.float32, device=out.device)
+            L.call('u2mkd_pairs_gather_sum_stats', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), L.ptr(partial), st)
+            sink.partial, sink.slab_rows, sink.of = partial, rows, (out.data_ptr(), n_rows, cout)
             return out
         L.call('u2mkd_pairs_gather_sum', L.ptr(y), L.ptr(pos), n_rows, self.k, cout, L.ptr(out), st)
         return out
@@ -1598,7 +1642,7 @@ class BatchNormFunction(Function):
     csrc/bn.hip; statistics identical to nn.BatchNorm1d."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None, res=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, counter=None, res=None, stats=None):
         L.require_cuda(x)
         # bf16 storage: rows stay bf16 through the BatchNorm (as nn.BatchNorm1d passes half through under the
         # reference's amp), statistics / parameters / gradient sums fp32
@@ -1613,7 +1657,12 @@ class BatchNormFunction(Function):
             res = _rows(res, b16)
         y = torch.empty_like(x)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
-        if training:
+        if training and stats is not None and not b16:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            L.call('u2mkd_bn_train_forward_from_partial', L.ptr(x), L.ptr(res), n, c, L.ptr(gamma), L.ptr(beta), float(eps),
+                   float(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(counter), int(relu), L.ptr(stats.partial),
+                   int(stats.slab_rows), L.ptr(mean), L.ptr(invstd), L.ptr(y), L.stream())
+        elif training:
             slabs = L.load().u2mkd_bn_num_slabs(n)
             partial = torch.empty(max(slabs, 1) * 2 * c, dtype=torch.float32, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
@@ -1649,7 +1698,7 @@ class BatchNormFunction(Function):
         if dres is not None and dres.dtype != ctx.res_dtype:
             dres = dres.to(ctx.res_dtype)
         return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None,
-                None, None, None, None, None, None, None, dres)
+                None, None, None, None, None, None, None, dres, None)
 
 
 # SyncBatchNorm exchanges of the current process since the last reset: [calls, bytes sent per rank] per kind.  Counted where a
@@ -1788,7 +1837,7 @@ def _sync_group(bn):
 
 
 def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool = False,
-               residual: torch.Tensor = None) -> torch.Tensor:
+               residual: torch.Tensor = None, stats: 'BnStats' = None) -> torch.Tensor:
     """nn.BatchNorm1d semantics (training or eval, running statistics, momentum=None =
     cumulative average) on a [N, C] tensor, optionally fused with ReLU; ``residual`` [N, C] (with relu):
     relu(bn(x) + residual), the tail of a ResidualBlock (build_blocks.py:80-83), in the same pass."""
@@ -1815,6 +1864,9 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, relu:
         return SyncBatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, factor, bn.eps, relu, sync[0], sync[1], residual, counter)
     if training and x.shape[0] < 2:
         raise ValueError(f'Expected more than 1 value per channel when training, got input size {tuple(x.shape)}')
+    if stats is not None and training and stats.describes(x) and not bf16_rows() and (residual is None or residual.dtype == torch.float32):
+        # the slab statistics came with x (the producing convolution's store): merge + apply, no statistics pass
+        return BatchNormFunction.apply(x, bn.weight, bn.bias, rm, rv, training, factor, bn.eps, relu, counter, residual, stats)
     h = _HOST if _HOST is not False else host_ops()
     if h is not None and x.dtype == torch.float32 and x.is_cuda and x.shape[0] > 0 and not bf16_rows() \
             and (residual is None or residual.dtype == torch.float32):
