@@ -82,24 +82,26 @@ class FusedSequential(nn.Sequential):
                     spf.BN_STATS_SINK[0] = None
                 i += 1
                 continue
-            st, stats = stats, None            # (the statistics of the tensor the previous module produced, if it left any)
+            st, stats = (stats if stats is not None and stats.partial is not None else None), None      # (what the previous module's store left)
             fusable = (type(m).__name__ in _FUSABLE_BN and type(nxt) in (spnn.ReLU, nn.ReLU))
             if residual is not None and i == len(mods) - 1:
                 assert type(m).__name__ in _FUSABLE_BN, type(m).__name__
                 r = residual.F if isinstance(residual, SparseTensor) else residual
+                kw = {'stats': st} if st is not None else {}      # (the call's shape stays batch_norm(x, bn, relu, residual) otherwise)
                 if isinstance(x, SparseTensor):
-                    x = fapply(x, spf.batch_norm, m, True, r, st)
+                    x = fapply(x, spf.batch_norm, m, True, r, **kw)
                 else:
-                    x = spf.batch_norm(x, m, True, r, st)
+                    x = spf.batch_norm(x, m, True, r, **kw)
                 i += 1
             elif fusable:
+                kw = {'stats': st} if st is not None else {}
                 if isinstance(x, SparseTensor):
-                    x = fapply(x, spf.batch_norm, m, True, None, st)
+                    x = fapply(x, spf.batch_norm, m, True, **kw)
                 else:
-                    x = spf.batch_norm(x, m, True, None, st)
+                    x = spf.batch_norm(x, m, True, **kw)
                 i += 2
-            elif st is not None and type(m).__name__ in _STATS_BN:
-                x = fapply(x, spf.batch_norm, m, False, None, st)      # (BatchNorm without a ReLU behind it)
+            elif st is not None and st.partial is not None and type(m).__name__ in _STATS_BN:
+                x = fapply(x, spf.batch_norm, m, False, None, stats=st)      # (BatchNorm without a ReLU behind it)
                 i += 1
             elif isinstance(m, PointLinear) and type(nxt).__name__ in _FUSABLE_BN and nxt.training and not isinstance(x, SparseTensor):
                 x = spf.linear(x, m.weight, m.bias, bias_feeds_batchnorm=True)     # (its bias gradient is identically zero)
