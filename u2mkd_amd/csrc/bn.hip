@@ -112,9 +112,13 @@ bn_stats_partial_kernel(const T *__restrict__ x, int64_t n, int c, float *__rest
         const bool live = j < c4 && ry < rl;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
-            for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = ld4(x, (r0 + rr) * c4 + j);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            for (int rr0 = ry; rr0 < rows; rr0 += 8 * rl) {       // (eight rows' loads in flight per trip, summed in row order)
+                float4 vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    vv[u] = rr0 + u * rl < rows ? ld4(x, (r0 + rr0 + u * rl) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s.x += vv[u].x; s.y += vv[u].y; s.z += vv[u].z; s.w += vv[u].w; }
             }
         if (live) red[ry * c4 + (j % c4)] = s;
         __syncthreads();
@@ -130,10 +134,17 @@ bn_stats_partial_kernel(const T *__restrict__ x, int64_t n, int c, float *__rest
         __syncthreads();
         float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
-            for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = ld4(x, (r0 + rr) * c4 + j);
-                float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
-                m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+            for (int rr0 = ry; rr0 < rows; rr0 += 8 * rl) {
+                float4 vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    vv[u] = rr0 + u * rl < rows ? ld4(x, (r0 + rr0 + u * rl) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (rr0 + u * rl >= rows) break;
+                    float dx = vv[u].x - mean.x, dy = vv[u].y - mean.y, dz = vv[u].z - mean.z, dw = vv[u].w - mean.w;
+                    m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+                }
             }
         if (live) red[ry * c4 + (j % c4)] = m2;
         __syncthreads();
@@ -309,19 +320,32 @@ bn_bwd_partial_kernel(const T *__restrict__ dy, const T *__restrict__ x, int64_t
             float4 is = *reinterpret_cast<const float4 *>(invstd + 4 * j);
             float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + 4 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
             float4 b = beta ? *reinterpret_cast<const float4 *>(beta + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int rr = ry; rr < rows; rr += rl) {
-                float4 v = ld4(x, (r0 + rr) * c4 + j);
-                float4 d = ld4(dy, (r0 + rr) * c4 + j);
-                float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
-                if (relu) {
-                    const float4 rv = res ? ld4(res, (r0 + rr) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
-                    if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
-                    if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
-                    if (hw * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
+            // four rows' loads in flight per trip (the sums in the same row order: bitwise the same partials)
+            for (int rr0 = ry; rr0 < rows; rr0 += 4 * rl) {
+                float4 vv[4], dd[4], rr4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = rr0 + u * rl;
+                    const bool ok = rr < rows;
+                    vv[u] = ok ? ld4(x, (r0 + rr) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    dd[u] = ok ? ld4(dy, (r0 + rr) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rr4[u] = (ok && relu && res) ? ld4(res, (r0 + rr) * c4 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
-                s2.x += d.x * hx; s2.y += d.y * hy; s2.z += d.z * hz; s2.w += d.w * hw;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (rr0 + u * rl >= rows) break;
+                    const float4 v = vv[u], rv = rr4[u];
+                    float4 d = dd[u];
+                    float hx = (v.x - m.x) * is.x, hy = (v.y - m.y) * is.y, hz = (v.z - m.z) * is.z, hw = (v.w - m.w) * is.w;
+                    if (relu) {
+                        if (hx * g.x + b.x + rv.x <= 0.f) d.x = 0.f;
+                        if (hy * g.y + b.y + rv.y <= 0.f) d.y = 0.f;
+                        if (hz * g.z + b.z + rv.z <= 0.f) d.z = 0.f;
+                        if (hw * g.w + b.w + rv.w <= 0.f) d.w = 0.f;
+                    }
+                    s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+                    s2.x += d.x * hx; s2.y += d.y * hy; s2.z += d.z * hz; s2.w += d.w * hw;
+                }
             }
             red[ry * cw + jl] = s1;
             red[(rl + ry) * cw + jl] = s2;
